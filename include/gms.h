@@ -1,0 +1,141 @@
+/*
+ * gms.h -- C ABI of the MI355X-native GMS (Grid-based Motion Statistics) match filter.
+ *
+ * Drop-in boundary for ONE reference call:
+ *
+ *   cv::xfeatures2d::matchGMS(size1, size2, keypoints1, keypoints2, matches1to2, matchesGMS,
+ *                             withRotation=false, withScale=false, thresholdFactor=6.0)
+ *
+ * as called by the reference at
+ *   SfM-GMS/SfM-GMS/FeatureMatchUtil.cpp:69      (withRotation=true, withScale=true, 6.0)
+ *   SfM-GMS/SfM-GMS/DisparityUtil.cpp:149, :299  (defaults: false, false, 6.0)
+ * and implemented (binary only) in SfM-GMS/bin/opencv_xfeatures2d452.dll, export ordinal 884,
+ * RVA 0x48280 (opencv_contrib xfeatures2d 4.5.2, class GMSMatcher).
+ *
+ * Everything here is plain C: pointers, sizes, PODs. No torch, no OpenCV, no C++ types.
+ * The work behind every entry point is done by hand-written HIP kernels for gfx950; there is no
+ * CPU fallback in this library (a missing/failed GPU is an error code, never a silent detour).
+ */
+#ifndef MI355_GMS_H
+#define MI355_GMS_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- error codes (the reference signals nothing: void return, UB on bad input) ------------- */
+#define GMS_OK             0
+#define GMS_ERR_BAD_ARG   (-1) /* null pointer / negative size / zero image dimension            */
+#define GMS_ERR_DOMAIN    (-2) /* input outside the domain on which the reference is defined     */
+#define GMS_ERR_HIP       (-3) /* a HIP runtime call failed (gms_last_hip_error() has the code)  */
+#define GMS_ERR_NO_DEVICE (-4) /* no usable gfx950 device                                        */
+#define GMS_ERR_CAPACITY  (-5) /* m exceeds what this build supports (see gms_max_matches())     */
+
+/* ---- PODs, bit-compatible with the reference's element types ------------------------------- */
+
+/* cv::KeyPoint: 28 bytes, stride 0x1c at DLL@0x1800485d4; only pt.x (+0) and pt.y (+4) are read. */
+typedef struct gms_keypoint {
+    float x, y;      /* pt                                                      */
+    float size;      /* ignored by GMS                                          */
+    float angle;     /* ignored                                                 */
+    float response;  /* ignored                                                 */
+    int32_t octave;  /* ignored                                                 */
+    int32_t class_id;/* ignored                                                 */
+} gms_keypoint;
+
+/* cv::DMatch: 16 bytes, stride 0x10; queryIdx (+0) and trainIdx (+4) are read (DLL@0x180046aa3),
+ * the whole struct is copied verbatim to the output (DLL@0x18004836a). */
+typedef struct gms_dmatch {
+    int32_t queryIdx;
+    int32_t trainIdx;
+    int32_t imgIdx;   /* opaque payload, carried through */
+    float   distance; /* opaque payload, carried through */
+} gms_dmatch;
+
+/* One image pair of a batch: which two resident frames, and where its putative matches live. */
+typedef struct gms_pair {
+    int32_t frame_a;    /* index of the query ("left") frame  -> keypoints1 / size1 */
+    int32_t frame_b;    /* index of the train ("right") frame -> keypoints2 / size2 */
+    int32_t m;          /* number of putative matches of this pair                  */
+    int32_t reserved;   /* must be 0                                                */
+    int64_t match_off;  /* element offset of the pair's first gms_dmatch in the match (and out) array */
+} gms_pair;
+
+/* Per-pair result record. */
+typedef struct gms_pair_result {
+    int32_t n_inliers;  /* number of gms_dmatch written for this pair                           */
+    int32_t best_scale; /* 0..4 index into {1, 1/2, 1/sqrt2, sqrt2, 2}; -1 if no hypothesis won  */
+    int32_t best_rot;   /* 1..8 rotation pattern; -1 if no hypothesis won                        */
+    int32_t status;     /* GMS_OK or GMS_ERR_DOMAIN for this pair                                */
+} gms_pair_result;
+
+typedef struct gms_ctx gms_ctx;
+
+/* ---- one-shot drop-in ------------------------------------------------------------------------
+ * Same contract as the reference call: inputs borrowed, `out` must have room
+ * for m entries, receives the surviving matches verbatim and in input order, *n_out their number.
+ * Host pointers. Uses a lazily created process-wide context on device 0.
+ * Replaces: cv::xfeatures2d::matchGMS (FeatureMatchUtil.cpp:69; DisparityUtil.cpp:149,299). */
+int gms_match(const gms_keypoint* kp1, int n1, int w1, int h1,
+              const gms_keypoint* kp2, int n2, int w2, int h2,
+              const gms_dmatch* matches, int m,
+              int with_rotation, int with_scale, double threshold_factor,
+              gms_dmatch* out, int* n_out);
+
+/* Same, on an explicit context; additionally reports the winning hypothesis (may be NULL). */
+int gms_match_ctx(gms_ctx* ctx,
+                  const gms_keypoint* kp1, int n1, int w1, int h1,
+                  const gms_keypoint* kp2, int n2, int w2, int h2,
+                  const gms_dmatch* matches, int m,
+                  int with_rotation, int with_scale, double threshold_factor,
+                  gms_dmatch* out, int* n_out, gms_pair_result* result);
+
+/* ---- context -------------------------------------------------------------------------------- */
+int  gms_ctx_create(int device, gms_ctx** out_ctx);
+int  gms_ctx_destroy(gms_ctx* ctx);
+/* Launch on a caller-owned hipStream_t (pass it as void*); NULL selects the context's own stream. */
+int  gms_ctx_set_stream(gms_ctx* ctx, void* hip_stream);
+int  gms_ctx_synchronize(gms_ctx* ctx);
+
+/* ---- device-resident batch path (throughput API) ---------------------------------------------
+ * All d_* pointers are device pointers on the context's device; calls are stream-ordered on the
+ * context's stream and do not synchronise.
+ *
+ * gms_normalize_device: GMSMatcher::normalizePoints (DLL@0x180048420) for every keypoint of every
+ * frame: d_pts[2*i] = kp[i].x / (float)w[frame], d_pts[2*i+1] = kp[i].y / (float)h[frame]
+ * (IEEE fp32 divide). d_frame_off has n_frames+1 entries (keypoint offsets), d_wh 2*n_frames ints. */
+int gms_normalize_device(gms_ctx* ctx, const gms_keypoint* d_kp, const int64_t* d_frame_off,
+                         const int32_t* d_wh, int n_frames, int64_t total_kp, float* d_pts);
+
+/* gms_filter_device: the GMS filter proper (GMSMatcher ctor..getInlierMask..copy-out, DLL@0x180046900,
+ * 0x180047dc0, 0x180048630, 0x180048d10, 0x180048340) for n_pairs independent pairs.
+ *   d_pts/d_frame_off  normalised keypoint table from gms_normalize_device
+ *   d_pairs            n_pairs descriptors; max_m >= every d_pairs[i].m (host-known upper bound)
+ *   d_matches          putative matches, pair i at [match_off, match_off+m)
+ *   d_out              same offsets/capacity; pair i's survivors are written at d_out[match_off ...]
+ *   d_results          n_pairs result records
+ *   d_mask             optional (may be NULL): per-match inlier byte (0/1) at the match's offset */
+int gms_filter_device(gms_ctx* ctx, const float* d_pts, const int64_t* d_frame_off, int n_frames,
+                      const gms_pair* d_pairs, int n_pairs, int max_m,
+                      const gms_dmatch* d_matches,
+                      int with_rotation, int with_scale, double threshold_factor,
+                      gms_dmatch* d_out, gms_pair_result* d_results, uint8_t* d_mask);
+
+/* ---- introspection --------------------------------------------------------------------------- */
+int         gms_max_matches(void);        /* largest m per pair this build accepts                 */
+int         gms_last_hip_error(void);     /* last hipError_t seen by this thread's calls           */
+const char* gms_error_string(int code);
+const char* gms_version(void);
+
+/* Test hook (no production use): evaluates thresh = sqrt(T / n) * factor > score in device fp64 for
+ * `count` (T, n, score) triples, so the tests can pin the device's div/sqrt/mul against IEEE.
+ * Host pointers; out[i] = 1 iff the cell would be rejected. */
+int gms_selftest_threshold(gms_ctx* ctx, const int32_t* T, const int32_t* n, const int32_t* score,
+                           double factor, int count, uint8_t* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI355_GMS_H */

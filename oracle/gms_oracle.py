@@ -1,0 +1,91 @@
+"""oracle/gms_oracle.py -- TEST INFRASTRUCTURE, NOT PRODUCT.
+
+ctypes loader for oracle/libgms_oracle.so (the C restatement of the reference's matchGMS; parity
+unpinned -- see gms_ref.c). Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg
+may import this module."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_lib = None
+
+KEYPOINT_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),
+                           ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")])
+DMATCH_DTYPE = np.dtype([("queryIdx", "<i4"), ("trainIdx", "<i4"), ("imgIdx", "<i4"), ("distance", "<f4")])
+PAIR_DTYPE = np.dtype([("frame_a", "<i4"), ("frame_b", "<i4"), ("m", "<i4"), ("reserved", "<i4"),
+                       ("match_off", "<i8")])
+RESULT_DTYPE = np.dtype([("n_inliers", "<i4"), ("best_scale", "<i4"), ("best_rot", "<i4"), ("status", "<i4")])
+
+
+def build():
+    subprocess.check_call(["make", "-C", _HERE, "-s"])
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = os.path.join(_HERE, "libgms_oracle.so")
+    if not os.path.exists(path):
+        build()
+    lib = C.CDLL(path)
+    vp, i32, dbl = C.c_void_p, C.c_int, C.c_double
+    lib.gms_ref_match.argtypes = [vp, i32, i32, i32, vp, i32, i32, i32, vp, i32, i32, i32, dbl, vp,
+                                  C.POINTER(i32), vp, vp]
+    lib.gms_ref_match.restype = i32
+    lib.gms_ref_batch.argtypes = [vp, vp, vp, i32, vp, i32, vp, i32, i32, dbl, vp, vp, vp, i32]
+    lib.gms_ref_batch.restype = i32
+    lib.gms_ref_grid_index_left.argtypes = [C.c_float, C.c_float, i32]
+    lib.gms_ref_grid_index_left.restype = i32
+    lib.gms_ref_grid_index_right.argtypes = [C.c_float, C.c_float, i32, i32]
+    lib.gms_ref_grid_index_right.restype = i32
+    lib.gms_ref_right_grid.argtypes = [i32, C.POINTER(i32), C.POINTER(i32)]
+    lib.gms_ref_right_grid.restype = None
+    lib.gms_ref_normalize.argtypes = [C.c_float, i32]
+    lib.gms_ref_normalize.restype = C.c_float
+    lib.gms_ref_threshold_rejects.argtypes = [i32, i32, i32, dbl]
+    lib.gms_ref_threshold_rejects.restype = i32
+    lib.gms_ref_scale_ratio.argtypes = [i32]
+    lib.gms_ref_scale_ratio.restype = dbl
+    _lib = lib
+    return lib
+
+
+def match(size1, size2, kp1, kp2, matches, with_rotation=False, with_scale=False, threshold_factor=6.0):
+    """Returns (rc, out, mask, result)."""
+    lib = load()
+    kp1 = np.ascontiguousarray(kp1, dtype=KEYPOINT_DTYPE)
+    kp2 = np.ascontiguousarray(kp2, dtype=KEYPOINT_DTYPE)
+    mt = np.ascontiguousarray(matches, dtype=DMATCH_DTYPE)
+    out = np.zeros(max(len(mt), 1), dtype=DMATCH_DTYPE)
+    mask = np.zeros(max(len(mt), 1), dtype=np.uint8)
+    res = np.zeros(1, dtype=RESULT_DTYPE)
+    n_out = C.c_int(0)
+    rc = lib.gms_ref_match(kp1.ctypes.data, len(kp1), int(size1[0]), int(size1[1]),
+                           kp2.ctypes.data, len(kp2), int(size2[0]), int(size2[1]),
+                           mt.ctypes.data, len(mt), int(bool(with_rotation)), int(bool(with_scale)),
+                           float(threshold_factor), out.ctypes.data, C.byref(n_out), mask.ctypes.data,
+                           res.ctypes.data)
+    return rc, out[: n_out.value].copy(), mask[: len(mt)].copy(), res[0]
+
+
+def batch(kp_all, frame_off, wh, pairs, matches, with_rotation=False, with_scale=False, threshold_factor=6.0,
+          n_threads=1):
+    """Returns (n_failed, out, results, mask) over a batch of pairs."""
+    lib = load()
+    kp_all = np.ascontiguousarray(kp_all, dtype=KEYPOINT_DTYPE)
+    frame_off = np.ascontiguousarray(frame_off, dtype=np.int64)
+    wh = np.ascontiguousarray(wh, dtype=np.int32)
+    pairs = np.ascontiguousarray(pairs, dtype=PAIR_DTYPE)
+    mt = np.ascontiguousarray(matches, dtype=DMATCH_DTYPE)
+    out = np.zeros(max(len(mt), 1), dtype=DMATCH_DTYPE)
+    mask = np.zeros(max(len(mt), 1), dtype=np.uint8)
+    res = np.zeros(max(len(pairs), 1), dtype=RESULT_DTYPE)
+    failed = lib.gms_ref_batch(kp_all.ctypes.data, frame_off.ctypes.data, wh.ctypes.data, len(frame_off) - 1,
+                               pairs.ctypes.data, len(pairs), mt.ctypes.data, int(bool(with_rotation)),
+                               int(bool(with_scale)), float(threshold_factor), out.ctypes.data,
+                               res.ctypes.data, mask.ctypes.data, int(n_threads))
+    return failed, out[: len(mt)], res[: len(pairs)], mask[: len(mt)]

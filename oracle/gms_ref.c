@@ -1,0 +1,388 @@
+/*
+ * oracle/gms_ref.c -- TEST INFRASTRUCTURE, NOT PRODUCT.
+ *
+ * CPU restatement of cv::xfeatures2d::matchGMS as shipped in the reference's
+ * SfM-GMS/bin/opencv_xfeatures2d452.dll (opencv_contrib xfeatures2d 4.5.2, class GMSMatcher).
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this; the product
+ * path (sfm-gms_amd/csrc) never links, calls or falls back to it.
+ *
+ * PARITY UNPINNED: the reference holds no tests, golden vectors or recorded outputs for this path
+ *  and its implementation exists only as a Windows PE32+ DLL that cannot
+ * be loaded here. This file follows the DLL's disassembly address by address (cited per function,
+ * "DLL@0x..." = virtual address in that DLL, image base 0x180000000) and keeps the reference's
+ * dense 400 x N_right motion matrix and loop order on purpose, so that it is an obviously faithful,
+ * structurally independent checker for the sparse GPU formulation. The constant tables below are
+ * checked byte for byte against the DLL by tests/test_oracle_pins.py when /root/reference exists.
+ *
+ * Build: gcc -O2 -ffp-contract=off -fno-fast-math (x86-64 SSE2: float ops are true fp32, no x87).
+ */
+#include "gms_ref.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* mRotationPatterns: DLL .rdata 0x18012f520 (file offset 0x12df20), 8 x 9 int32. */
+const int gms_ref_rotation_patterns[8][9] = {
+    {1, 2, 3, 4, 5, 6, 7, 8, 9}, {4, 1, 2, 7, 5, 3, 8, 9, 6}, {7, 4, 1, 8, 5, 2, 9, 6, 3},
+    {8, 7, 4, 9, 5, 1, 6, 3, 2}, {9, 8, 7, 6, 5, 4, 3, 2, 1}, {6, 9, 8, 3, 5, 7, 2, 1, 4},
+    {3, 6, 9, 2, 5, 8, 1, 4, 7}, {2, 3, 6, 1, 5, 9, 4, 7, 8}};
+
+/* mScaleRatios: DLL .data 0x1802c5008 = {1.0, 0.5, <dyn>, <dyn>, 2.0}; the two dynamic slots are
+ * 1/sqrt(2) and sqrt(2), written by the static initialiser. */
+double gms_ref_scale_ratio(int s)
+{
+    switch (s) {
+    case 0: return 1.0;
+    case 1: return 1.0 / 2;
+    case 2: return 1.0 / sqrt(2.0);
+    case 3: return sqrt(2.0);
+    default: return 2.0;
+    }
+}
+
+/* cvFloor(float) / cvFloor(double) as compiled into the DLL: cvttss2si / cvttsd2si, then
+ * "i -= (i > v)" (DLL@0x180047be3-0x180047c01, 0x180047c65-0x180047c77). */
+static int floor_f32(float v)
+{
+    int i = (int)v;
+    return i - ((float)i > v);
+}
+static int floor_f64(double v)
+{
+    int i = (int)v;
+    return i - ((double)i > v);
+}
+/* cvRound(double): cvtsd2si, round-half-even in the default MXCSR mode (DLL@0x180048c10). */
+static int round_f64(double v) { return (int)lrint(v); }
+
+typedef struct {
+    int n_matches;
+    float *p1, *p2;            /* normalised points, 2 floats each            (normalizePoints) */
+    int n1, n2;
+    const gms_dmatch* matches; /* (queryIdx, trainIdx) read in place            (convertMatches) */
+    int wl, hl, n_left;        /* left grid 20 x 20                     (DLL@0x180046ac6-ace)   */
+    int wr, hr, n_right;       /* right grid, per scale                                (setScale) */
+    int* nb_left;              /* [n_left][9]                                                  */
+    int* nb_right;             /* [n_right][9]                                                 */
+    int* motion;               /* [n_left][n_right] dense                                      */
+    int* n_per_cell_left;      /* [n_left]                                                     */
+    int* cell_pairs;           /* [n_left]                                                     */
+    int *pair_first, *pair_second; /* mvMatchPairs                                             */
+    unsigned char* mask;       /* mvbInlierMask                                                */
+    double threshold_factor;
+    int domain_error;
+} gms_ref_state;
+
+/* GMSMatcher::normalizePoints, DLL@0x180048420: cvtdq2ps on width/height, divss per coordinate. */
+static void normalize_points(const gms_keypoint* kp, int n, int width, int height, float* out)
+{
+    for (int i = 0; i < n; i++) {
+        out[2 * i + 0] = kp[i].x / (float)width;
+        out[2 * i + 1] = kp[i].y / (float)height;
+    }
+}
+
+/* GMSMatcher::getNB9 / initalizeNeighbors, DLL@0x180048030 / 0x180048180. */
+static void init_neighbors(int* nb, int gw, int gh)
+{
+    for (int idx = 0; idx < gw * gh; idx++) {
+        int* nb9 = nb + 9 * idx;
+        for (int k = 0; k < 9; k++) nb9[k] = -1;
+        int ix = idx % gw, iy = idx / gw;
+        for (int yi = -1; yi <= 1; yi++)
+            for (int xi = -1; xi <= 1; xi++) {
+                int xx = ix + xi, yy = iy + yi;
+                if (xx < 0 || xx >= gw || yy < 0 || yy >= gh) continue;
+                nb9[xi + 4 + yi * 3] = xx + yy * gw;
+            }
+    }
+}
+
+/* GMSMatcher::getGridIndexLeft, DLL@0x180047bc0-0x180047d55. The product (float)W * nx is rounded
+ * to fp32 (mulss) before it is widened (cvtps2pd) and 0.5 added in fp64 (addsd [0x18012dfc0]).
+ * One common bounds test for all four grid types: x >= W || y >= H -> -1; no lower-bound test. */
+static int grid_index_left(const gms_ref_state* st, const float* pt, int type)
+{
+    int x = 0, y = 0;
+    float fx = (float)st->wl * pt[0];
+    float fy = (float)st->hl * pt[1];
+    if (type == 1) {
+        x = floor_f32(fx);
+        y = floor_f32(fy);
+    } else if (type == 2) {
+        x = floor_f64((double)fx + 0.5);
+        y = floor_f32(fy);
+    } else if (type == 3) {
+        x = floor_f32(fx);
+        y = floor_f64((double)fy + 0.5);
+    } else if (type == 4) {
+        x = floor_f64((double)fx + 0.5);
+        y = floor_f64((double)fy + 0.5);
+    }
+    if (x >= st->wl || y >= st->hl) return -1;
+    return x + y * st->wl;
+}
+
+/* GMSMatcher::getGridIndexRight, DLL@0x180047d60 (inlined at 0x1800478e7): no bounds test. */
+static int grid_index_right(const gms_ref_state* st, const float* pt)
+{
+    int x = floor_f32((float)st->wr * pt[0]);
+    int y = floor_f32((float)st->hr * pt[1]);
+    return x + y * st->wr;
+}
+
+/* GMSMatcher::setScale, DLL@0x180048c10. */
+static int set_scale(gms_ref_state* st, int scale)
+{
+    st->wr = round_f64(st->wl * gms_ref_scale_ratio(scale));
+    st->hr = round_f64(st->hl * gms_ref_scale_ratio(scale));
+    st->n_right = st->wr * st->hr;
+    free(st->nb_right);
+    free(st->motion);
+    st->nb_right = (int*)malloc(sizeof(int) * 9 * (size_t)st->n_right);
+    st->motion = (int*)malloc(sizeof(int) * (size_t)st->n_left * (size_t)st->n_right);
+    if (!st->nb_right || !st->motion) return -1;
+    init_neighbors(st->nb_right, st->wr, st->hr);
+    return 0;
+}
+
+/* A coordinate is inside the parity domain when the float->int conversions of the reference are
+ * defined and non-negative (SURVEY.md section 8a "valid input domain"): finite, >= 0, < 2^20. */
+static int coord_ok(float v) { return v >= 0.0f && v < 1048576.0f; }
+
+/* GMSMatcher::assignMatchPairs, DLL@0x180047880 (inlined in run at 0x1800489e0-0x180048ab4). */
+static void assign_match_pairs(gms_ref_state* st, int grid_type)
+{
+    for (int i = 0; i < st->n_matches; i++) {
+        const float* lp = st->p1 + 2 * (size_t)st->matches[i].queryIdx;
+        const float* rp = st->p2 + 2 * (size_t)st->matches[i].trainIdx;
+        int lgidx = st->pair_first[i] = grid_index_left(st, lp, grid_type);
+        int rgidx;
+        if (grid_type == 1)
+            rgidx = st->pair_second[i] = grid_index_right(st, rp);
+        else
+            rgidx = st->pair_second[i];
+        if (lgidx < 0 || rgidx < 0) continue;
+        if (rgidx >= st->n_right) { /* the reference would write outside its matrix row/allocation */
+            st->domain_error = 1;
+            continue;
+        }
+        st->motion[(size_t)lgidx * st->n_right + rgidx]++;
+        st->n_per_cell_left[lgidx]++;
+    }
+}
+
+/* GMSMatcher::verifyCellPairs, DLL@0x180048d10-0x1800491ec. */
+static void verify_cell_pairs(gms_ref_state* st, int rotation_type)
+{
+    const int* rp = gms_ref_rotation_patterns[rotation_type - 1];
+    for (int i = 0; i < st->n_left; i++) {
+        const int* row = st->motion + (size_t)i * st->n_right;
+        /* cv::sum(row)[0] == 0 (fp64 compare at DLL@0x180048dd7) */
+        double s = 0;
+        for (int j = 0; j < st->n_right; j++) s += row[j];
+        if (s == 0) {
+            st->cell_pairs[i] = -1;
+            continue;
+        }
+        /* arg-max, strict '>' from 0, ascending j: lowest index among maxima (DLL@0x180048e20-e4f) */
+        int max_number = 0;
+        for (int j = 0; j < st->n_right; j++)
+            if (row[j] > max_number) {
+                st->cell_pairs[i] = j;
+                max_number = row[j];
+            }
+        int idx_grid_rt = st->cell_pairs[i];
+        const int* nb9_lt = st->nb_left + 9 * i;
+        const int* nb9_rt = st->nb_right + 9 * idx_grid_rt;
+        int score = 0;
+        double thresh = 0;
+        int numpair = 0;
+        for (int j = 0; j < 9; j++) {
+            int ll = nb9_lt[j];
+            int rr = nb9_rt[rp[j] - 1];
+            if (ll == -1 || rr == -1) continue;
+            score += st->motion[(size_t)ll * st->n_right + rr];
+            thresh += (double)st->n_per_cell_left[ll];
+            numpair++;
+        }
+        /* divsd, sqrtsd, mulsd [this+0x1f0]; comisd thresh,score; reject iff thresh > score
+         * (DLL@0x180049171-0x18004919d) */
+        thresh = sqrt(thresh / (double)numpair) * st->threshold_factor;
+        if (thresh > (double)score) st->cell_pairs[i] = -2;
+    }
+}
+
+/* GMSMatcher::run, DLL@0x180048630-0x180048c08. */
+static int run(gms_ref_state* st, int rotation_type)
+{
+    memset(st->mask, 0, (size_t)st->n_matches);
+    for (int i = 0; i < st->n_matches; i++) st->pair_first[i] = st->pair_second[i] = 0;
+    for (int grid_type = 1; grid_type <= 4; grid_type++) {
+        memset(st->motion, 0, sizeof(int) * (size_t)st->n_left * (size_t)st->n_right);
+        for (int i = 0; i < st->n_left; i++) {
+            st->cell_pairs[i] = -1;
+            st->n_per_cell_left[i] = 0;
+        }
+        assign_match_pairs(st, grid_type);
+        verify_cell_pairs(st, rotation_type);
+        for (int i = 0; i < st->n_matches; i++)
+            if (st->pair_first[i] >= 0 && st->cell_pairs[st->pair_first[i]] == st->pair_second[i])
+                st->mask[i] = 1;
+    }
+    int c = 0;
+    for (int i = 0; i < st->n_matches; i++) c += st->mask[i];
+    return c;
+}
+
+int gms_ref_match(const gms_keypoint* kp1, int n1, int w1, int h1,
+                  const gms_keypoint* kp2, int n2, int w2, int h2,
+                  const gms_dmatch* matches, int m,
+                  int with_rotation, int with_scale, double threshold_factor,
+                  gms_dmatch* out, int* n_out, unsigned char* mask_out, gms_pair_result* result)
+{
+    if (n_out) *n_out = 0;
+    if (result) {
+        result->n_inliers = 0;
+        result->best_scale = -1;
+        result->best_rot = -1;
+        result->status = GMS_OK;
+    }
+    if (n1 < 0 || n2 < 0 || m < 0 || w1 <= 0 || h1 <= 0 || w2 <= 0 || h2 <= 0) return GMS_ERR_BAD_ARG;
+    if ((n1 > 0 && !kp1) || (n2 > 0 && !kp2) || (m > 0 && (!matches || !out)) || !n_out)
+        return GMS_ERR_BAD_ARG;
+    if (mask_out && m > 0) memset(mask_out, 0, (size_t)m);
+
+    gms_ref_state st;
+    memset(&st, 0, sizeof st);
+    st.n_matches = m;
+    st.n1 = n1;
+    st.n2 = n2;
+    st.matches = matches;
+    st.threshold_factor = threshold_factor;
+    st.wl = 20;
+    st.hl = 20;
+    st.n_left = 400;
+
+    int rc = GMS_OK;
+    unsigned char* best_mask = NULL;
+    st.p1 = (float*)malloc(sizeof(float) * 2 * (size_t)(n1 ? n1 : 1));
+    st.p2 = (float*)malloc(sizeof(float) * 2 * (size_t)(n2 ? n2 : 1));
+    st.nb_left = (int*)malloc(sizeof(int) * 9 * 400);
+    st.n_per_cell_left = (int*)malloc(sizeof(int) * 400);
+    st.cell_pairs = (int*)malloc(sizeof(int) * 400);
+    st.pair_first = (int*)malloc(sizeof(int) * (size_t)(m ? m : 1));
+    st.pair_second = (int*)malloc(sizeof(int) * (size_t)(m ? m : 1));
+    st.mask = (unsigned char*)malloc((size_t)(m ? m : 1));
+    best_mask = (unsigned char*)calloc((size_t)(m ? m : 1), 1);
+    if (!st.p1 || !st.p2 || !st.nb_left || !st.n_per_cell_left || !st.cell_pairs || !st.pair_first ||
+        !st.pair_second || !st.mask || !best_mask) {
+        rc = GMS_ERR_BAD_ARG;
+        goto done;
+    }
+
+    normalize_points(kp1, n1, w1, h1, st.p1);
+    normalize_points(kp2, n2, w2, h2, st.p2);
+    init_neighbors(st.nb_left, st.wl, st.hl);
+
+    /* Domain check (the reference has none, DLL@0x180048280): indices in range, matched points
+     * finite and non-negative. Outside it the reference reads/writes out of bounds. */
+    for (int i = 0; i < m; i++) {
+        int q = matches[i].queryIdx, t = matches[i].trainIdx;
+        if (q < 0 || q >= n1 || t < 0 || t >= n2) {
+            rc = GMS_ERR_DOMAIN;
+            goto done;
+        }
+        if (!coord_ok(st.p1[2 * q]) || !coord_ok(st.p1[2 * q + 1]) || !coord_ok(st.p2[2 * t]) ||
+            !coord_ok(st.p2[2 * t + 1])) {
+            rc = GMS_ERR_DOMAIN;
+            goto done;
+        }
+    }
+
+    /* GMSMatcher::getInlierMask, DLL@0x180047dc0-0x180047fe1: scale outer (0..4), rotation inner
+     * (1..8); keep (mask, count) on strict '>' starting from 0. Without either flag: setScale(0),
+     * run(1), take the mask unconditionally. */
+    int max_inlier = 0, best_scale = -1, best_rot = -1;
+    int n_scales = with_scale ? 5 : 1;
+    int n_rots = with_rotation ? 8 : 1;
+    for (int scale = 0; scale < n_scales; scale++) {
+        if (set_scale(&st, scale)) {
+            rc = GMS_ERR_BAD_ARG;
+            goto done;
+        }
+        for (int rot = 1; rot <= n_rots; rot++) {
+            int num_inlier = run(&st, rot);
+            if (st.domain_error) {
+                rc = GMS_ERR_DOMAIN;
+                goto done;
+            }
+            if (num_inlier > max_inlier) {
+                memcpy(best_mask, st.mask, (size_t)m);
+                max_inlier = num_inlier;
+                best_scale = scale;
+                best_rot = rot;
+            }
+        }
+    }
+
+    /* matchGMS copy-out, DLL@0x18004831e-0x180048371: clear, then push every masked match. */
+    {
+        int k = 0;
+        for (int i = 0; i < m; i++)
+            if (best_mask[i]) out[k++] = matches[i];
+        *n_out = k;
+        if (mask_out && m > 0) memcpy(mask_out, best_mask, (size_t)m);
+        if (result) {
+            result->n_inliers = k;
+            result->best_scale = best_scale;
+            result->best_rot = best_rot;
+        }
+    }
+
+done:
+    if (result) result->status = rc;
+    free(st.p1);
+    free(st.p2);
+    free(st.nb_left);
+    free(st.nb_right);
+    free(st.motion);
+    free(st.n_per_cell_left);
+    free(st.cell_pairs);
+    free(st.pair_first);
+    free(st.pair_second);
+    free(st.mask);
+    free(best_mask);
+    return rc;
+}
+
+/* Exposed pieces, so tests can pin them one at a time. */
+int gms_ref_grid_index_left(float nx, float ny, int type)
+{
+    gms_ref_state st;
+    memset(&st, 0, sizeof st);
+    st.wl = st.hl = 20;
+    float pt[2] = {nx, ny};
+    return grid_index_left(&st, pt, type);
+}
+int gms_ref_grid_index_right(float nx, float ny, int wr, int hr)
+{
+    gms_ref_state st;
+    memset(&st, 0, sizeof st);
+    st.wr = wr;
+    st.hr = hr;
+    float pt[2] = {nx, ny};
+    return grid_index_right(&st, pt);
+}
+void gms_ref_right_grid(int scale, int* wr, int* hr)
+{
+    *wr = round_f64(20 * gms_ref_scale_ratio(scale));
+    *hr = round_f64(20 * gms_ref_scale_ratio(scale));
+}
+float gms_ref_normalize(float v, int extent) { return v / (float)extent; }
+int gms_ref_threshold_rejects(int T, int n, int score, double factor)
+{
+    double thresh = sqrt((double)T / (double)n) * factor;
+    return thresh > (double)score;
+}

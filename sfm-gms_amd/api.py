@@ -1,0 +1,123 @@
+"""Python mirror of the reference's operator: same name, argument meaning and output as
+
+    cv::xfeatures2d::matchGMS(size1, size2, keypoints1, keypoints2, matches1to2, matchesGMS,
+                              withRotation=false, withScale=false, thresholdFactor=6.0)
+
+(reference call sites: SfM-GMS/SfM-GMS/FeatureMatchUtil.cpp:69, DisparityUtil.cpp:149,299).
+Inputs/outputs are numpy structured arrays laid out exactly like cv::KeyPoint / cv::DMatch.
+All work happens in csrc/libgms_hip.so on the GPU; nothing here computes the filter.
+"""
+import ctypes as C
+
+import numpy as np
+
+from .capi import load_library
+from .types import (DMATCH_DTYPE, KEYPOINT_DTYPE, RESULT_DTYPE, GMS_OK, GmsError)
+
+
+def _as(arr, dtype, name):
+    a = np.ascontiguousarray(arr)
+    if a.dtype != dtype:
+        raise TypeError(f"{name} must have dtype {dtype}, got {a.dtype}")
+    return a
+
+
+def _check(rc, lib, what):
+    if rc != GMS_OK:
+        msg = lib.gms_error_string(rc).decode()
+        if rc == -3:
+            msg += f" (hipError {lib.gms_last_hip_error()})"
+        raise GmsError(rc, f"{what}: {msg}")
+
+
+class GmsContext:
+    """gms_ctx: one per (process, device). Thread-safe for the one-shot call; stream-ordered batch calls."""
+
+    def __init__(self, device=0):
+        self._lib = load_library()
+        h = C.c_void_p()
+        _check(self._lib.gms_ctx_create(int(device), C.byref(h)), self._lib, "gms_ctx_create")
+        self._h = h
+        self.device = int(device)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.gms_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    @property
+    def max_matches(self):
+        return int(self._lib.gms_max_matches())
+
+    def set_stream(self, hip_stream_handle):
+        """Launch on a caller-owned HIP stream (e.g. torch.cuda.Stream().cuda_stream); 0/None = own stream."""
+        _check(self._lib.gms_ctx_set_stream(self._h, C.c_void_p(hip_stream_handle or 0)), self._lib, "set_stream")
+
+    def synchronize(self):
+        _check(self._lib.gms_ctx_synchronize(self._h), self._lib, "synchronize")
+
+    # -- one-shot, host arrays ---------------------------------------------------------------------
+    def match(self, size1, size2, keypoints1, keypoints2, matches1to2, withRotation=False, withScale=False,
+              thresholdFactor=6.0, return_result=False):
+        kp1 = _as(keypoints1, KEYPOINT_DTYPE, "keypoints1")
+        kp2 = _as(keypoints2, KEYPOINT_DTYPE, "keypoints2")
+        mt = _as(matches1to2, DMATCH_DTYPE, "matches1to2")
+        out = np.empty(max(len(mt), 1), dtype=DMATCH_DTYPE)
+        n_out = C.c_int(0)
+        res = np.zeros(1, dtype=RESULT_DTYPE)
+        rc = self._lib.gms_match_ctx(self._h, kp1.ctypes.data, len(kp1), int(size1[0]), int(size1[1]),
+                                     kp2.ctypes.data, len(kp2), int(size2[0]), int(size2[1]),
+                                     mt.ctypes.data, len(mt), int(bool(withRotation)), int(bool(withScale)),
+                                     float(thresholdFactor), out.ctypes.data, C.byref(n_out), res.ctypes.data)
+        _check(rc, self._lib, "gms_match_ctx")
+        kept = out[: n_out.value].copy()
+        return (kept, res[0]) if return_result else kept
+
+    # -- device-resident batch path (raw device pointers; torch tensors' data_ptr() are fine) ---------
+    def normalize_device(self, d_kp, d_frame_off, d_wh, n_frames, total_kp, d_pts):
+        _check(self._lib.gms_normalize_device(self._h, d_kp, d_frame_off, d_wh, int(n_frames), int(total_kp), d_pts),
+               self._lib, "gms_normalize_device")
+
+    def filter_device(self, d_pts, d_frame_off, n_frames, d_pairs, n_pairs, max_m, d_matches, d_out, d_results,
+                      d_mask=None, withRotation=False, withScale=False, thresholdFactor=6.0):
+        _check(self._lib.gms_filter_device(self._h, d_pts, d_frame_off, int(n_frames), d_pairs, int(n_pairs),
+                                           int(max_m), d_matches, int(bool(withRotation)), int(bool(withScale)),
+                                           float(thresholdFactor), d_out, d_results, d_mask or None),
+               self._lib, "gms_filter_device")
+
+    def selftest_threshold(self, T, n, score, factor):
+        T = np.ascontiguousarray(T, dtype=np.int32)
+        n = np.ascontiguousarray(n, dtype=np.int32)
+        score = np.ascontiguousarray(score, dtype=np.int32)
+        out = np.zeros(len(T), dtype=np.uint8)
+        _check(self._lib.gms_selftest_threshold(self._h, T.ctypes.data, n.ctypes.data, score.ctypes.data,
+                                                float(factor), len(T), out.ctypes.data), self._lib, "selftest")
+        return out
+
+
+_default_ctx = None
+
+
+def matchGMS(size1, size2, keypoints1, keypoints2, matches1to2, withRotation=False, withScale=False,
+             thresholdFactor=6.0):
+    """Drop-in for cv::xfeatures2d::matchGMS; returns matchesGMS (the surviving DMatch, in input order).
+
+    size = (width, height) like cv::Size. Raises GmsError instead of the reference's undefined behaviour
+    on out-of-domain input."""
+    global _default_ctx
+    if _default_ctx is None:
+        _default_ctx = GmsContext(0)
+    return _default_ctx.match(size1, size2, keypoints1, keypoints2, matches1to2, withRotation, withScale,
+                              thresholdFactor)

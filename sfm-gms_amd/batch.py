@@ -1,0 +1,68 @@
+"""Device-resident batch driver: resident frame tables + pair descriptors -> filtered matches.
+
+torch is used here for what the project allows it for: device memory and streams. The filter itself
+is gms_filter_device in csrc/libgms_hip.so. Mirrors how the reference's callers use matchGMS
+(FeatureMatchUtil.cpp:66-69: M = N1 matches from BFMatcher, then one matchGMS per image pair), but
+for many pairs per launch with the per-frame keypoint tables kept in HBM.
+"""
+import numpy as np
+import torch
+
+from .api import GmsContext
+from .types import DMATCH_DTYPE, KEYPOINT_DTYPE, PAIR_DTYPE, RESULT_DTYPE
+
+
+def _to_dev(arr, device):
+    a = np.ascontiguousarray(arr)
+    return torch.from_numpy(a.view(np.uint8).reshape(-1)).to(device)
+
+
+class FrameTable:
+    """Keypoints of all frames of a sequence, normalised once on the GPU (GMSMatcher::normalizePoints)."""
+
+    def __init__(self, ctx, keypoints_per_frame, sizes, device="cuda:0"):
+        self.ctx = ctx
+        self.device = torch.device(device)
+        self.n_frames = len(keypoints_per_frame)
+        counts = np.array([len(k) for k in keypoints_per_frame], dtype=np.int64)
+        self.frame_off_host = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+        self.total = int(self.frame_off_host[-1])
+        kp_all = (np.concatenate([np.ascontiguousarray(k, dtype=KEYPOINT_DTYPE) for k in keypoints_per_frame])
+                  if self.total else np.zeros(0, dtype=KEYPOINT_DTYPE))
+        wh = np.asarray(sizes, dtype=np.int32).reshape(-1, 2)
+        assert wh.shape[0] == self.n_frames
+        self.d_kp = _to_dev(kp_all, self.device)
+        self.d_frame_off = torch.from_numpy(self.frame_off_host).to(self.device)
+        self.d_wh = torch.from_numpy(wh.reshape(-1).copy()).to(self.device)
+        self.d_pts = torch.empty(max(2 * self.total, 2), dtype=torch.float32, device=self.device)
+        torch.cuda.synchronize(self.device)
+        ctx.normalize_device(self.d_kp.data_ptr(), self.d_frame_off.data_ptr(), self.d_wh.data_ptr(),
+                             self.n_frames, self.total, self.d_pts.data_ptr())
+        ctx.synchronize()
+
+
+def filter_pairs(ctx, frames, pairs, matches, withRotation=False, withScale=False, thresholdFactor=6.0,
+                 want_mask=True):
+    """Run the filter over `pairs` (PAIR_DTYPE array) whose matches live in `matches` (DMATCH_DTYPE array,
+    pair i at [match_off, match_off+m)). Returns (out, results, mask) as host arrays."""
+    dev = frames.device
+    pairs = np.ascontiguousarray(pairs, dtype=PAIR_DTYPE)
+    matches = np.ascontiguousarray(matches, dtype=DMATCH_DTYPE)
+    n_pairs = len(pairs)
+    max_m = int(pairs["m"].max()) if n_pairs else 0
+    total_m = len(matches)
+    d_pairs = _to_dev(pairs, dev)
+    d_matches = _to_dev(matches, dev) if total_m else torch.zeros(16, dtype=torch.uint8, device=dev)
+    d_out = torch.zeros(max(total_m, 1) * 16, dtype=torch.uint8, device=dev)
+    d_res = torch.zeros(max(n_pairs, 1) * 16, dtype=torch.uint8, device=dev)
+    d_mask = torch.zeros(max(total_m, 1), dtype=torch.uint8, device=dev) if want_mask else None
+    torch.cuda.synchronize(dev)
+    ctx.filter_device(frames.d_pts.data_ptr(), frames.d_frame_off.data_ptr(), frames.n_frames,
+                      d_pairs.data_ptr(), n_pairs, max_m, d_matches.data_ptr(), d_out.data_ptr(),
+                      d_res.data_ptr(), d_mask.data_ptr() if want_mask else None,
+                      withRotation, withScale, thresholdFactor)
+    ctx.synchronize()
+    out = d_out.cpu().numpy().view(DMATCH_DTYPE)[:total_m]
+    res = d_res.cpu().numpy().view(RESULT_DTYPE)[:n_pairs]
+    mask = d_mask.cpu().numpy()[:total_m] if want_mask else None
+    return out, res, mask

@@ -1,0 +1,52 @@
+"""ctypes binding of include/gms.h -> csrc/libgms_hip.so. Fails loudly if the library is missing."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+# Every symbol include/gms.h declares; tests check the built library exports all of them.
+EXPORTED_SYMBOLS = [
+    "gms_match", "gms_match_ctx", "gms_ctx_create", "gms_ctx_destroy", "gms_ctx_set_stream",
+    "gms_ctx_synchronize", "gms_normalize_device", "gms_filter_device", "gms_max_matches",
+    "gms_last_hip_error", "gms_error_string", "gms_version", "gms_selftest_threshold",
+]
+
+_lib = None
+
+
+def library_path():
+    return os.path.join(_HERE, "csrc", "libgms_hip.so")
+
+
+def load_library():
+    """Load the HIP extension. No fallback: a missing .so is an error (build with __graft_entry__.build())."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = library_path()
+    if not os.path.exists(path):
+        raise ImportError(f"{path} not found: the HIP extension is not built "
+                          f"(run `python -c 'import __graft_entry__ as g; g.build()'`)")
+    lib = C.CDLL(path)
+    vp, i32, i64, dbl = C.c_void_p, C.c_int, C.c_int64, C.c_double
+    lib.gms_match.argtypes = [vp, i32, i32, i32, vp, i32, i32, i32, vp, i32, i32, i32, dbl, vp, C.POINTER(i32)]
+    lib.gms_match_ctx.argtypes = [vp, vp, i32, i32, i32, vp, i32, i32, i32, vp, i32, i32, i32, dbl, vp,
+                                  C.POINTER(i32), vp]
+    lib.gms_ctx_create.argtypes = [i32, C.POINTER(vp)]
+    lib.gms_ctx_destroy.argtypes = [vp]
+    lib.gms_ctx_set_stream.argtypes = [vp, vp]
+    lib.gms_ctx_synchronize.argtypes = [vp]
+    lib.gms_normalize_device.argtypes = [vp, vp, vp, vp, i32, i64, vp]
+    lib.gms_filter_device.argtypes = [vp, vp, vp, i32, vp, i32, i32, vp, i32, i32, dbl, vp, vp, vp]
+    lib.gms_selftest_threshold.argtypes = [vp, vp, vp, vp, dbl, i32, vp]
+    lib.gms_max_matches.argtypes = []
+    lib.gms_last_hip_error.argtypes = []
+    lib.gms_error_string.argtypes = [i32]
+    lib.gms_error_string.restype = C.c_char_p
+    lib.gms_version.argtypes = []
+    lib.gms_version.restype = C.c_char_p
+    for name in EXPORTED_SYMBOLS:
+        if name not in ("gms_error_string", "gms_version"):
+            getattr(lib, name).restype = i32
+    _lib = lib
+    return lib

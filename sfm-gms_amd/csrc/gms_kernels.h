@@ -1,0 +1,38 @@
+// gms_kernels.h -- internal interface between the C-ABI host code and the HIP kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "gms.h"
+
+namespace gms {
+
+constexpr int kLeftW = 20, kLeftH = 20, kLeftN = 400;  // DLL@0x180046ac6: fixed 20 x 20 left grid
+constexpr int kThreads = 1024;                         // one 16-wave workgroup per image pair
+constexpr size_t kLdsBytes = 160 * 1024;               // gfx950 LDS per CU (and per workgroup)
+
+struct FilterParams {
+    const float2* pts;          // normalised keypoints of all frames
+    const int64_t* frame_off;   // n_frames + 1
+    int n_frames;
+    const gms_pair* pairs;
+    const gms_dmatch* matches;
+    gms_dmatch* out;
+    gms_pair_result* results;
+    uint8_t* mask;              // optional
+    int mcap;                   // multiple of 64, >= max m
+    uint32_t table_slots;       // even, > mcap
+    int with_rotation, with_scale;
+    double threshold_factor;
+    int right_w[5], right_h[5]; // setScale (DLL@0x180048c10): cvRound(20 * ratio[s])
+};
+
+size_t     filter_lds_bytes(int mcap, uint32_t table_slots);
+hipError_t launch_normalize(const gms_keypoint* d_kp, const int64_t* d_frame_off, const int32_t* d_wh,
+                            int n_frames, int64_t total_kp, float* d_pts, hipStream_t stream);
+hipError_t launch_filter(const FilterParams& p, int n_pairs, size_t lds_bytes, hipStream_t stream);
+hipError_t launch_threshold(const int32_t* d_T, const int32_t* d_n, const int32_t* d_score, double factor,
+                            int count, uint8_t* d_out, hipStream_t stream);
+
+}  // namespace gms

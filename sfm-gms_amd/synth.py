@@ -1,0 +1,102 @@
+"""Seeded synthetic inputs for the GMS path (SURVEY.md section 8d "synthetic input recipe").
+
+The reference feeds matchGMS with detector keypoints and BFMatcher output (FeatureMatchUtil.cpp:58-68:
+M = N1 matches, queryIdx = i). No detector/matcher exists offline, so inputs of the same shape are
+synthesised: keypoints uniform in the image, a ground-truth similarity motion, a fraction of true
+correspondences plus uniformly random outliers.
+"""
+import numpy as np
+
+from .types import DMATCH_DTYPE, KEYPOINT_DTYPE
+
+SEED_BASE = 0x5F3759DF
+
+
+def rng_for(case_id):
+    return np.random.Generator(np.random.PCG64(SEED_BASE ^ int(case_id)))
+
+
+def make_keypoints(xy):
+    xy = np.asarray(xy, dtype=np.float32).reshape(-1, 2)
+    kp = np.zeros(len(xy), dtype=KEYPOINT_DTYPE)
+    kp["x"], kp["y"] = xy[:, 0], xy[:, 1]
+    kp["size"], kp["angle"], kp["response"], kp["octave"], kp["class_id"] = 31.0, -1.0, 0.0, 0, -1
+    return kp
+
+
+def make_matches(query, train, rng=None):
+    m = np.zeros(len(query), dtype=DMATCH_DTYPE)
+    m["queryIdx"], m["trainIdx"] = query, train
+    m["imgIdx"] = 0
+    m["distance"] = (rng.uniform(0, 256, len(query)) if rng is not None else 0).astype(np.float32) \
+        if rng is not None else 0
+    return m
+
+
+def similarity(xy, size_from, size_to, theta_deg=0.0, scale=1.0, shift=(0.0, 0.0)):
+    """Rotate by theta about the source image centre, scale, move to the target centre, shift."""
+    t = np.deg2rad(theta_deg)
+    c, s = np.cos(t), np.sin(t)
+    ctr_a = np.array([size_from[0] / 2.0, size_from[1] / 2.0])
+    ctr_b = np.array([size_to[0] / 2.0, size_to[1] / 2.0])
+    d = xy.astype(np.float64) - ctr_a
+    r = np.stack([c * d[:, 0] - s * d[:, 1], s * d[:, 0] + c * d[:, 1]], axis=1) * scale
+    return r + ctr_b + np.asarray(shift, dtype=np.float64)
+
+
+def make_pair(case_id, size1=(1920, 1080), size2=None, n1=10000, n2=None, inlier_frac=0.5, theta_deg=0.0,
+              scale=1.0, shift=(3.0, -2.0), noise_px=2.0):
+    """One image pair: kp1, kp2, matches (M = n1, queryIdx = i) -- BASELINE configs 1, 2 and 4."""
+    size2 = size2 or size1
+    n2 = n2 or n1
+    rng = rng_for(case_id)
+    w1, h1 = size1
+    w2, h2 = size2
+    xy1 = np.stack([rng.uniform(0, w1 - 1, n1), rng.uniform(0, h1 - 1, n1)], axis=1).astype(np.float32)
+    xy2 = np.stack([rng.uniform(0, w2 - 1, n2), rng.uniform(0, h2 - 1, n2)], axis=1).astype(np.float32)
+    is_in = rng.uniform(size=n1) < inlier_frac
+    train = rng.integers(0, n2, n1)
+    # true correspondences overwrite slots of kp2 (distinct slots, so kp2 stays a proper keypoint set)
+    slots = rng.permutation(n2)[: min(n1, n2)]
+    mapped = similarity(xy1, size1, size2, theta_deg, scale, shift) + rng.normal(0, noise_px, (n1, 2))
+    inb = (mapped[:, 0] >= 0) & (mapped[:, 0] < w2 - 1) & (mapped[:, 1] >= 0) & (mapped[:, 1] < h2 - 1)
+    k = 0
+    for i in np.nonzero(is_in & inb)[0]:
+        if k >= len(slots):
+            break
+        xy2[slots[k]] = mapped[i]
+        train[i] = slots[k]
+        k += 1
+    kp1, kp2 = make_keypoints(xy1), make_keypoints(xy2)
+    matches = make_matches(np.arange(n1), train, rng)
+    return kp1, kp2, matches
+
+
+def make_sequence(case_id, n_frames, size=(1920, 1080), n_kp=10000, drift_px=6.0, noise_px=1.5):
+    """A sequence of frames observing one scene under a slow drift (BASELINE config 3): frame f sees
+    base point i at base[i] + f * drift + noise (kept inside the image), so keypoint i of frame a
+    truly corresponds to keypoint i of frame b."""
+    rng = rng_for(case_id)
+    w, h = size
+    margin = 0.15
+    base = np.stack([rng.uniform(margin * w, (1 - margin) * w, n_kp),
+                     rng.uniform(margin * h, (1 - margin) * h, n_kp)], axis=1)
+    direction = rng.uniform(-1, 1, 2)
+    direction /= np.linalg.norm(direction)
+    frames = []
+    for f in range(n_frames):
+        step = (f - (n_frames - 1) / 2.0) * drift_px / max(1.0, n_frames / 16.0)
+        xy = base + direction * step + rng.normal(0, noise_px, (n_kp, 2))
+        xy[:, 0] = np.clip(xy[:, 0], 0, w - 1.001)
+        xy[:, 1] = np.clip(xy[:, 1], 0, h - 1.001)
+        frames.append(make_keypoints(xy.astype(np.float32)))
+    return frames
+
+
+def sequence_matches(case_id, n_kp_a, n_kp_b, inlier_frac=0.5):
+    """Putative matches of one pair of a make_sequence() sequence: M = n_kp_a, queryIdx = i, a fraction
+    true (trainIdx = i), the rest uniformly random."""
+    rng = rng_for(case_id)
+    q = np.arange(n_kp_a)
+    t = np.where(rng.uniform(size=n_kp_a) < inlier_frac, np.minimum(q, n_kp_b - 1), rng.integers(0, n_kp_b, n_kp_a))
+    return make_matches(q, t, rng)

@@ -1,0 +1,22 @@
+"""PODs shared with the C ABI (include/gms.h), as numpy structured dtypes."""
+import numpy as np
+
+# cv::KeyPoint, 28 bytes (stride 0x1c at DLL@0x1800485d4); GMS reads only x, y.
+KEYPOINT_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),
+                           ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")])
+# cv::DMatch, 16 bytes (stride 0x10 at DLL@0x180046aa3); copied verbatim to the output.
+DMATCH_DTYPE = np.dtype([("queryIdx", "<i4"), ("trainIdx", "<i4"), ("imgIdx", "<i4"), ("distance", "<f4")])
+PAIR_DTYPE = np.dtype([("frame_a", "<i4"), ("frame_b", "<i4"), ("m", "<i4"), ("reserved", "<i4"),
+                       ("match_off", "<i8")])
+RESULT_DTYPE = np.dtype([("n_inliers", "<i4"), ("best_scale", "<i4"), ("best_rot", "<i4"), ("status", "<i4")])
+
+assert KEYPOINT_DTYPE.itemsize == 28 and DMATCH_DTYPE.itemsize == 16
+assert PAIR_DTYPE.itemsize == 24 and RESULT_DTYPE.itemsize == 16
+
+GMS_OK, GMS_ERR_BAD_ARG, GMS_ERR_DOMAIN, GMS_ERR_HIP, GMS_ERR_NO_DEVICE, GMS_ERR_CAPACITY = 0, -1, -2, -3, -4, -5
+
+
+class GmsError(RuntimeError):
+    def __init__(self, code, what=""):
+        self.code = int(code)
+        super().__init__(f"gms error {code}: {what}")
