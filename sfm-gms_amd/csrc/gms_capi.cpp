@@ -20,6 +20,10 @@ static_assert(sizeof(gms_pair) == 24, "gms_pair layout");
 static_assert(sizeof(gms_pair_result) == 16, "gms_pair_result layout");
 
 static thread_local int t_last_hip = 0;
+#ifdef GMS_PHASE_TIMING
+static unsigned long long* g_diag = nullptr;
+extern "C" int gms_diag_set_buffer(void* d_buf) { g_diag = (unsigned long long*)d_buf; return 0; }
+#endif
 
 #define GMS_HIP(call)                         \
     do {                                      \
@@ -40,24 +44,6 @@ void right_grids(int rw[5], int rh[5])
         rw[s] = (int)std::lrint(gms::kLeftW * ratio[s]);
         rh[s] = (int)std::lrint(gms::kLeftH * ratio[s]);
     }
-}
-
-// LDS plan for one workgroup: code[mcap] + hash table. Returns false if max_m does not fit.
-bool plan_lds(int max_m, int* mcap_out, uint32_t* slots_out, size_t* bytes_out)
-{
-    if (max_m < 0) return false;
-    const int mcap = ((max_m > 0 ? max_m : 1) + 63) & ~63;
-    uint32_t want = (uint32_t)mcap + (uint32_t)(mcap >> 1);  // load factor <= 2/3 even if every key is distinct
-    if (want < 1024) want = 1024;
-    want = (want + 1) & ~1u;
-    const uint32_t floor_slots = ((uint32_t)mcap + (uint32_t)(mcap >> 3) + 64 + 1) & ~1u;
-    uint32_t s = want;
-    while (s >= floor_slots && gms::filter_lds_bytes(mcap, s) > gms::kLdsBytes) s -= 2;
-    if (s < floor_slots || gms::filter_lds_bytes(mcap, s) > gms::kLdsBytes) return false;
-    *mcap_out = mcap;
-    *slots_out = s;
-    *bytes_out = gms::filter_lds_bytes(mcap, s);
-    return true;
 }
 
 struct DevBuf {
@@ -113,14 +99,12 @@ const char* gms_error_string(int code)
 
 int gms_max_matches(void)
 {
-    int lo = 0, hi = 1 << 16;  // 16-bit per-cell counters bound m anyway
+    int lo = 0, hi = 1 << 20;
     while (lo < hi) {
-        int mid = (lo + hi + 1) / 2, mcap;
-        uint32_t s;
-        size_t b;
-        if (plan_lds(mid, &mcap, &s, &b)) lo = mid; else hi = mid - 1;
+        int mid = (lo + hi + 1) / 2;
+        if (gms::filter_pick_kpt(mid)) lo = mid; else hi = mid - 1;
     }
-    return lo > 65535 ? 65535 : lo;
+    return lo;
 }
 
 int gms_ctx_create(int device, gms_ctx** out_ctx)
@@ -197,8 +181,9 @@ int gms_filter_device(gms_ctx* c, const float* d_pts, const int64_t* d_frame_off
     if (!d_frame_off || !d_pairs || !d_results) return GMS_ERR_BAD_ARG;
     if (max_m > 0 && (!d_matches || !d_out || !d_pts)) return GMS_ERR_BAD_ARG;
     gms::FilterParams p;
-    size_t lds = 0;
-    if (!plan_lds(max_m, &p.mcap, &p.table_slots, &lds)) return GMS_ERR_CAPACITY;
+    const int kpt = gms::filter_pick_kpt(max_m);
+    if (!kpt) return GMS_ERR_CAPACITY;
+    p.table_slots = gms::filter_table_slots(kpt);
     p.pts = reinterpret_cast<const float2*>(d_pts);
     p.frame_off = d_frame_off;
     p.n_frames = n_frames;
@@ -211,8 +196,11 @@ int gms_filter_device(gms_ctx* c, const float* d_pts, const int64_t* d_frame_off
     p.with_scale = with_scale ? 1 : 0;
     p.threshold_factor = threshold_factor;
     right_grids(p.right_w, p.right_h);
+#ifdef GMS_PHASE_TIMING
+    p.diag = g_diag;
+#endif
     GMS_HIP(hipSetDevice(c->device));
-    GMS_HIP(gms::launch_filter(p, n_pairs, lds, c->stream));
+    GMS_HIP(gms::launch_filter(p, kpt, n_pairs, c->stream));
     return GMS_OK;
 }
 

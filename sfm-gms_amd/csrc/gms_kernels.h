@@ -9,6 +9,7 @@
 namespace gms {
 
 constexpr int kLeftW = 20, kLeftH = 20, kLeftN = 400;  // DLL@0x180046ac6: fixed 20 x 20 left grid
+constexpr int kFineW = 40, kFineN = 1600;                  // half-cell grid: carries all four grid types
 constexpr int kThreads = 1024;                         // one 16-wave workgroup per image pair
 constexpr size_t kLdsBytes = 160 * 1024;               // gfx950 LDS per CU (and per workgroup)
 
@@ -21,17 +22,21 @@ struct FilterParams {
     gms_dmatch* out;
     gms_pair_result* results;
     uint8_t* mask;              // optional
-    int mcap;                   // multiple of 64, >= max m
-    uint32_t table_slots;       // even, > mcap
+    uint32_t table_slots;       // multiple of 4, >= 1.5 * KPT * 1024 + 1200
     int with_rotation, with_scale;
     double threshold_factor;
     int right_w[5], right_h[5]; // setScale (DLL@0x180048c10): cvRound(20 * ratio[s])
+#ifdef GMS_PHASE_TIMING
+    unsigned long long* diag;   // diagnostic build only: [n_pairs][12] cycle sums
+#endif
 };
 
-size_t     filter_lds_bytes(int mcap, uint32_t table_slots);
+int        filter_pick_kpt(int max_m);   // matches per thread (template variant) for max_m, 0 = too large
+uint32_t   filter_table_slots(int kpt);
+size_t     filter_lds_bytes(int kpt, uint32_t table_slots);
 hipError_t launch_normalize(const gms_keypoint* d_kp, const int64_t* d_frame_off, const int32_t* d_wh,
                             int n_frames, int64_t total_kp, float* d_pts, hipStream_t stream);
-hipError_t launch_filter(const FilterParams& p, int n_pairs, size_t lds_bytes, hipStream_t stream);
+hipError_t launch_filter(const FilterParams& p, int kpt, int n_pairs, hipStream_t stream);
 hipError_t launch_threshold(const int32_t* d_T, const int32_t* d_n, const int32_t* d_score, double factor,
                             int count, uint8_t* d_out, hipStream_t stream);
 

@@ -37,70 +37,119 @@ __constant__ int8_t c_rot[8][9] = {
 
 constexpr uint32_t kEmpty = 0xFFFFFFFFu;
 
-// code word layout
-constexpr uint32_t kRMask = 0x7FFu;       // bits 0..10  right cell (< 1600)
-constexpr int kLxShift = 11;              // bits 11..15 floor(20*nx), clamped to 31
-constexpr int kLyShift = 16;              // bits 16..20 floor(20*ny), clamped to 31
-constexpr uint32_t kSxBit = 1u << 21;     // floor(20*nx + 0.5) - floor(20*nx)
-constexpr uint32_t kSyBit = 1u << 22;
-constexpr uint32_t kValidBit = 1u << 23;
-constexpr int kAccShift = 24;             // bits 24..31 inlier-under-rotation bits (OR over grid types)
+// Diagnostic build only (-DGMS_PHASE_TIMING, libgms_hip_diag.so): thread 0 of each workgroup sums the
+// shader-clock cycles between phase boundaries into p.diag[block][phase]. No stamp exists in the product build.
+#ifdef GMS_PHASE_TIMING
+#define GMS_STAMP_DECL unsigned long long ph_[12] = {0}; unsigned long long t_prev_ = __builtin_readcyclecounter();
+#define GMS_STAMP(k) do { unsigned long long t_ = __builtin_readcyclecounter(); ph_[k] += t_ - t_prev_; t_prev_ = t_; } while (0)
+#define GMS_STAMP_FLUSH do { if (tid == 0 && p.diag) for (int k_ = 0; k_ < 12; ++k_) p.diag[blockIdx.x * 12 + k_] = ph_[k_]; } while (0)
+#else
+#define GMS_STAMP_DECL
+#define GMS_STAMP(k)
+#define GMS_STAMP_FLUSH
+#endif
 
-__device__ __forceinline__ int floor_f32(float v)
+// code word (one dword per match, kept in a register for the whole pair)
+constexpr uint32_t kRMask = 0x7FFu;        // bits 0..10   right cell of the current scale (< 1600)
+constexpr int kFShift = 11;                // bits 11..21  half-cell ("fine") index hy * 40 + hx of the left point,
+constexpr uint32_t kFMask = 0x7FFu;        //              or kFineInvalid when the point is never binned
+constexpr int kAccShift = 24;              // bits 24..31  inlier-under-rotation bits (OR over the 4 grid types)
+constexpr uint32_t kFineInvalid = kFineN;  // entries [1600, 1664) of the fine tables are "nothing here"
+constexpr int kFineStride = 1664;
+constexpr uint32_t kNoMatch = 0xFFFFFF00u; // fres value that equals no right cell
+
+// table slot: [right cell : 11 | count : 21]; a left cell's region holds only its own right cells and is
+// organised in 4-slot buckets so that one ds_read_b128 sees a whole bucket
+constexpr int kSlotRShift = 21;
+constexpr uint32_t kSlotCountMask = (1u << kSlotRShift) - 1u;
+
+// buckets (of 4 slots) of a left cell holding n matches: slots >= n + 1, so an empty slot always exists
+// and ends every probe chain; about 1.5 slots per match keeps most buckets short of full
+__device__ __forceinline__ uint32_t region_buckets(uint32_t n) { return n ? ((n + (n >> 1) + 3u) >> 2) : 0u; }
+
+// byte offset (0, 4, 8, 12) of the slot of bucket v whose key is r (kr = r << 21), or -1
+__device__ __forceinline__ int bucket_find(const uint4& v, uint32_t kr)
 {
-    int i = (int)v;
-    return i - ((float)i > v);
+    int o = -1;
+    o = ((v.w ^ kr) <= kSlotCountMask) ? 12 : o;
+    o = ((v.z ^ kr) <= kSlotCountMask) ? 8 : o;
+    o = ((v.y ^ kr) <= kSlotCountMask) ? 4 : o;
+    o = ((v.x ^ kr) <= kSlotCountMask) ? 0 : o;
+    return o;
 }
-__device__ __forceinline__ int floor_f64(double v)
+__device__ __forceinline__ int bucket_first_empty(const uint4& v)
 {
-    int i = (int)v;
-    return i - ((double)i > v);
+    int o = -1;
+    o = (v.w == kEmpty) ? 12 : o;
+    o = (v.z == kEmpty) ? 8 : o;
+    o = (v.y == kEmpty) ? 4 : o;
+    o = (v.x == kEmpty) ? 0 : o;
+    return o;
+}
+__device__ __forceinline__ uint32_t bucket_count(const uint4& v, uint32_t kr)
+{
+    uint32_t c = 0;
+    c = ((v.w ^ kr) <= kSlotCountMask) ? v.w : c;
+    c = ((v.z ^ kr) <= kSlotCountMask) ? v.z : c;
+    c = ((v.y ^ kr) <= kSlotCountMask) ? v.y : c;
+    c = ((v.x ^ kr) <= kSlotCountMask) ? v.x : c;
+    return c & kSlotCountMask;
 }
 
-// Left cell of grid type g (0..3; bit0 = x shifted by half a cell, bit1 = y shifted), or -1.
-__device__ __forceinline__ int left_cell(uint32_t c, int g)
+__device__ __forceinline__ uint32_t* lds_at(uint32_t* base, uint32_t byte_off)
 {
-    int x = (int)((c >> kLxShift) & 31u) + ((g & 1) ? (int)((c >> 21) & 1u) : 0);
-    int y = (int)((c >> kLyShift) & 31u) + ((g & 2) ? (int)((c >> 22) & 1u) : 0);
-    if (!(c & kValidBit) || x >= kLeftW || y >= kLeftH) return -1;
-    return x + y * kLeftW;
+    return reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(base) + byte_off);
 }
 
-__device__ __forceinline__ uint32_t hash_slot(uint32_t key, uint32_t S)
+// motion[l][r]++, general form: walk the region d = (first bucket << 16) | buckets from its hashed bucket.
+// Every lane terminates: the region always has an empty slot.
+__device__ __noinline__ void region_insert_general(uint32_t* tab, uint32_t d, uint32_t r)
 {
-    return __umulhi(key * 0x9E3779B1u, S);
-}
-
-// motion[l][r]++ on the sparse table. Every lane terminates: S > number of distinct keys.
-__device__ __forceinline__ void table_insert(uint32_t* keys, uint32_t* cnt, uint32_t S, uint32_t key)
-{
-    uint32_t h = hash_slot(key, S);
-    for (uint32_t probe = 0; probe < S; ++probe) {
-        uint32_t prev = atomicCAS(&keys[h], kEmpty, key);
-        if (prev == kEmpty || prev == key) {
-            atomicAdd(&cnt[h >> 1], 1u << ((h & 1u) << 4));
+    const uint32_t nb = d & 0xFFFFu, first = d >> 16;
+    if (nb == 0) return;
+    const uint32_t kr = r << kSlotRShift;
+    uint32_t b = __umulhi(r * 0x9E3779B1u, nb);
+    for (uint32_t guard = 0; guard < 8u * nb + 8u; ++guard) {
+        const uint32_t boff = (first + b) << 4;
+        const uint4 v = *reinterpret_cast<const uint4*>(lds_at(tab, boff));
+        const int f = bucket_find(v, kr);
+        if (f >= 0) {
+            atomicAdd(lds_at(tab, boff + (uint32_t)f), 1u);
             return;
         }
-        if (++h == S) h = 0;
+        const int e = bucket_first_empty(v);
+        if (e >= 0) {
+            const uint32_t prev = atomicCAS(lds_at(tab, boff + (uint32_t)e), kEmpty, kr | 1u);
+            if (prev == kEmpty) return;
+            if ((prev ^ kr) <= kSlotCountMask) {
+                atomicAdd(lds_at(tab, boff + (uint32_t)e), 1u);
+                return;
+            }
+            continue;  // somebody else took that slot: look at the same bucket again
+        }
+        if (++b == nb) b = 0;
     }
 }
 
-// motion[l][r]
-__device__ __forceinline__ uint32_t table_lookup(const uint32_t* keys, const uint32_t* cnt, uint32_t S,
-                                                 uint32_t key)
+// motion[l][r], general form, starting one bucket after the hashed one (which was full without the key).
+__device__ __noinline__ uint32_t region_lookup_general(const uint32_t* tab, uint32_t d, uint32_t r)
 {
-    uint32_t h = hash_slot(key, S);
-    for (uint32_t probe = 0; probe < S; ++probe) {
-        uint32_t k = keys[h];
-        if (k == key) return (cnt[h >> 1] >> ((h & 1u) << 4)) & 0xFFFFu;
-        if (k == kEmpty) return 0;
-        if (++h == S) h = 0;
+    const uint32_t nb = d & 0xFFFFu, first = d >> 16;
+    const uint32_t kr = r << kSlotRShift;
+    uint32_t b = __umulhi(r * 0x9E3779B1u, nb);
+    for (uint32_t guard = 1; guard < nb; ++guard) {
+        if (++b == nb) b = 0;
+        const uint4 v = *reinterpret_cast<const uint4*>(tab + ((first + b) << 2));
+        if (bucket_find(v, kr) >= 0) return bucket_count(v, kr);
+        if (bucket_first_empty(v) >= 0) return 0;
     }
     return 0;
 }
 
 // ------------------------------------------------------------------------------------------------
 // normalizePoints (DLL@0x180048420): one thread per keypoint; frame found by binary search.
+// A -0.0 result is stored as +0.0 (adding +0.0f): every later use is floor(n * W), which is 0 for
+// both, and it lets the filter test "finite, non-negative" on the bit pattern alone.
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 normalize_kernel(const gms_keypoint* __restrict__ kp, const int64_t* __restrict__ frame_off,
@@ -117,42 +166,53 @@ normalize_kernel(const gms_keypoint* __restrict__ kp, const int64_t* __restrict_
         float w = (float)wh[2 * lo], h = (float)wh[2 * lo + 1];
         const float* p = reinterpret_cast<const float*>(kp + i);
         float2 o;
-        o.x = p[0] / w;  // IEEE fp32 divide (divss)
-        o.y = p[1] / h;
+        o.x = p[0] / w + 0.0f;  // IEEE fp32 divide (divss)
+        o.y = p[1] / h + 0.0f;
         pts[i] = o;
     }
 }
 
 // ------------------------------------------------------------------------------------------------
-// The filter: one workgroup per pair.
+// The filter: one 1024-thread workgroup per pair, KPT matches per thread held in registers.
+// The kernel is VALU-issue bound, so the per-match work is kept to a few instructions: the left cell of
+// a match under grid type g is never computed per match -- a per-pair table indexed by the match's
+// half-cell index gives the table region (insert) and the verified cell result (mark) with one LDS read.
 // ------------------------------------------------------------------------------------------------
+template <int KPT, bool ROT>
 __global__ void __launch_bounds__(kThreads)
 filter_kernel(FilterParams p)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    constexpr int kMcap = KPT * kThreads;
+    constexpr int kNRot = ROT ? 8 : 1;
+    constexpr int kChunk = (KPT % 5 == 0) ? 5 : 4;  // matches a thread keeps in flight through the LDS stages
+    static_assert(KPT % kChunk == 0, "KPT must be a multiple of the chunk");
     const int tid = threadIdx.x;
     const int lane = tid & 63;
+    const int wave = tid >> 6;
 
     const gms_pair pr = p.pairs[blockIdx.x];
     const int m = pr.m;
     const gms_dmatch* __restrict__ matches = p.matches + pr.match_off;
 
-    const int mcap = p.mcap;  // multiple of 64, >= every m
-    const uint32_t S = p.table_slots;
-    uint32_t* code = smem;
-    uint32_t* keys = code + mcap;
-    uint32_t* cnt = keys + S;                    // S/2 dwords, two 16-bit counters each
-    uint32_t* bestmask = cnt + (S >> 1);         // mcap/32 dwords
-    uint32_t* nleft = bestmask + (mcap >> 5);    // 400
-    uint32_t* best = nleft + kLeftN;             // 400
-    uint32_t* accept = best + kLeftN;            // 400
-    uint32_t* chunk_base = accept + kLeftN;      // mcap/64 (+1)
-    uint32_t* misc = chunk_base + (mcap >> 6) + 1;  // [0..7] rotation counts, [8] error, [9..] scan scratch
+    const uint32_t T = p.table_slots;              // multiple of 4
+    uint32_t* tab = smem;                          // per-left-cell regions of [r | count] slots
+    uint32_t* nfine = tab + T;                     // 40 x 40 half-cell histogram of the left points
+    uint32_t* nleft4 = nfine + kFineN;             // [4][400] mNumberPointsInPerCellLeft per grid type
+    uint32_t* desc4 = nleft4 + 4 * kLeftN;         // [4][400] (first bucket << 16) | buckets
+    uint32_t* fdesc4 = desc4 + 4 * kLeftN;         // [4][1664] the same, per half-cell: region of the cell it falls in
+    uint32_t* fres = fdesc4 + 4 * kFineStride;     // [1664] per half-cell: (j* << 8) | rotation bits that pass
+    uint32_t* best = fres + kFineStride;           // 400: (max count << 11) | (2047 - lowest right cell)
+    uint32_t* bestmask = best + kLeftN;            // kMcap / 32
+    uint32_t* chunk_base = bestmask + (kMcap >> 5);// kMcap / 64 + 1
+    uint32_t* misc = chunk_base + (kMcap >> 6) + 1;// [0..7] rotation counts, [8] error, [9] carry, [16..] scan scratch
 
-    if (tid < 16 + kThreads / 64) misc[tid] = 0;
-    for (int i = tid; i < (mcap >> 5); i += kThreads) bestmask[i] = 0;
+    if (tid < 48) misc[tid] = 0;
+    for (int i = tid; i < (kMcap >> 5); i += kThreads) bestmask[i] = 0;
+    for (int i = tid; i < kFineN; i += kThreads) nfine[i] = 0;
+    for (int i = tid; i < 4 * kFineStride; i += kThreads) fdesc4[i] = 0;
 
-    const bool bad_pair = m < 0 || m > mcap || pr.frame_a < 0 || pr.frame_a >= p.n_frames ||
+    const bool bad_pair = m < 0 || m > kMcap || pr.frame_a < 0 || pr.frame_a >= p.n_frames ||
                           pr.frame_b < 0 || pr.frame_b >= p.n_frames;
     int64_t offA = 0, offB = 0;
     int nA = 0, nB = 0;
@@ -167,162 +227,379 @@ filter_kernel(FilterParams p)
     const int mm = bad_pair ? 0 : m;
 
     const int n_scales = p.with_scale ? 5 : 1;
-    const int n_rot = p.with_rotation ? 8 : 1;
     uint32_t best_count = 0;
     int best_scale = -1, best_rot = -1;
+    GMS_STAMP_DECL
     __syncthreads();
     if (bad_pair && tid == 0) misc[8] = 1;
 
+    // ---- both sides of every match, scale 0: one 8-byte load of (queryIdx, trainIdx), two gathers ---------
+    uint32_t code[KPT];
+    {
+        int2 qt[KPT];
+#pragma unroll
+        for (int k = 0; k < KPT; ++k) {
+            const int i = k * kThreads + tid;
+            qt[k] = (i < mm) ? *reinterpret_cast<const int2*>(&matches[i]) : make_int2(-1, -1);
+        }
+        float2 a[KPT], b[KPT];
+        const float2 nan2 = make_float2(__int_as_float(0x7FC00000), __int_as_float(0x7FC00000));
+#pragma unroll
+        for (int k = 0; k < KPT; ++k) {
+            a[k] = ((uint32_t)qt[k].x < (uint32_t)nA) ? ptsA[qt[k].x] : nan2;
+            b[k] = ((uint32_t)qt[k].y < (uint32_t)nB) ? ptsB[qt[k].y] : nan2;
+        }
+        const int wr = p.right_w[0];
+        const uint32_t nr = (uint32_t)(wr * p.right_h[0]);
+        const float fwr = (float)wr, fhr = (float)p.right_h[0];
+        bool any_bad = false;
+#pragma unroll
+        for (int k = 0; k < KPT; ++k) {
+            const int i = k * kThreads + tid;
+            // parity domain: finite, non-negative, < 2^20 -- one unsigned compare on the bit patterns
+            // (negative, NaN and Inf patterns are all above 0x49800000 = 2^20; -0.0 never reaches here)
+            const uint32_t worst = max(max(__float_as_uint(a[k].x), __float_as_uint(a[k].y)),
+                                       max(__float_as_uint(b[k].x), __float_as_uint(b[k].y)));
+            const float fx = 20.0f * a[k].x, fy = 20.0f * a[k].y;   // mulss, rounded to fp32
+            // floor == truncation for non-negative values; 2f is exact
+            const uint32_t hx = (uint32_t)(int)(fx + fx), hy = (uint32_t)(int)(fy + fy);
+            const uint32_t r = (uint32_t)((int)(fwr * b[k].x) + (int)(fhr * b[k].y) * wr);  // no bounds test in the reference
+            const bool ok = worst < 0x49800000u && r < nr;
+            // hx >= 40 or hy >= 40: x >= 20 or y >= 20 under every grid type, never binned
+            const uint32_t f = (ok && hx < 40u && hy < 40u) ? hy * kFineW + hx : kFineInvalid;
+            if (f != kFineInvalid) atomicAdd(&nfine[f], 1u);
+            any_bad |= (i < mm) && !ok;
+            code[k] = (ok ? r : 0u) | (f << kFShift);
+        }
+        if (any_bad) misc[8] = 1;  // benign race: every writer stores 1
+    }
+    __syncthreads();  // nfine complete
+    GMS_STAMP(0);     // bin (HBM read + gathers + half-cell histogram)
+
+    // ---- per grid type, once per pair: nLeft of every cell, its table region, and the half-cell view of it ---
+    for (int g = 0; g < 4; ++g) {
+        uint32_t my_n = 0, my_nb = 0, incl = 0;
+        const int x = tid % kLeftW, y = tid / kLeftW;
+        const int hx0 = 2 * x - (g & 1), hy0 = 2 * y - (g >> 1);
+        if (tid < 448) {  // 7 waves cover the 400 cells
+            if (tid < kLeftN) {
+#pragma unroll
+                for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                    for (int dx = 0; dx < 2; ++dx) {
+                        const int hx = hx0 + dx, hy = hy0 + dy;
+                        if (hx >= 0 && hy >= 0) my_n += nfine[hy * kFineW + hx];  // hx, hy <= 39 always
+                    }
+                my_nb = region_buckets(my_n);
+            }
+            incl = my_nb;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t v = __shfl_up(incl, d);
+                if (lane >= d) incl += v;
+            }
+            if (lane == 63) misc[16 + wave] = incl;
+        }
+        __syncthreads();
+        if (tid < kLeftN) {
+            uint32_t base = 0;
+            for (int w = 0; w < wave; ++w) base += misc[16 + w];
+            const uint32_t d = ((base + incl - my_nb) << 16) | my_nb;
+            nleft4[g * kLeftN + tid] = my_n;
+            desc4[g * kLeftN + tid] = d;
+#pragma unroll
+            for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 2; ++dx) {
+                    const int hx = hx0 + dx, hy = hy0 + dy;
+                    if (hx >= 0 && hy >= 0) fdesc4[g * kFineStride + hy * kFineW + hx] = d;
+                }
+        }
+        __syncthreads();
+    }
+    GMS_STAMP(1);  // region tables
+
     for (int s = 0; s < n_scales; ++s) {
         const int wr = p.right_w[s], hr = p.right_h[s];
-        const int nr = wr * hr;
-        const float fwr = (float)wr, fhr = (float)hr;
 
-        // ---- bin every match: left cells of the 4 grid types, right cell of this scale --------------
-        for (int i = tid; i < mm; i += kThreads) {
-            const int2 qt = *reinterpret_cast<const int2*>(&matches[i]);  // queryIdx, trainIdx
-            uint32_t c = 0;
-            bool ok = qt.x >= 0 && qt.x < nA && qt.y >= 0 && qt.y < nB;
-            if (ok) {
-                const float2 a = ptsA[qt.x];
-                const float2 b = ptsB[qt.y];
-                // parity domain: finite, non-negative, < 2^20 (NaN fails every compare)
-                ok = a.x >= 0.f && a.x < 1048576.f && a.y >= 0.f && a.y < 1048576.f &&
-                     b.x >= 0.f && b.x < 1048576.f && b.y >= 0.f && b.y < 1048576.f;
-                if (ok) {
-                    const float fx = 20.0f * a.x, fy = 20.0f * a.y;       // mulss, rounded to fp32
-                    const int lx = floor_f32(fx), ly = floor_f32(fy);
-                    const int lx2 = floor_f64((double)fx + 0.5), ly2 = floor_f64((double)fy + 0.5);
-                    const int rx = floor_f32(fwr * b.x), ry = floor_f32(fhr * b.y);
-                    const int r = rx + ry * wr;                             // no bounds test in the reference
-                    ok = r >= 0 && r < nr;
-                    c = (uint32_t)r | ((uint32_t)min(lx, 31) << kLxShift) | ((uint32_t)min(ly, 31) << kLyShift) |
-                        ((lx2 > lx) ? kSxBit : 0u) | ((ly2 > ly) ? kSyBit : 0u) | kValidBit;
-                }
+        if (s > 0) {
+            // ---- getGridIndexRight again for this scale's right grid ------------------------------------------
+            const uint32_t nr = (uint32_t)(wr * hr);
+            const float fwr = (float)wr, fhr = (float)hr;
+            int t[KPT];
+#pragma unroll
+            for (int k = 0; k < KPT; ++k) {
+                const int i = k * kThreads + tid;
+                t[k] = (i < mm) ? matches[i].trainIdx : -1;
             }
-            if (!ok) {
-                c = 0;
-                misc[8] = 1;  // benign race: every writer stores 1
+            float2 b[KPT];
+#pragma unroll
+            for (int k = 0; k < KPT; ++k) b[k] = ((uint32_t)t[k] < (uint32_t)nB) ? ptsB[t[k]] : make_float2(0.f, 0.f);
+            bool any_bad = false;
+#pragma unroll
+            for (int k = 0; k < KPT; ++k) {
+                const int i = k * kThreads + tid;
+                const uint32_t r = (uint32_t)((int)(fwr * b[k].x) + (int)(fhr * b[k].y) * wr);
+                const bool ok = r < nr;
+                any_bad |= (i < mm) && !ok;
+                code[k] = (code[k] & (kFMask << kFShift)) | (ok ? r : 0u);
+                if (!ok) code[k] = kFineInvalid << kFShift;
             }
-            code[i] = c;
+            if (any_bad) misc[8] = 1;
         }
 
         for (int g = 0; g < 4; ++g) {
-            // ---- motion.setTo(0), nLeft = 0, cellPairs = -1 ------------------------------------------
-            for (uint32_t i = tid; i < S; i += kThreads) keys[i] = kEmpty;
-            for (uint32_t i = tid; i < (S >> 1); i += kThreads) cnt[i] = 0;
-            for (int i = tid; i < kLeftN; i += kThreads) {
-                nleft[i] = 0;
-                best[i] = 0;
-                accept[i] = 0;
+            const uint32_t* nleft = nleft4 + g * kLeftN;
+            const uint32_t* desc = desc4 + g * kLeftN;
+            const uint32_t* fdesc = fdesc4 + g * kFineStride;
+
+            // ---- motion.setTo(0); cellPairs = "no match" ------------------------------------------------------
+            {
+                const uint4 e4 = make_uint4(kEmpty, kEmpty, kEmpty, kEmpty);
+                uint4* tab4 = reinterpret_cast<uint4*>(tab);
+                for (uint32_t i = tid; i < (T >> 2); i += kThreads) tab4[i] = e4;
             }
             __syncthreads();
+            GMS_STAMP(2);  // clear
+            // every wave is past the previous grid type's mark (it reads fres): reset it before verify writes
+            for (int i = tid; i < kFineStride; i += kThreads) fres[i] = kNoMatch;
 
-            // ---- assignMatchPairs: sparse motion[l][r]++, nLeft[l]++ ---------------------------------
-            for (int i = tid; i < mm; i += kThreads) {
-                const uint32_t c = code[i];
-                const int l = left_cell(c, g);
-                if (l >= 0) {
-                    table_insert(keys, cnt, S, ((uint32_t)l << 11) | (c & kRMask));
-                    atomicAdd(&nleft[l], 1u);
-                }
-            }
-            __syncthreads();
-
-            // ---- arg-max over each left cell's row: max count, lowest right cell on ties -------------
-            for (uint32_t h = tid; h < S; h += kThreads) {
-                const uint32_t k = keys[h];
-                if (k != kEmpty) {
-                    const uint32_t c = (cnt[h >> 1] >> ((h & 1u) << 4)) & 0xFFFFu;
-                    atomicMax(&best[k >> 11], (c << 11) | (2047u - (k & kRMask)));
-                }
-            }
-            __syncthreads();
-
-            // ---- verifyCellPairs: one thread per (left cell, rotation) -----------------------------------
-            for (int item = tid; item < kLeftN * n_rot; item += kThreads) {
-                const int i = item / n_rot, rot = item - i * n_rot;
-                if (nleft[i] == 0) continue;
-                const int j = 2047 - (int)(best[i] & kRMask);
-                const int jx = j % wr, jy = j / wr;
-                const int ix = i % kLeftW, iy = i / kLeftW;
-                int score = 0, tsum = 0, numpair = 0;
+            // ---- assignMatchPairs: motion[l][r]++, kChunk matches in flight per thread -----------------------
+            {
+                uint32_t pending = 0;
 #pragma unroll
-                for (int k = 0; k < 9; ++k) {
-                    const int lx = ix + (k % 3) - 1, ly = iy + (k / 3) - 1;
-                    const int q = c_rot[rot][k];
-                    const int rx = jx + (q % 3) - 1, ry = jy + (q / 3) - 1;
-                    if (lx < 0 || lx >= kLeftW || ly < 0 || ly >= kLeftH) continue;  // ll == -1
-                    if (rx < 0 || rx >= wr || ry < 0 || ry >= hr) continue;          // rr == -1
-                    const int ll = lx + ly * kLeftW, rr = rx + ry * wr;
-                    score += (int)table_lookup(keys, cnt, S, ((uint32_t)ll << 11) | (uint32_t)rr);
-                    tsum += (int)nleft[ll];
-                    numpair++;
+                for (int k0 = 0; k0 < KPT; k0 += kChunk) {
+                    uint32_t d[kChunk];   // region of the match's left cell under this grid type, 0 = not binned
+#pragma unroll
+                    for (int c = 0; c < kChunk; ++c) d[c] = fdesc[(code[k0 + c] >> kFShift) & kFMask];
+                    uint32_t boff[kChunk];  // byte offset of the hashed bucket
+                    uint4 v[kChunk];
+#pragma unroll
+                    for (int c = 0; c < kChunk; ++c) {
+                        const uint32_t nb = d[c] & 0xFFFFu;
+                        boff[c] = ((d[c] >> 16) + __umulhi((code[k0 + c] & kRMask) * 0x9E3779B1u, nb)) << 4;
+                        v[c] = make_uint4(0, 0, 0, 0);
+                        if (nb) v[c] = *reinterpret_cast<const uint4*>(lds_at(tab, boff[c]));
+                    }
+#pragma unroll
+                    for (int c = 0; c < kChunk; ++c) {
+#ifdef GMS_DBG_NO_FAST
+                        if (d[c] & 0xFFFFu) pending |= 1u << (k0 + c);
+                        if (false) {
+#else
+                        if (d[c] & 0xFFFFu) {
+#endif
+                            const uint32_t kr = (code[k0 + c] & kRMask) << kSlotRShift;
+                            const int f = bucket_find(v[c], kr);
+                            if (f >= 0) {
+                                atomicAdd(lds_at(tab, boff[c] + (uint32_t)f), 1u);
+                            } else {
+                                bool done = false;
+                                const int e = bucket_first_empty(v[c]);
+                                if (e >= 0) {
+                                    const uint32_t prev = atomicCAS(lds_at(tab, boff[c] + (uint32_t)e), kEmpty, kr | 1u);
+                                    done = prev == kEmpty;
+                                    if (!done && (prev ^ kr) <= kSlotCountMask) {
+                                        atomicAdd(lds_at(tab, boff[c] + (uint32_t)e), 1u);
+                                        done = true;
+                                    }
+                                }
+                                if (!done) pending |= 1u << (k0 + c);
+                            }
+                        }
+                    }
                 }
-                // divsd, sqrtsd, mulsd, comisd: reject iff thresh > score
-                const double thresh = sqrt((double)tsum / (double)numpair) * p.threshold_factor;
-                if (!(thresh > (double)score)) atomicOr(&accept[i], 1u << rot);
+                GMS_STAMP(3);  // insert: first-probe rounds
+                // leftovers (full bucket, or lost the race for its empty slot to another right cell)
+                while (pending) {
+                    const int k1 = __ffs(pending) - 1;
+                    pending &= pending - 1u;
+                    uint32_t cw = 0;
+#pragma unroll
+                    for (int k = 0; k < KPT; ++k) cw = (k == k1) ? code[k] : cw;
+                    region_insert_general(tab, fdesc[(cw >> kFShift) & kFMask], cw & kRMask);
+                }
+                GMS_STAMP(10);  // insert: leftovers
             }
             __syncthreads();
+            GMS_STAMP(11);  // insert: wait for the other waves
 
-            // ---- mark inliers: cellPairs[l] == r, for all rotations at once ------------------------------
-            for (int i = tid; i < mm; i += kThreads) {
-                const uint32_t c = code[i];
-                const int l = left_cell(c, g);
-                if (l >= 0) {
-                    const uint32_t j = 2047u - (best[l] & kRMask);
-                    if (j == (c & kRMask)) code[i] = c | (accept[l] << kAccShift);
+            // ---- arg-max over each left cell's row: max count, lowest right cell on ties ---------------------
+            if (tid < kLeftN) {
+                const uint32_t dd = desc[tid];
+                const uint32_t nb = dd & 0xFFFFu;
+                const uint4* reg4 = reinterpret_cast<const uint4*>(tab) + (dd >> 16);
+                uint32_t bp = 0;
+#pragma unroll 2
+                for (uint32_t i = 0; i < nb; ++i) {
+                    const uint4 q = reg4[i];
+                    // an empty slot is 0xFFFFFFFF: give it key 0 so that it never wins (real counts are >= 1)
+                    const uint32_t k0 = (q.x == kEmpty) ? 0u : ((q.x & kSlotCountMask) << 11) | (2047u - (q.x >> kSlotRShift));
+                    const uint32_t k1 = (q.y == kEmpty) ? 0u : ((q.y & kSlotCountMask) << 11) | (2047u - (q.y >> kSlotRShift));
+                    const uint32_t k2 = (q.z == kEmpty) ? 0u : ((q.z & kSlotCountMask) << 11) | (2047u - (q.z >> kSlotRShift));
+                    const uint32_t k3 = (q.w == kEmpty) ? 0u : ((q.w & kSlotCountMask) << 11) | (2047u - (q.w >> kSlotRShift));
+                    bp = max(max(bp, k0), max(max(k1, k2), k3));
+                }
+                best[tid] = bp;
+            }
+            __syncthreads();
+            GMS_STAMP(4);  // arg-max
+
+            // ---- verifyCellPairs: one lane per (left cell, rotation), 4 neighbour look-ups in flight ----------
+            for (int item = tid; item < kLeftN * kNRot; item += kThreads) {
+                const int i = ROT ? (item >> 3) : item;
+                const int rot = ROT ? (item & 7) : 0;
+                const uint32_t ni = nleft[i];
+                uint32_t pass = 0;
+                const uint32_t bi = best[i];
+                const int j = 2047 - (int)(bi & kRMask);
+                if (ni != 0) {
+                    const int jx = j % wr, jy = j / wr;
+                    const int ix = i % kLeftW, iy = i / kLeftW;
+                    // centre pair (k = 4): ll = i, rr = j*, whose count is the arg-max count
+                    uint32_t score = bi >> 11, tsum = ni, numpair = 1;
+#pragma unroll
+                    for (int h = 0; h < 8; h += 4) {
+                        uint32_t dn[4], rq[4];
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            const int k8 = h + c;
+                            const int k = k8 < 4 ? k8 : k8 + 1;
+                            const int q = ROT ? c_rot[rot][k] : k;
+                            const int lx = ix + (k % 3) - 1, ly = iy + (k / 3) - 1;
+                            const int rx = jx + (q % 3) - 1, ry = jy + (q / 3) - 1;
+                            const bool okp = (uint32_t)lx < (uint32_t)kLeftW && (uint32_t)ly < (uint32_t)kLeftH &&  // ll != -1
+                                             (uint32_t)rx < (uint32_t)wr && (uint32_t)ry < (uint32_t)hr;            // rr != -1
+                            const int ll = okp ? lx + ly * kLeftW : 0;
+                            rq[c] = okp ? (uint32_t)(rx + ry * wr) : 0u;  // 0: matches no slot of the all-empty stand-in
+                            tsum += okp ? nleft[ll] : 0u;
+                            dn[c] = okp ? desc[ll] : 0u;
+                            numpair += okp ? 1u : 0u;
+                        }
+                        uint4 v[4];
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            const uint32_t nb = dn[c] & 0xFFFFu;
+                            v[c] = make_uint4(kEmpty, kEmpty, kEmpty, kEmpty);
+                            if (nb) v[c] = *reinterpret_cast<const uint4*>(tab + (((dn[c] >> 16) + __umulhi(rq[c] * 0x9E3779B1u, nb)) << 2));
+                        }
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            const uint32_t kr = rq[c] << kSlotRShift;
+#ifdef GMS_DBG_SLOW_LOOKUP
+                            if (dn[c] & 0xFFFFu) {
+                                uint32_t cnt2 = 0;
+                                const uint32_t nb2 = dn[c] & 0xFFFFu, first2 = dn[c] >> 16;
+                                for (uint32_t bb = 0; bb < nb2; ++bb)
+                                    for (int e2 = 0; e2 < 4; ++e2) {
+                                        const uint32_t sv = tab[((first2 + bb) << 2) + e2];
+                                        if (sv != kEmpty && (sv >> kSlotRShift) == rq[c]) cnt2 += sv & kSlotCountMask;
+                                    }
+                                score += cnt2;
+                            } else if (false) {
+#else
+                            if (bucket_find(v[c], kr) >= 0) {
+                                score += bucket_count(v[c], kr);
+                            } else if (bucket_first_empty(v[c]) < 0) {  // full bucket without the key: walk on
+#endif
+                                score += region_lookup_general(tab, dn[c], rq[c]);
+                            }
+                        }
+                    }
+                    // divsd, sqrtsd, mulsd, comisd: reject iff thresh > score
+                    const double thresh = sqrt((double)tsum / (double)numpair) * p.threshold_factor;
+                    pass = (thresh > (double)score) ? 0u : 1u;
+                }
+                uint32_t bits = pass;
+                bool writer = ni != 0;
+                if (ROT) {
+                    const unsigned long long bal = __ballot(pass);
+                    bits = (uint32_t)(bal >> (lane & 56)) & 0xFFu;
+                    writer = writer && (lane & 7) == 0;
+                }
+                if (writer) {
+                    // cellPairs[i] as every half-cell of cell i sees it
+                    const uint32_t cr = ((uint32_t)j << 8) | bits;
+                    const int hx0 = 2 * (i % kLeftW) - (g & 1), hy0 = 2 * (i / kLeftW) - (g >> 1);
+#pragma unroll
+                    for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                        for (int dx = 0; dx < 2; ++dx) {
+                            const int hx = hx0 + dx, hy = hy0 + dy;
+                            if (hx >= 0 && hy >= 0) fres[hy * kFineW + hx] = cr;
+                        }
                 }
             }
             __syncthreads();
+            GMS_STAMP(5);  // verify
+
+            // ---- mark inliers: cellPairs[l] == r, all rotations at once ---------------------------------------
+            {
+                uint32_t cr[KPT];
+#pragma unroll
+                for (int k = 0; k < KPT; ++k) cr[k] = fres[(code[k] >> kFShift) & kFMask];
+#pragma unroll
+                for (int k = 0; k < KPT; ++k)
+                    if ((cr[k] >> 8) == (code[k] & kRMask)) code[k] |= cr[k] << kAccShift;
+            }
+            GMS_STAMP(6);  // mark
         }
 
         // ---- run() return value for each rotation of this scale ---------------------------------------
-        for (int i0 = tid - lane; i0 < mm; i0 += kThreads) {
-            const int i = i0 + lane;
-            const uint32_t bits = (i < mm) ? (code[i] >> kAccShift) : 0u;
-            for (int rot = 0; rot < n_rot; ++rot) {
-                const unsigned long long b = __ballot((bits >> rot) & 1u);
-                if (lane == 0 && b) atomicAdd(&misc[rot], (uint32_t)__popcll(b));
+        {
+            uint32_t cnt[kNRot];
+#pragma unroll
+            for (int r = 0; r < kNRot; ++r) cnt[r] = 0;
+#pragma unroll
+            for (int k = 0; k < KPT; ++k)
+#pragma unroll
+                for (int r = 0; r < kNRot; ++r)
+                    cnt[r] += (uint32_t)__popcll(__ballot((code[k] >> (kAccShift + r)) & 1u));
+            if (lane == 0) {
+#pragma unroll
+                for (int r = 0; r < kNRot; ++r)
+                    if (cnt[r]) atomicAdd(&misc[r], cnt[r]);
             }
         }
         __syncthreads();
 
         // ---- getInlierMask: keep on strict '>' (scale outer, rotation inner) ---------------------------
         int winner = -1;
-        for (int rot = 0; rot < n_rot; ++rot) {
-            const uint32_t c = misc[rot];
+#pragma unroll
+        for (int r = 0; r < kNRot; ++r) {
+            const uint32_t c = misc[r];
             if (c > best_count) {
                 best_count = c;
                 best_scale = s;
-                best_rot = rot + 1;
-                winner = rot;
+                best_rot = r + 1;
+                winner = r;
             }
         }
         if (winner >= 0) {
-            for (int i0 = tid - lane; i0 < mm; i0 += kThreads) {
-                const int i = i0 + lane;
-                const uint32_t bit = (i < mm) ? ((code[i] >> (kAccShift + winner)) & 1u) : 0u;
-                const unsigned long long b = __ballot(bit);
+#pragma unroll
+            for (int k = 0; k < KPT; ++k) {
+                const unsigned long long b = __ballot((code[k] >> (kAccShift + winner)) & 1u);
                 if (lane == 0) {
-                    bestmask[(i0 >> 5)] = (uint32_t)b;
-                    bestmask[(i0 >> 5) + 1] = (uint32_t)(b >> 32);
+                    const int ch = k * (kThreads / 64) + wave;  // chunk of 64 consecutive matches
+                    bestmask[2 * ch] = (uint32_t)b;
+                    bestmask[2 * ch + 1] = (uint32_t)(b >> 32);
                 }
             }
         }
+#pragma unroll
+        for (int k = 0; k < KPT; ++k) code[k] &= (1u << kAccShift) - 1u;
         __syncthreads();
         if (tid < 8) misc[tid] = 0;
-        __syncthreads();
+        GMS_STAMP(7);  // count + select
     }
+    __syncthreads();
 
     // ---- copy-out: surviving DMatch verbatim, in input order (DLL@0x180048340) -----------------------
     const bool failed = misc[8] != 0;
     const int n_chunks = (mm + 63) >> 6;
     {
-        // exclusive scan of per-chunk popcounts; THREADS chunks per round, carry in misc[9]
+        // exclusive scan of per-chunk popcounts; kThreads chunks per round, carry in misc[9]
         uint32_t* wave_tot = misc + 16;
-        if (tid == 0) misc[9] = 0;
-        __syncthreads();
         for (int base = 0; base < n_chunks; base += kThreads) {
             const int c = base + tid;
             const uint32_t v = (c < n_chunks && !failed) ? __popc(bestmask[2 * c]) + __popc(bestmask[2 * c + 1]) : 0u;
@@ -332,10 +609,10 @@ filter_kernel(FilterParams p)
                 const uint32_t t = __shfl_up(incl, d);
                 if (lane >= d) incl += t;
             }
-            if (lane == 63) wave_tot[tid >> 6] = incl;
+            if (lane == 63) wave_tot[wave] = incl;
             __syncthreads();
             uint32_t wave_off = misc[9];
-            for (int w = 0; w < (tid >> 6); ++w) wave_off += wave_tot[w];
+            for (int w = 0; w < wave; ++w) wave_off += wave_tot[w];
             if (c < n_chunks) chunk_base[c] = wave_off + incl - v;
             __syncthreads();
             if (tid == kThreads - 1) misc[9] = wave_off + incl;
@@ -343,24 +620,30 @@ filter_kernel(FilterParams p)
         }
     }
     const uint32_t total = misc[9];
+    GMS_STAMP(8);  // out scan
 
     gms_dmatch* __restrict__ out = p.out + pr.match_off;
     uint8_t* mask_out = p.mask ? p.mask + pr.match_off : nullptr;
-    for (int i0 = tid - lane; i0 < mm; i0 += kThreads) {
-        const int i = i0 + lane;
-        const int c = i0 >> 6;
-        const unsigned long long bits =
-            failed ? 0ull : ((unsigned long long)bestmask[2 * c] | ((unsigned long long)bestmask[2 * c + 1] << 32));
-        const bool in = (bits >> lane) & 1ull;
-        if (i < mm) {
-            if (mask_out) mask_out[i] = in ? 1 : 0;
-            if (in) {
-                const uint32_t pos = chunk_base[c] + (uint32_t)__popcll(bits & ((1ull << lane) - 1ull));
-                const uint4 v = *reinterpret_cast<const uint4*>(&matches[i]);
-                *reinterpret_cast<uint4*>(&out[pos]) = v;
+#pragma unroll
+    for (int k = 0; k < KPT; ++k) {
+        const int i = k * kThreads + tid;
+        const int c = i >> 6;
+        if (i - lane < mm) {  // wave-uniform
+            const unsigned long long bits =
+                failed ? 0ull : ((unsigned long long)bestmask[2 * c] | ((unsigned long long)bestmask[2 * c + 1] << 32));
+            const bool in = (bits >> lane) & 1ull;
+            if (i < mm) {
+                if (mask_out) mask_out[i] = in ? 1 : 0;
+                if (in) {
+                    const uint32_t pos = chunk_base[c] + (uint32_t)__popcll(bits & ((1ull << lane) - 1ull));
+                    const uint4 v = *reinterpret_cast<const uint4*>(&matches[i]);
+                    *reinterpret_cast<uint4*>(&out[pos]) = v;
+                }
             }
         }
     }
+    GMS_STAMP(9);  // copy-out
+    GMS_STAMP_FLUSH;
     if (tid == 0) {
         gms_pair_result r;
         r.n_inliers = failed ? 0 : (int)total;
@@ -385,11 +668,26 @@ __global__ void threshold_kernel(const int32_t* T, const int32_t* n, const int32
 // ------------------------------------------------------------------------------------------------
 // launch helpers (called from gms_capi.cpp through gms_kernels.h)
 // ------------------------------------------------------------------------------------------------
-size_t filter_lds_bytes(int mcap, uint32_t table_slots)
+size_t filter_lds_bytes(int kpt, uint32_t table_slots)
 {
-    size_t dwords = (size_t)mcap + table_slots + (table_slots >> 1) + (mcap >> 5) + 3 * kLeftN +
-                    (mcap >> 6) + 1 + 16 + kThreads / 64 + 16;
+    const size_t mcap = (size_t)kpt * kThreads;
+    size_t dwords = table_slots + kFineN + 9 * kLeftN + 5 * 1664 + (mcap >> 5) + (mcap >> 6) + 1 + 64;
     return dwords * 4;
+}
+
+uint32_t filter_table_slots(int kpt)
+{
+    // sum over cells of 4 * region_buckets(n) <= 1.5 * M + 3 * 400
+    const uint32_t mcap = (uint32_t)kpt * kThreads;
+    return (mcap + (mcap >> 1) + 3 * kLeftN + 3u) & ~3u;
+}
+
+int filter_pick_kpt(int max_m)
+{
+    static const int kKpt[] = {4, 10, 16, 24};
+    for (int k : kKpt)
+        if (max_m <= k * kThreads && filter_lds_bytes(k, filter_table_slots(k)) <= kLdsBytes) return k;
+    return 0;
 }
 
 hipError_t launch_normalize(const gms_keypoint* d_kp, const int64_t* d_frame_off, const int32_t* d_wh,
@@ -403,14 +701,32 @@ hipError_t launch_normalize(const gms_keypoint* d_kp, const int64_t* d_frame_off
     return hipGetLastError();
 }
 
-hipError_t launch_filter(const FilterParams& p, int n_pairs, size_t lds_bytes, hipStream_t stream)
+template <int KPT, bool ROT>
+static hipError_t launch_filter_t(const FilterParams& p, int n_pairs, size_t lds_bytes, hipStream_t stream)
+{
+    static bool attr_set = false;  // per instantiation; the largest request this variant can make
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(filter_kernel<KPT, ROT>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((filter_kernel<KPT, ROT>), dim3((unsigned)n_pairs), dim3(kThreads), lds_bytes, stream, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_filter(const FilterParams& p, int kpt, int n_pairs, hipStream_t stream)
 {
     if (n_pairs <= 0) return hipSuccess;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(filter_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(filter_kernel, dim3((unsigned)n_pairs), dim3(kThreads), lds_bytes, stream, p);
-    return hipGetLastError();
+    const size_t lds = filter_lds_bytes(kpt, p.table_slots);
+    const bool rot = p.with_rotation != 0;
+    switch (kpt) {
+    case 4: return rot ? launch_filter_t<4, true>(p, n_pairs, lds, stream) : launch_filter_t<4, false>(p, n_pairs, lds, stream);
+    case 10: return rot ? launch_filter_t<10, true>(p, n_pairs, lds, stream) : launch_filter_t<10, false>(p, n_pairs, lds, stream);
+    case 16: return rot ? launch_filter_t<16, true>(p, n_pairs, lds, stream) : launch_filter_t<16, false>(p, n_pairs, lds, stream);
+    case 24: return rot ? launch_filter_t<24, true>(p, n_pairs, lds, stream) : launch_filter_t<24, false>(p, n_pairs, lds, stream);
+    default: return hipErrorInvalidValue;
+    }
 }
 
 hipError_t launch_threshold(const int32_t* d_T, const int32_t* d_n, const int32_t* d_score, double factor,

@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""Diagnostic (not product): run the bench workload on libgms_hip_diag.so (built with -DGMS_PHASE_TIMING)
+and print the mean shader-clock cycles thread 0 of a workgroup spends in each phase of filter_kernel.
+Read the SHARES, not the length: the stamps themselves cost cycles."""
+import argparse
+import ctypes as C
+import importlib
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+PHASES = ["bin", "region_tables", "clear", "insert_first", "argmax", "verify", "mark", "count_select", "out_scan", "copy_out", "insert_leftover", "insert_barrier"]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--pairs", type=int, default=1024)
+    ap.add_argument("--rot", type=int, default=0)
+    ap.add_argument("--scale", type=int, default=0)
+    a = ap.parse_args()
+    capi = importlib.import_module("sfm-gms_amd.capi")
+    diag_path = os.path.join(ROOT, "sfm-gms_amd", "csrc", "libgms_hip_diag.so")
+    capi.library_path = lambda: diag_path
+    pkg = importlib.import_module("sfm-gms_amd")
+    synth = importlib.import_module("sfm-gms_amd.synth")
+    lib = pkg.load_library()
+    dev = torch.device("cuda", 0)
+    ctx = pkg.GmsContext(0)
+    stream = torch.cuda.Stream(device=dev)
+    ctx.set_stream(stream.cuda_stream)
+    args = argparse.Namespace(pairs=a.pairs, frames=64, features=10000, inlier_frac=0.5)
+    wl = bench.build_workload(args, 0, 1, dev, pkg, synth, ctx)
+    dbuf = torch.zeros(a.pairs * 12, dtype=torch.int64, device=dev)
+    lib.gms_diag_set_buffer.argtypes = [C.c_void_p]
+    lib.gms_diag_set_buffer(dbuf.data_ptr())
+    for _ in range(3):
+        with torch.cuda.stream(stream):
+            bench.launch(ctx, wl, bool(a.rot), bool(a.scale))
+    torch.cuda.synchronize()
+    d = dbuf.cpu().numpy().reshape(-1, 12)[:, :12].astype(np.float64)
+    mean = d.mean(axis=0)
+    tot = mean.sum()
+    out = {"pairs": a.pairs, "rot": a.rot, "scale": a.scale, "total_cycles": tot,
+           "phases": {n: {"cycles": float(c), "share": float(c / tot)} for n, c in zip(PHASES, mean)}}
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()
