@@ -7,6 +7,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -184,10 +185,19 @@ int gms_filter_device(gms_ctx* c, const float* d_pts, const int64_t* d_frame_off
     const int kpt = gms::filter_pick_kpt(max_m);
     if (!kpt) return GMS_ERR_CAPACITY;
     p.table_slots = gms::filter_table_slots(kpt);
+    p.region_shift = gms::filter_region_shift(kpt);
     p.pts = reinterpret_cast<const float2*>(d_pts);
     p.frame_off = d_frame_off;
     p.n_frames = n_frames;
     p.pairs = d_pairs;
+    p.n_pairs = n_pairs;
+    // experimental, off by default (measured slower at 10k matches/pair): GMS_PREFETCH_STRIDE=256 touches the
+    // match array of the pair one dispatch round ahead
+    static const int prefetch_stride = [] {
+        const char* e = std::getenv("GMS_PREFETCH_STRIDE");
+        return e ? std::atoi(e) : 0;
+    }();
+    p.prefetch_stride = prefetch_stride;
     p.matches = d_matches;
     p.out = d_out;
     p.results = d_results;

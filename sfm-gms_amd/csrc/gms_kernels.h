@@ -18,11 +18,14 @@ struct FilterParams {
     const int64_t* frame_off;   // n_frames + 1
     int n_frames;
     const gms_pair* pairs;
+    int n_pairs;
+    int prefetch_stride;        // workgroup b touches the match array of pair b + stride (0 = off)
     const gms_dmatch* matches;
     gms_dmatch* out;
     gms_pair_result* results;
     uint8_t* mask;              // optional
-    uint32_t table_slots;       // multiple of 4, >= 1.5 * KPT * 1024 + 1200
+    uint32_t table_slots;       // multiple of 4: data + header buckets of all 400 regions
+    int region_shift;           // region slots per match = 1 + 2^-shift
     int with_rotation, with_scale;
     double threshold_factor;
     int right_w[5], right_h[5]; // setScale (DLL@0x180048c10): cvRound(20 * ratio[s])
@@ -33,6 +36,7 @@ struct FilterParams {
 
 int        filter_pick_kpt(int max_m);   // matches per thread (template variant) for max_m, 0 = too large
 uint32_t   filter_table_slots(int kpt);
+int        filter_region_shift(int kpt);
 size_t     filter_lds_bytes(int kpt, uint32_t table_slots);
 hipError_t launch_normalize(const gms_keypoint* d_kp, const int64_t* d_frame_off, const int32_t* d_wh,
                             int n_frames, int64_t total_kp, float* d_pts, hipStream_t stream);

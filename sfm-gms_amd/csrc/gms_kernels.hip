@@ -42,7 +42,7 @@ constexpr uint32_t kEmpty = 0xFFFFFFFFu;
 #ifdef GMS_PHASE_TIMING
 #define GMS_STAMP_DECL unsigned long long ph_[12] = {0}; unsigned long long t_prev_ = __builtin_readcyclecounter();
 #define GMS_STAMP(k) do { unsigned long long t_ = __builtin_readcyclecounter(); ph_[k] += t_ - t_prev_; t_prev_ = t_; } while (0)
-#define GMS_STAMP_FLUSH do { if (tid == 0 && p.diag) for (int k_ = 0; k_ < 12; ++k_) p.diag[blockIdx.x * 12 + k_] = ph_[k_]; } while (0)
+#define GMS_STAMP_FLUSH do { if (tid == 0 && p.diag) { ph_[4] = misc[40]; for (int k_ = 0; k_ < 12; ++k_) p.diag[blockIdx.x * 12 + k_] = ph_[k_]; } } while (0)
 #else
 #define GMS_STAMP_DECL
 #define GMS_STAMP(k)
@@ -63,9 +63,19 @@ constexpr uint32_t kNoMatch = 0xFFFFFF00u; // fres value that equals no right ce
 constexpr int kSlotRShift = 21;
 constexpr uint32_t kSlotCountMask = (1u << kSlotRShift) - 1u;
 
-// buckets (of 4 slots) of a left cell holding n matches: slots >= n + 1, so an empty slot always exists
-// and ends every probe chain; about 1.5 slots per match keeps most buckets short of full
-__device__ __forceinline__ uint32_t region_buckets(uint32_t n) { return n ? ((n + (n >> 1) + 3u) >> 2) : 0u; }
+// Data buckets (of 4 slots) of a left cell holding n matches: slots >= distinct right cells + 1, so an
+// empty slot always exists and ends every probe chain. sh = 0, 1, 2 gives about 2, 1.5, 1.25 slots per match;
+// 2048 buckets already exceed the 1600 right cells any region can hold.
+__device__ __forceinline__ uint32_t region_buckets(uint32_t n, int sh)
+{
+    return n ? min((n + (n >> sh) + 3u) >> 2, 2048u) : 0u;
+}
+
+// bucket of right cell r in a region of nb <= 2048 buckets: Fibonacci hash on 12 bits, all 24-bit multiplies
+__device__ __forceinline__ uint32_t bucket_of(uint32_t r, uint32_t nb)
+{
+    return __umul24(__umul24(r, 2531u) & 0xFFFu, nb) >> 12;
+}
 
 // byte offset (0, 4, 8, 12) of the slot of bucket v whose key is r (kr = r << 21), or -1
 __device__ __forceinline__ int bucket_find(const uint4& v, uint32_t kr)
@@ -86,6 +96,13 @@ __device__ __forceinline__ int bucket_first_empty(const uint4& v)
     o = (v.x == kEmpty) ? 0 : o;
     return o;
 }
+// first empty slot of bucket v, trying slot pref (0..3) first: different right cells that meet in an empty
+// bucket at the same moment then mostly go for different slots instead of racing for slot 0
+__device__ __forceinline__ int bucket_pref_empty(const uint4& v, uint32_t pref)
+{
+    const uint32_t vp = pref == 0 ? v.x : pref == 1 ? v.y : pref == 2 ? v.z : v.w;
+    return vp == kEmpty ? (int)(pref << 2) : bucket_first_empty(v);
+}
 __device__ __forceinline__ uint32_t bucket_count(const uint4& v, uint32_t kr)
 {
     uint32_t c = 0;
@@ -101,42 +118,52 @@ __device__ __forceinline__ uint32_t* lds_at(uint32_t* base, uint32_t byte_off)
     return reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(base) + byte_off);
 }
 
-// motion[l][r]++, general form: walk the region d = (first bucket << 16) | buckets from its hashed bucket.
-// Every lane terminates: the region always has an empty slot.
-__device__ __noinline__ void region_insert_general(uint32_t* tab, uint32_t d, uint32_t r)
+// A region is one header bucket followed by nb data buckets; d = (header bucket << 16) | nb.
+// Header dword 0 is the running arg-max of the cell's row, kept inverted so that the table's 0xFFFFFFFF
+// fill means "nothing yet": ~((count << 11) | (2047 - right cell)), updated with atomicMin. The largest
+// key ever reached by a slot is its final one, so the minimum over all updates is the row's arg-max with
+// the lowest right cell winning ties -- the reference's ascending scan with strict '>'.
+__device__ __forceinline__ void header_update(uint32_t* tab, uint32_t d, uint32_t r, uint32_t count)
 {
-    const uint32_t nb = d & 0xFFFFu, first = d >> 16;
+    atomicMin(lds_at(tab, (d >> 16) << 4), ~((count << 11) | (2047u - r)));
+}
+
+// motion[l][r]++, general form: walk the region from its hashed bucket.
+// Every lane terminates: the region always has an empty slot.
+__device__ __forceinline__ void region_insert_general(uint32_t* tab, uint32_t d, uint32_t r)
+{
+    const uint32_t nb = d & 0xFFFFu, first = (d >> 16) + 1u;
     if (nb == 0) return;
     const uint32_t kr = r << kSlotRShift;
-    uint32_t b = __umulhi(r * 0x9E3779B1u, nb);
+    uint32_t b = bucket_of(r, nb);
     for (uint32_t guard = 0; guard < 8u * nb + 8u; ++guard) {
         const uint32_t boff = (first + b) << 4;
         const uint4 v = *reinterpret_cast<const uint4*>(lds_at(tab, boff));
         const int f = bucket_find(v, kr);
         if (f >= 0) {
-            atomicAdd(lds_at(tab, boff + (uint32_t)f), 1u);
+            const uint32_t old = atomicAdd(lds_at(tab, boff + (uint32_t)f), 1u);
+            header_update(tab, d, r, (old & kSlotCountMask) + 1u);
             return;
         }
         const int e = bucket_first_empty(v);
         if (e >= 0) {
             const uint32_t prev = atomicCAS(lds_at(tab, boff + (uint32_t)e), kEmpty, kr | 1u);
-            if (prev == kEmpty) return;
-            if ((prev ^ kr) <= kSlotCountMask) {
-                atomicAdd(lds_at(tab, boff + (uint32_t)e), 1u);
+            if (prev == kEmpty) {
+                header_update(tab, d, r, 1u);
                 return;
             }
-            continue;  // somebody else took that slot: look at the same bucket again
+            continue;  // the slot went to somebody else (maybe to this very key): look at the bucket again
         }
         if (++b == nb) b = 0;
     }
 }
 
 // motion[l][r], general form, starting one bucket after the hashed one (which was full without the key).
-__device__ __noinline__ uint32_t region_lookup_general(const uint32_t* tab, uint32_t d, uint32_t r)
+__device__ __forceinline__ uint32_t region_lookup_general(const uint32_t* tab, uint32_t d, uint32_t r)
 {
-    const uint32_t nb = d & 0xFFFFu, first = d >> 16;
+    const uint32_t nb = d & 0xFFFFu, first = (d >> 16) + 1u;
     const uint32_t kr = r << kSlotRShift;
-    uint32_t b = __umulhi(r * 0x9E3779B1u, nb);
+    uint32_t b = bucket_of(r, nb);
     for (uint32_t guard = 1; guard < nb; ++guard) {
         if (++b == nb) b = 0;
         const uint4 v = *reinterpret_cast<const uint4*>(tab + ((first + b) << 2));
@@ -144,6 +171,12 @@ __device__ __noinline__ uint32_t region_lookup_general(const uint32_t* tab, uint
         if (bucket_first_empty(v) >= 0) return 0;
     }
     return 0;
+}
+
+// lane ^ 1 exchange on the VALU (DPP quad_perm [1,0,3,2]), no LDS round trip
+__device__ __forceinline__ uint32_t dpp_xor1(uint32_t x)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1, 0xF, 0xF, false);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -197,19 +230,24 @@ filter_kernel(FilterParams p)
 
     const uint32_t T = p.table_slots;              // multiple of 4
     uint32_t* tab = smem;                          // per-left-cell regions of [r | count] slots
-    uint32_t* nfine = tab + T;                     // 40 x 40 half-cell histogram of the left points
-    uint32_t* nleft4 = nfine + kFineN;             // [4][400] mNumberPointsInPerCellLeft per grid type
-    uint32_t* desc4 = nleft4 + 4 * kLeftN;         // [4][400] (first bucket << 16) | buckets
+    uint32_t* nfine = tab + T;                     // [1664] 40 x 40 half-cell histogram of the left points; later reused as
+    uint32_t* fres = nfine;                        //        per half-cell (j* << 8) | rotation bits that pass
+    uint32_t* nleft4 = nfine + kFineStride;        // [4][400] mNumberPointsInPerCellLeft per grid type
+    uint32_t* desc4 = nleft4 + 4 * kLeftN;         // [4][400] (header bucket << 16) | data buckets
     uint32_t* fdesc4 = desc4 + 4 * kLeftN;         // [4][1664] the same, per half-cell: region of the cell it falls in
-    uint32_t* fres = fdesc4 + 4 * kFineStride;     // [1664] per half-cell: (j* << 8) | rotation bits that pass
-    uint32_t* best = fres + kFineStride;           // 400: (max count << 11) | (2047 - lowest right cell)
-    uint32_t* bestmask = best + kLeftN;            // kMcap / 32
+    uint32_t* bestmask = fdesc4 + 4 * kFineStride; // kMcap / 32
     uint32_t* chunk_base = bestmask + (kMcap >> 5);// kMcap / 64 + 1
-    uint32_t* misc = chunk_base + (kMcap >> 6) + 1;// [0..7] rotation counts, [8] error, [9] carry, [16..] scan scratch
+    uint32_t* misc = chunk_base + (kMcap >> 6) + 1;// [0..7] rotation counts, [8] error, [9] carry, [12..15] bucket
+                                                   // allocators, [16..] scan scratch
+    uint32_t* trash = reinterpret_cast<uint32_t*>((reinterpret_cast<uintptr_t>(misc + 48) + 15) & ~uintptr_t(15));
+                                                   // [0..63] add/CAS sink per lane, [64..127] min sink per lane,
+                                                   // [128..131] an always-empty bucket (16-byte aligned)
 
     if (tid < 48) misc[tid] = 0;
+    if (tid < 128) trash[tid] = 0;
+    if (tid >= 128 && tid < 132) trash[tid] = kEmpty;
     for (int i = tid; i < (kMcap >> 5); i += kThreads) bestmask[i] = 0;
-    for (int i = tid; i < kFineN; i += kThreads) nfine[i] = 0;
+    for (int i = tid; i < kFineStride; i += kThreads) nfine[i] = 0;
     for (int i = tid; i < 4 * kFineStride; i += kThreads) fdesc4[i] = 0;
 
     const bool bad_pair = m < 0 || m > kMcap || pr.frame_a < 0 || pr.frame_a >= p.n_frames ||
@@ -225,29 +263,39 @@ filter_kernel(FilterParams p)
     const float2* __restrict__ ptsA = p.pts + offA;
     const float2* __restrict__ ptsB = p.pts + offB;
     const int mm = bad_pair ? 0 : m;
-
     const int n_scales = p.with_scale ? 5 : 1;
     uint32_t best_count = 0;
     int best_scale = -1, best_rot = -1;
     GMS_STAMP_DECL
+    if (mm == 0 || nA <= 0 || nB <= 0) {  // workgroup-uniform: nothing to filter (or nothing valid to index)
+        if (tid == 0) {
+            gms_pair_result r;
+            r.n_inliers = 0;
+            r.best_scale = -1;
+            r.best_rot = -1;
+            r.status = (bad_pair || m > 0) ? GMS_ERR_DOMAIN : GMS_OK;
+            p.results[blockIdx.x] = r;
+        }
+        return;
+    }
     __syncthreads();
-    if (bad_pair && tid == 0) misc[8] = 1;
 
-    // ---- both sides of every match, scale 0: one 8-byte load of (queryIdx, trainIdx), two gathers ---------
+    // ---- both sides of every match, scale 0: one 8-byte load of (queryIdx, trainIdx), two gathers.
+    //      Loads are unconditional on clamped indices (so that all of a thread's loads are in flight
+    //      together); validity is applied to the values afterwards.
     uint32_t code[KPT];
     {
         int2 qt[KPT];
 #pragma unroll
         for (int k = 0; k < KPT; ++k) {
-            const int i = k * kThreads + tid;
-            qt[k] = (i < mm) ? *reinterpret_cast<const int2*>(&matches[i]) : make_int2(-1, -1);
+            const int i = min(k * kThreads + tid, mm - 1);
+            qt[k] = *reinterpret_cast<const int2*>(&matches[i]);
         }
         float2 a[KPT], b[KPT];
-        const float2 nan2 = make_float2(__int_as_float(0x7FC00000), __int_as_float(0x7FC00000));
 #pragma unroll
         for (int k = 0; k < KPT; ++k) {
-            a[k] = ((uint32_t)qt[k].x < (uint32_t)nA) ? ptsA[qt[k].x] : nan2;
-            b[k] = ((uint32_t)qt[k].y < (uint32_t)nB) ? ptsB[qt[k].y] : nan2;
+            a[k] = ptsA[min((uint32_t)qt[k].x, (uint32_t)(nA - 1))];
+            b[k] = ptsB[min((uint32_t)qt[k].y, (uint32_t)(nB - 1))];
         }
         const int wr = p.right_w[0];
         const uint32_t nr = (uint32_t)(wr * p.right_h[0]);
@@ -255,68 +303,71 @@ filter_kernel(FilterParams p)
         bool any_bad = false;
 #pragma unroll
         for (int k = 0; k < KPT; ++k) {
-            const int i = k * kThreads + tid;
-            // parity domain: finite, non-negative, < 2^20 -- one unsigned compare on the bit patterns
-            // (negative, NaN and Inf patterns are all above 0x49800000 = 2^20; -0.0 never reaches here)
+            const bool live = k * kThreads + tid < mm;
+            // parity domain: indices in range; coordinates finite, non-negative, < 2^20 -- one unsigned
+            // compare on the bit patterns (negative, NaN and Inf patterns are all above 0x49800000 = 2^20;
+            // -0.0 was canonicalised away by normalize_kernel)
             const uint32_t worst = max(max(__float_as_uint(a[k].x), __float_as_uint(a[k].y)),
                                        max(__float_as_uint(b[k].x), __float_as_uint(b[k].y)));
             const float fx = 20.0f * a[k].x, fy = 20.0f * a[k].y;   // mulss, rounded to fp32
             // floor == truncation for non-negative values; 2f is exact
             const uint32_t hx = (uint32_t)(int)(fx + fx), hy = (uint32_t)(int)(fy + fy);
             const uint32_t r = (uint32_t)((int)(fwr * b[k].x) + (int)(fhr * b[k].y) * wr);  // no bounds test in the reference
-            const bool ok = worst < 0x49800000u && r < nr;
+            const bool ok = (uint32_t)qt[k].x < (uint32_t)nA && (uint32_t)qt[k].y < (uint32_t)nB &&
+                            worst < 0x49800000u && r < nr;
             // hx >= 40 or hy >= 40: x >= 20 or y >= 20 under every grid type, never binned
-            const uint32_t f = (ok && hx < 40u && hy < 40u) ? hy * kFineW + hx : kFineInvalid;
+            const uint32_t f = (live && ok && hx < 40u && hy < 40u) ? hy * kFineW + hx : kFineInvalid;
             if (f != kFineInvalid) atomicAdd(&nfine[f], 1u);
-            any_bad |= (i < mm) && !ok;
-            code[k] = (ok ? r : 0u) | (f << kFShift);
+            any_bad |= live && !ok;
+            code[k] = ((live && ok) ? r : 0u) | (f << kFShift);
         }
         if (any_bad) misc[8] = 1;  // benign race: every writer stores 1
+    }
+    // Touch the match array of the pair that a workgroup of the next dispatch round will filter (same XCD
+    // under round-robin placement; speed only): one dword per 128-byte line, results unused. Its HBM reads
+    // then overlap this pair's LDS work instead of arriving as one burst in front of it.
+    {
+        const int nxt = blockIdx.x + p.prefetch_stride;
+        if (p.prefetch_stride > 0 && nxt < p.n_pairs) {
+            const gms_pair np = p.pairs[nxt];
+            const volatile char* base = reinterpret_cast<const volatile char*>(p.matches + np.match_off);
+            const int lines = (np.m > 0 && np.m <= kMcap) ? (np.m * 16 + 127) >> 7 : 0;
+            for (int ln = tid; ln < lines; ln += kThreads)
+                (void)*reinterpret_cast<const volatile uint32_t*>(base + (size_t)ln * 128);
+        }
     }
     __syncthreads();  // nfine complete
     GMS_STAMP(0);     // bin (HBM read + gathers + half-cell histogram)
 
-    // ---- per grid type, once per pair: nLeft of every cell, its table region, and the half-cell view of it ---
-    for (int g = 0; g < 4; ++g) {
-        uint32_t my_n = 0, my_nb = 0, incl = 0;
-        const int x = tid % kLeftW, y = tid / kLeftW;
+    // ---- per grid type, once per pair: nLeft of every cell, its table region, and the half-cell view of it.
+    //      Regions may sit in the table in any order, so a cell simply takes the next free buckets from a
+    //      per-grid-type counter (misc[12 + g]); 1600 (grid type, cell) items over the workgroup.
+    for (int item = tid; item < 4 * kLeftN; item += kThreads) {
+        const int g = item / kLeftN, cell = item - g * kLeftN;
+        const int x = cell % kLeftW, y = cell / kLeftW;
         const int hx0 = 2 * x - (g & 1), hy0 = 2 * y - (g >> 1);
-        if (tid < 448) {  // 7 waves cover the 400 cells
-            if (tid < kLeftN) {
+        uint32_t n = 0;
 #pragma unroll
-                for (int dy = 0; dy < 2; ++dy)
+        for (int dy = 0; dy < 2; ++dy)
 #pragma unroll
-                    for (int dx = 0; dx < 2; ++dx) {
-                        const int hx = hx0 + dx, hy = hy0 + dy;
-                        if (hx >= 0 && hy >= 0) my_n += nfine[hy * kFineW + hx];  // hx, hy <= 39 always
-                    }
-                my_nb = region_buckets(my_n);
+            for (int dx = 0; dx < 2; ++dx) {
+                const int hx = hx0 + dx, hy = hy0 + dy;
+                if (hx >= 0 && hy >= 0) n += nfine[hy * kFineW + hx];  // hx, hy <= 39 always
             }
-            incl = my_nb;
+        const uint32_t nb = region_buckets(n, p.region_shift);
+        uint32_t d = 0;
+        if (nb) d = (atomicAdd(&misc[12 + g], nb + 1u) << 16) | nb;  // header bucket + nb data buckets
+        nleft4[item] = n;
+        desc4[item] = d;
 #pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const uint32_t v = __shfl_up(incl, d);
-                if (lane >= d) incl += v;
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) {
+                const int hx = hx0 + dx, hy = hy0 + dy;
+                if (hx >= 0 && hy >= 0) fdesc4[g * kFineStride + hy * kFineW + hx] = d;
             }
-            if (lane == 63) misc[16 + wave] = incl;
-        }
-        __syncthreads();
-        if (tid < kLeftN) {
-            uint32_t base = 0;
-            for (int w = 0; w < wave; ++w) base += misc[16 + w];
-            const uint32_t d = ((base + incl - my_nb) << 16) | my_nb;
-            nleft4[g * kLeftN + tid] = my_n;
-            desc4[g * kLeftN + tid] = d;
-#pragma unroll
-            for (int dy = 0; dy < 2; ++dy)
-#pragma unroll
-                for (int dx = 0; dx < 2; ++dx) {
-                    const int hx = hx0 + dx, hy = hy0 + dy;
-                    if (hx >= 0 && hy >= 0) fdesc4[g * kFineStride + hy * kFineW + hx] = d;
-                }
-        }
-        __syncthreads();
     }
+    __syncthreads();
     GMS_STAMP(1);  // region tables
 
     for (int s = 0; s < n_scales; ++s) {
@@ -328,22 +379,19 @@ filter_kernel(FilterParams p)
             const float fwr = (float)wr, fhr = (float)hr;
             int t[KPT];
 #pragma unroll
-            for (int k = 0; k < KPT; ++k) {
-                const int i = k * kThreads + tid;
-                t[k] = (i < mm) ? matches[i].trainIdx : -1;
-            }
+            for (int k = 0; k < KPT; ++k) t[k] = matches[min(k * kThreads + tid, mm - 1)].trainIdx;
             float2 b[KPT];
 #pragma unroll
-            for (int k = 0; k < KPT; ++k) b[k] = ((uint32_t)t[k] < (uint32_t)nB) ? ptsB[t[k]] : make_float2(0.f, 0.f);
+            for (int k = 0; k < KPT; ++k) b[k] = ptsB[min((uint32_t)t[k], (uint32_t)(nB - 1))];
             bool any_bad = false;
 #pragma unroll
             for (int k = 0; k < KPT; ++k) {
-                const int i = k * kThreads + tid;
+                const uint32_t fpart = code[k] & (kFMask << kFShift);
+                const bool had = fpart != (kFineInvalid << kFShift);  // valid at scale 0 (so indices and points are fine)
                 const uint32_t r = (uint32_t)((int)(fwr * b[k].x) + (int)(fhr * b[k].y) * wr);
                 const bool ok = r < nr;
-                any_bad |= (i < mm) && !ok;
-                code[k] = (code[k] & (kFMask << kFShift)) | (ok ? r : 0u);
-                if (!ok) code[k] = kFineInvalid << kFShift;
+                any_bad |= had && !ok;
+                code[k] = (had && ok) ? (fpart | r) : (kFineInvalid << kFShift);
             }
             if (any_bad) misc[8] = 1;
         }
@@ -353,7 +401,7 @@ filter_kernel(FilterParams p)
             const uint32_t* desc = desc4 + g * kLeftN;
             const uint32_t* fdesc = fdesc4 + g * kFineStride;
 
-            // ---- motion.setTo(0); cellPairs = "no match" ------------------------------------------------------
+            // ---- motion.setTo(0) (this also resets every region header to "no arg-max yet") ------------------
             {
                 const uint4 e4 = make_uint4(kEmpty, kEmpty, kEmpty, kEmpty);
                 uint4* tab4 = reinterpret_cast<uint4*>(tab);
@@ -364,53 +412,76 @@ filter_kernel(FilterParams p)
             // every wave is past the previous grid type's mark (it reads fres): reset it before verify writes
             for (int i = tid; i < kFineStride; i += kThreads) fres[i] = kNoMatch;
 
-            // ---- assignMatchPairs: motion[l][r]++, kChunk matches in flight per thread -----------------------
+            // ---- assignMatchPairs: motion[l][r]++, kChunk matches in flight per thread. Written without
+            //      branches: every lane issues every atomic, and a lane the operation does not apply to is
+            //      pointed at its own trash dword instead (the scalar unit that all four SIMDs share, not the
+            //      LDS, is what divergent exec-mask handling would saturate here).
             {
                 uint32_t pending = 0;
+                uint32_t d[KPT];   // region of the match's left cell under this grid type, 0 = not binned
+#pragma unroll
+                for (int k = 0; k < KPT; ++k) d[k] = fdesc[(code[k] >> kFShift) & kFMask];
+                const uint32_t trash_add = (uint32_t)((trash - tab) + lane) << 2;        // never equals kEmpty
+                const uint32_t trash_min = (uint32_t)((trash - tab) + 64 + lane) << 2;
+                const uint32_t trash_bkt = (uint32_t)((trash - tab) + 128) << 2;          // one all-empty bucket
 #pragma unroll
                 for (int k0 = 0; k0 < KPT; k0 += kChunk) {
-                    uint32_t d[kChunk];   // region of the match's left cell under this grid type, 0 = not binned
-#pragma unroll
-                    for (int c = 0; c < kChunk; ++c) d[c] = fdesc[(code[k0 + c] >> kFShift) & kFMask];
-                    uint32_t boff[kChunk];  // byte offset of the hashed bucket
+                    uint32_t slot[kChunk];  // byte offset of the hashed bucket, then of the match's slot
                     uint4 v[kChunk];
 #pragma unroll
                     for (int c = 0; c < kChunk; ++c) {
-                        const uint32_t nb = d[c] & 0xFFFFu;
-                        boff[c] = ((d[c] >> 16) + __umulhi((code[k0 + c] & kRMask) * 0x9E3779B1u, nb)) << 4;
-                        v[c] = make_uint4(0, 0, 0, 0);
-                        if (nb) v[c] = *reinterpret_cast<const uint4*>(lds_at(tab, boff[c]));
+                        const uint32_t nb = d[k0 + c] & 0xFFFFu;
+                        const uint32_t bo = ((d[k0 + c] >> 16) + 1u + bucket_of(code[k0 + c] & kRMask, nb)) << 4;
+                        slot[c] = nb ? bo : trash_bkt;
+                        v[c] = *reinterpret_cast<const uint4*>(lds_at(tab, slot[c]));
                     }
+                    // round 1: "+1" where the bucket already holds the right cell, CAS into its first empty slot
+                    // where it does not
+                    uint32_t o_add[kChunk], o_cas[kChunk];
+                    uint32_t found = 0, canput = 0;
 #pragma unroll
                     for (int c = 0; c < kChunk; ++c) {
-#ifdef GMS_DBG_NO_FAST
-                        if (d[c] & 0xFFFFu) pending |= 1u << (k0 + c);
-                        if (false) {
-#else
-                        if (d[c] & 0xFFFFu) {
-#endif
-                            const uint32_t kr = (code[k0 + c] & kRMask) << kSlotRShift;
-                            const int f = bucket_find(v[c], kr);
-                            if (f >= 0) {
-                                atomicAdd(lds_at(tab, boff[c] + (uint32_t)f), 1u);
-                            } else {
-                                bool done = false;
-                                const int e = bucket_first_empty(v[c]);
-                                if (e >= 0) {
-                                    const uint32_t prev = atomicCAS(lds_at(tab, boff[c] + (uint32_t)e), kEmpty, kr | 1u);
-                                    done = prev == kEmpty;
-                                    if (!done && (prev ^ kr) <= kSlotCountMask) {
-                                        atomicAdd(lds_at(tab, boff[c] + (uint32_t)e), 1u);
-                                        done = true;
-                                    }
-                                }
-                                if (!done) pending |= 1u << (k0 + c);
-                            }
-                        }
+                        const bool valid = (d[k0 + c] & 0xFFFFu) != 0;
+                        const uint32_t kr = (code[k0 + c] & kRMask) << kSlotRShift;
+                        const int f = bucket_find(v[c], kr);
+                        const int e = bucket_pref_empty(v[c], (__umul24(code[k0 + c] & kRMask, 2531u) >> 12) & 3u);
+                        const bool fnd = valid && f >= 0;
+                        const bool put = valid && f < 0 && e >= 0;
+                        if (valid && f < 0 && e < 0) pending |= 1u << (k0 + c);  // full bucket: leftovers
+                        slot[c] += (uint32_t)(f >= 0 ? f : (e & 12));
+                        found |= (fnd ? 1u : 0u) << c;
+                        canput |= (put ? 1u : 0u) << c;
+                        o_add[c] = atomicAdd(lds_at(tab, fnd ? slot[c] : trash_add), 1u);
+                        o_cas[c] = atomicCAS(lds_at(tab, put ? slot[c] : trash_add), kEmpty, kr | 1u);
+                    }
+                    // round 2: a lost CAS whose winner was the same right cell (common: the true matches of a
+                    // cell arrive together) becomes "+1" on that slot; any other winner sends us to the leftovers
+                    uint32_t o_again[kChunk];
+                    uint32_t won = 0, same = 0;
+#pragma unroll
+                    for (int c = 0; c < kChunk; ++c) {
+                        const uint32_t kr = (code[k0 + c] & kRMask) << kSlotRShift;
+                        const bool put = (canput >> c) & 1u;
+                        const bool w = put && o_cas[c] == kEmpty;
+                        const bool sm = put && !w && (o_cas[c] ^ kr) <= kSlotCountMask;
+                        if (put && !w && !sm) pending |= 1u << (k0 + c);
+                        won |= (w ? 1u : 0u) << c;
+                        same |= (sm ? 1u : 0u) << c;
+                        o_again[c] = atomicAdd(lds_at(tab, sm ? slot[c] : trash_add), 1u);
+                    }
+                    // the count this match produced, folded into the cell's running arg-max
+#pragma unroll
+                    for (int c = 0; c < kChunk; ++c) {
+                        const bool fnd = (found >> c) & 1u, w = (won >> c) & 1u, sm = (same >> c) & 1u;
+                        const uint32_t count = fnd ? (o_add[c] & kSlotCountMask) + 1u
+                                                   : (w ? 1u : (o_again[c] & kSlotCountMask) + 1u);
+                        const uint32_t key = ~((count << 11) | (2047u - (code[k0 + c] & kRMask)));
+                        const uint32_t hdr = (d[k0 + c] >> 16) << 4;
+                        atomicMin(lds_at(tab, (fnd || w || sm) ? hdr : trash_min), key);
                     }
                 }
                 GMS_STAMP(3);  // insert: first-probe rounds
-                // leftovers (full bucket, or lost the race for its empty slot to another right cell)
+                // leftovers, one at a time through the general walk
                 while (pending) {
                     const int k1 = __ffs(pending) - 1;
                     pending &= pending - 1u;
@@ -424,110 +495,104 @@ filter_kernel(FilterParams p)
             __syncthreads();
             GMS_STAMP(11);  // insert: wait for the other waves
 
-            // ---- arg-max over each left cell's row: max count, lowest right cell on ties ---------------------
-            if (tid < kLeftN) {
-                const uint32_t dd = desc[tid];
-                const uint32_t nb = dd & 0xFFFFu;
-                const uint4* reg4 = reinterpret_cast<const uint4*>(tab) + (dd >> 16);
-                uint32_t bp = 0;
-#pragma unroll 2
-                for (uint32_t i = 0; i < nb; ++i) {
-                    const uint4 q = reg4[i];
-                    // an empty slot is 0xFFFFFFFF: give it key 0 so that it never wins (real counts are >= 1)
-                    const uint32_t k0 = (q.x == kEmpty) ? 0u : ((q.x & kSlotCountMask) << 11) | (2047u - (q.x >> kSlotRShift));
-                    const uint32_t k1 = (q.y == kEmpty) ? 0u : ((q.y & kSlotCountMask) << 11) | (2047u - (q.y >> kSlotRShift));
-                    const uint32_t k2 = (q.z == kEmpty) ? 0u : ((q.z & kSlotCountMask) << 11) | (2047u - (q.z >> kSlotRShift));
-                    const uint32_t k3 = (q.w == kEmpty) ? 0u : ((q.w & kSlotCountMask) << 11) | (2047u - (q.w >> kSlotRShift));
-                    bp = max(max(bp, k0), max(max(k1, k2), k3));
-                }
-                best[tid] = bp;
-            }
-            __syncthreads();
-            GMS_STAMP(4);  // arg-max
-
-            // ---- verifyCellPairs: one lane per (left cell, rotation), 4 neighbour look-ups in flight ----------
-            for (int item = tid; item < kLeftN * kNRot; item += kThreads) {
-                const int i = ROT ? (item >> 3) : item;
-                const int rot = ROT ? (item & 7) : 0;
-                const uint32_t ni = nleft[i];
-                uint32_t pass = 0;
-                const uint32_t bi = best[i];
-                const int j = 2047 - (int)(bi & kRMask);
-                if (ni != 0) {
+            // ---- verifyCellPairs. Without rotation: two lanes per left cell, four neighbour look-ups each, joined
+            //      by one DPP exchange. With rotation: one lane per (cell, rotation), eight look-ups in two rounds.
+            {
+                constexpr int kItems = ROT ? kLeftN * 8 : kLeftN * 2;
+                for (int item = tid; item < ((kItems + 63) & ~63); item += kThreads) {
+                    const bool live = item < kItems;
+                    const int i = live ? (ROT ? (item >> 3) : (item >> 1)) : 0;
+                    const int rot = ROT ? (item & 7) : 0;
+                    const int half = item & 1;  // !ROT only
+                    const uint32_t ni = live ? nleft[i] : 0u;
+                    const uint32_t di = desc[i];
+                    const uint32_t bi = ni ? ~tab[(di >> 16) << 2] : 0u;  // (max count << 11) | (2047 - j*)
+                    const int j = 2047 - (int)(bi & kRMask);
                     const int jx = j % wr, jy = j / wr;
                     const int ix = i % kLeftW, iy = i / kLeftW;
                     // centre pair (k = 4): ll = i, rr = j*, whose count is the arg-max count
-                    uint32_t score = bi >> 11, tsum = ni, numpair = 1;
+                    uint32_t score = 0, tn = 0;  // tn = (sum of nLeft << 4) | numpair
 #pragma unroll
-                    for (int h = 0; h < 8; h += 4) {
+                    for (int h = 0; h < (ROT ? 8 : 4); h += 4) {
                         uint32_t dn[4], rq[4];
 #pragma unroll
                         for (int c = 0; c < 4; ++c) {
-                            const int k8 = h + c;
-                            const int k = k8 < 4 ? k8 : k8 + 1;
+                            int k;
+                            if (ROT) {
+                                const int k8 = h + c;
+                                k = k8 < 4 ? k8 : k8 + 1;
+                            } else {
+                                k = half ? c + 5 : c;  // lane 0: neighbours 0..3, lane 1: neighbours 5..8
+                            }
                             const int q = ROT ? c_rot[rot][k] : k;
-                            const int lx = ix + (k % 3) - 1, ly = iy + (k / 3) - 1;
-                            const int rx = jx + (q % 3) - 1, ry = jy + (q / 3) - 1;
-                            const bool okp = (uint32_t)lx < (uint32_t)kLeftW && (uint32_t)ly < (uint32_t)kLeftH &&  // ll != -1
+                            int ldx, ldy, rdx, rdy;
+                            if (ROT) {
+                                ldx = (k % 3) - 1; ldy = (k / 3) - 1;  // compile-time
+                                rdx = (q % 3) - 1; rdy = (q / 3) - 1;
+                            } else {
+                                // k = c or c + 5, both compile-time: select by lane parity
+                                ldx = half ? ((c + 5) % 3) - 1 : (c % 3) - 1;
+                                ldy = half ? ((c + 5) / 3) - 1 : (c / 3) - 1;
+                                rdx = ldx; rdy = ldy;
+                            }
+                            const int lx = ix + ldx, ly = iy + ldy;
+                            const int rx = jx + rdx, ry = jy + rdy;
+                            const bool okp = ni != 0 &&
+                                             (uint32_t)lx < (uint32_t)kLeftW && (uint32_t)ly < (uint32_t)kLeftH &&  // ll != -1
                                              (uint32_t)rx < (uint32_t)wr && (uint32_t)ry < (uint32_t)hr;            // rr != -1
                             const int ll = okp ? lx + ly * kLeftW : 0;
                             rq[c] = okp ? (uint32_t)(rx + ry * wr) : 0u;  // 0: matches no slot of the all-empty stand-in
-                            tsum += okp ? nleft[ll] : 0u;
+                            tn += okp ? ((nleft[ll] << 4) | 1u) : 0u;
                             dn[c] = okp ? desc[ll] : 0u;
-                            numpair += okp ? 1u : 0u;
                         }
                         uint4 v[4];
 #pragma unroll
                         for (int c = 0; c < 4; ++c) {
                             const uint32_t nb = dn[c] & 0xFFFFu;
                             v[c] = make_uint4(kEmpty, kEmpty, kEmpty, kEmpty);
-                            if (nb) v[c] = *reinterpret_cast<const uint4*>(tab + (((dn[c] >> 16) + __umulhi(rq[c] * 0x9E3779B1u, nb)) << 2));
+                            if (nb) v[c] = *reinterpret_cast<const uint4*>(tab + (((dn[c] >> 16) + 1u + bucket_of(rq[c], nb)) << 2));
                         }
 #pragma unroll
                         for (int c = 0; c < 4; ++c) {
                             const uint32_t kr = rq[c] << kSlotRShift;
-#ifdef GMS_DBG_SLOW_LOOKUP
-                            if (dn[c] & 0xFFFFu) {
-                                uint32_t cnt2 = 0;
-                                const uint32_t nb2 = dn[c] & 0xFFFFu, first2 = dn[c] >> 16;
-                                for (uint32_t bb = 0; bb < nb2; ++bb)
-                                    for (int e2 = 0; e2 < 4; ++e2) {
-                                        const uint32_t sv = tab[((first2 + bb) << 2) + e2];
-                                        if (sv != kEmpty && (sv >> kSlotRShift) == rq[c]) cnt2 += sv & kSlotCountMask;
-                                    }
-                                score += cnt2;
-                            } else if (false) {
-#else
                             if (bucket_find(v[c], kr) >= 0) {
                                 score += bucket_count(v[c], kr);
                             } else if (bucket_first_empty(v[c]) < 0) {  // full bucket without the key: walk on
-#endif
                                 score += region_lookup_general(tab, dn[c], rq[c]);
                             }
                         }
                     }
-                    // divsd, sqrtsd, mulsd, comisd: reject iff thresh > score
-                    const double thresh = sqrt((double)tsum / (double)numpair) * p.threshold_factor;
-                    pass = (thresh > (double)score) ? 0u : 1u;
-                }
-                uint32_t bits = pass;
-                bool writer = ni != 0;
-                if (ROT) {
-                    const unsigned long long bal = __ballot(pass);
-                    bits = (uint32_t)(bal >> (lane & 56)) & 0xFFu;
-                    writer = writer && (lane & 7) == 0;
-                }
-                if (writer) {
-                    // cellPairs[i] as every half-cell of cell i sees it
-                    const uint32_t cr = ((uint32_t)j << 8) | bits;
-                    const int hx0 = 2 * (i % kLeftW) - (g & 1), hy0 = 2 * (i / kLeftW) - (g >> 1);
+                    if (!ROT) {
+                        score += dpp_xor1(score);
+                        tn += dpp_xor1(tn);
+                    }
+                    score += bi >> 11;
+                    tn += (ni << 4) | 1u;
+                    uint32_t pass = 0;
+                    if (ni != 0 && (ROT || half == 0)) {
+                        // divsd, sqrtsd, mulsd, comisd: reject iff thresh > score
+                        const double thresh = sqrt((double)(tn >> 4) / (double)(tn & 15u)) * p.threshold_factor;
+                        pass = (thresh > (double)score) ? 0u : 1u;
+                    }
+                    uint32_t bits = pass;
+                    bool writer = ni != 0 && half == 0;
+                    if (ROT) {
+                        const unsigned long long bal = __ballot(pass);
+                        bits = (uint32_t)(bal >> (lane & 56)) & 0xFFu;
+                        writer = ni != 0 && (lane & 7) == 0;
+                    }
+                    if (writer) {
+                        // cellPairs[i] as every half-cell of cell i sees it
+                        const uint32_t cr = ((uint32_t)j << 8) | bits;
+                        const int hx0 = 2 * ix - (g & 1), hy0 = 2 * iy - (g >> 1);
 #pragma unroll
-                    for (int dy = 0; dy < 2; ++dy)
+                        for (int dy = 0; dy < 2; ++dy)
 #pragma unroll
-                        for (int dx = 0; dx < 2; ++dx) {
-                            const int hx = hx0 + dx, hy = hy0 + dy;
-                            if (hx >= 0 && hy >= 0) fres[hy * kFineW + hx] = cr;
-                        }
+                            for (int dx = 0; dx < 2; ++dx) {
+                                const int hx = hx0 + dx, hy = hy0 + dy;
+                                if (hx >= 0 && hy >= 0) fres[hy * kFineW + hx] = cr;
+                            }
+                    }
                 }
             }
             __syncthreads();
@@ -625,22 +690,31 @@ filter_kernel(FilterParams p)
     gms_dmatch* __restrict__ out = p.out + pr.match_off;
     uint8_t* mask_out = p.mask ? p.mask + pr.match_off : nullptr;
 #pragma unroll
-    for (int k = 0; k < KPT; ++k) {
-        const int i = k * kThreads + tid;
-        const int c = i >> 6;
-        if (i - lane < mm) {  // wave-uniform
-            const unsigned long long bits =
-                failed ? 0ull : ((unsigned long long)bestmask[2 * c] | ((unsigned long long)bestmask[2 * c + 1] << 32));
-            const bool in = (bits >> lane) & 1ull;
+    for (int k0 = 0; k0 < KPT; k0 += kChunk) {
+        uint32_t pos[kChunk];
+        uint4 v[kChunk];
+        uint32_t inm = 0;
+#pragma unroll
+        for (int c = 0; c < kChunk; ++c) {
+            const int i = (k0 + c) * kThreads + tid;
+            const int ch = i >> 6;
+            pos[c] = 0;
+            v[c] = make_uint4(0, 0, 0, 0);
             if (i < mm) {
+                const unsigned long long bits =
+                    failed ? 0ull : ((unsigned long long)bestmask[2 * ch] | ((unsigned long long)bestmask[2 * ch + 1] << 32));
+                const bool in = (bits >> lane) & 1ull;
                 if (mask_out) mask_out[i] = in ? 1 : 0;
                 if (in) {
-                    const uint32_t pos = chunk_base[c] + (uint32_t)__popcll(bits & ((1ull << lane) - 1ull));
-                    const uint4 v = *reinterpret_cast<const uint4*>(&matches[i]);
-                    *reinterpret_cast<uint4*>(&out[pos]) = v;
+                    inm |= 1u << c;
+                    pos[c] = chunk_base[ch] + (uint32_t)__popcll(bits & ((1ull << lane) - 1ull));
+                    v[c] = *reinterpret_cast<const uint4*>(&matches[i]);
                 }
             }
         }
+#pragma unroll
+        for (int c = 0; c < kChunk; ++c)
+            if ((inm >> c) & 1u) *reinterpret_cast<uint4*>(&out[pos[c]]) = v[c];
     }
     GMS_STAMP(9);  // copy-out
     GMS_STAMP_FLUSH;
@@ -671,20 +745,22 @@ __global__ void threshold_kernel(const int32_t* T, const int32_t* n, const int32
 size_t filter_lds_bytes(int kpt, uint32_t table_slots)
 {
     const size_t mcap = (size_t)kpt * kThreads;
-    size_t dwords = table_slots + kFineN + 9 * kLeftN + 5 * 1664 + (mcap >> 5) + (mcap >> 6) + 1 + 64;
+    size_t dwords = table_slots + 5 * 1664 + 8 * kLeftN + (mcap >> 5) + (mcap >> 6) + 1 + 48 + 4 + 132 + 12;
     return dwords * 4;
 }
 
+int filter_region_shift(int kpt) { return kpt <= 10 ? 0 : 2; }  // ~2 slots per match while the LDS allows it
+
 uint32_t filter_table_slots(int kpt)
 {
-    // sum over cells of 4 * region_buckets(n) <= 1.5 * M + 3 * 400
+    // sum over cells of 4 * (region_buckets(n) + 1 header) <= M + (M >> sh) + 3 * 400 + 4 * 400
     const uint32_t mcap = (uint32_t)kpt * kThreads;
-    return (mcap + (mcap >> 1) + 3 * kLeftN + 3u) & ~3u;
+    return (mcap + (mcap >> filter_region_shift(kpt)) + 7 * kLeftN + 3u) & ~3u;
 }
 
 int filter_pick_kpt(int max_m)
 {
-    static const int kKpt[] = {4, 10, 16, 24};
+    static const int kKpt[] = {4, 10, 16};
     for (int k : kKpt)
         if (max_m <= k * kThreads && filter_lds_bytes(k, filter_table_slots(k)) <= kLdsBytes) return k;
     return 0;
@@ -724,7 +800,6 @@ hipError_t launch_filter(const FilterParams& p, int kpt, int n_pairs, hipStream_
     case 4: return rot ? launch_filter_t<4, true>(p, n_pairs, lds, stream) : launch_filter_t<4, false>(p, n_pairs, lds, stream);
     case 10: return rot ? launch_filter_t<10, true>(p, n_pairs, lds, stream) : launch_filter_t<10, false>(p, n_pairs, lds, stream);
     case 16: return rot ? launch_filter_t<16, true>(p, n_pairs, lds, stream) : launch_filter_t<16, false>(p, n_pairs, lds, stream);
-    case 24: return rot ? launch_filter_t<24, true>(p, n_pairs, lds, stream) : launch_filter_t<24, false>(p, n_pairs, lds, stream);
     default: return hipErrorInvalidValue;
     }
 }

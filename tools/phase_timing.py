@@ -16,7 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 
-PHASES = ["bin", "region_tables", "clear", "insert_first", "argmax", "verify", "mark", "count_select", "out_scan", "copy_out", "insert_leftover", "insert_barrier"]
+PHASES = ["bin", "region_tables", "clear", "insert_first", "n_leftover_items", "verify", "mark", "count_select", "out_scan", "copy_out", "insert_leftover", "insert_barrier"]
 
 
 def main():
