@@ -27,6 +27,13 @@ def load_library():
     if not os.path.exists(path):
         raise ImportError(f"{path} not found: the HIP extension is not built "
                           f"(run `python -c 'import __graft_entry__ as g; g.build()'`)")
+    # torch (used by batch.py for device memory and streams) ships its own copy of the HIP runtime; it
+    # must be the first one loaded in a process that uses both, or torch finds "no HIP GPUs". Nothing of
+    # torch is called here.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(path)
     vp, i32, i64, dbl = C.c_void_p, C.c_int, C.c_int64, C.c_double
     lib.gms_match.argtypes = [vp, i32, i32, i32, vp, i32, i32, i32, vp, i32, i32, i32, dbl, vp, C.POINTER(i32)]

@@ -1,0 +1,99 @@
+"""CPU: pins for the oracle's pieces. The reference holds no tests or golden vectors for this path
+(parity unpinned); what CAN be pinned is pinned here: the constant tables byte for byte
+against the reference's DLL (when /root/reference is present), and the arithmetic of each piece against
+hand-derived known answers taken from the DLL's disassembly."""
+import math
+import os
+import struct
+
+import numpy as np
+import pytest
+
+DLL = "/root/reference/SfM-GMS/bin/opencv_xfeatures2d452.dll"
+
+
+@pytest.mark.skipif(not os.path.exists(DLL), reason="reference DLL not present on this box")
+def test_tables_match_reference_dll(oracle):
+    import ctypes as C
+    lib = oracle.load()
+    data = open(DLL, "rb").read()
+    # mRotationPatterns: .rdata VA 0x18012f520 -> file offset 0x12df20, 8 x 9 int32
+    rot = struct.unpack("<72i", data[0x12DF20:0x12DF20 + 288])
+    mine = (C.c_int * 72).in_dll(lib, "gms_ref_rotation_patterns")
+    assert tuple(mine) == rot
+    # mScaleRatios: .data VA 0x1802c5008 -> file offset 0x2c2c08; slots 2, 3 are filled by the static
+    # initialiser (1/sqrt2, sqrt2), the others are literal
+    sc = struct.unpack("<5d", data[0x2C2C08:0x2C2C08 + 40])
+    assert sc[0] == 1.0 and sc[1] == 0.5 and sc[4] == 2.0 and sc[2] == 0.0 and sc[3] == 0.0
+    assert [lib.gms_ref_scale_ratio(i) for i in range(5)] == [1.0, 0.5, 1.0 / math.sqrt(2.0), math.sqrt(2.0), 2.0]
+    # the 0.5 added before the fp64 floor of the shifted grids: VA 0x18012dfc0 -> file offset 0x12c9c0
+    assert struct.unpack("<d", data[0x12C9C0:0x12C9C8])[0] == 0.5
+
+
+def test_rotation_patterns_are_rotations_of_the_ring(oracle):
+    import ctypes as C
+    pat = np.array((C.c_int * 72).in_dll(oracle.load(), "gms_ref_rotation_patterns")).reshape(8, 9)
+    ring = [0, 1, 2, 5, 8, 7, 6, 3]  # the 8 neighbours clockwise, as positions in the 3x3 block
+    for rot in range(8):
+        assert pat[rot][4] == 5  # centre stays
+        assert sorted(pat[rot]) == list(range(1, 10))
+        # pattern rot is the identity ring rotated by rot steps
+        assert [pat[rot][ring[(k + rot) % 8]] for k in range(8)] == [pat[0][ring[k]] for k in range(8)]
+
+
+def test_right_grids(oracle):
+    import ctypes as C
+    lib = oracle.load()
+    got = []
+    for s in range(5):
+        w, h = C.c_int(), C.c_int()
+        lib.gms_ref_right_grid(s, C.byref(w), C.byref(h))
+        got.append((w.value, h.value))
+    assert got == [(20, 20), (10, 10), (14, 14), (28, 28), (40, 40)]  # cvRound(20 * ratio), DLL@0x180048c10
+
+
+def test_grid_index_left_known_answers(oracle):
+    lib = oracle.load()
+    L = lib.gms_ref_grid_index_left
+    # (nx, ny) -> cell for types 1..4; 20*0.26 = 5.2, 20*0.53 = 10.6
+    assert [L(0.26, 0.53, t) for t in (1, 2, 3, 4)] == [5 + 10 * 20, 5 + 10 * 20, 5 + 11 * 20, 5 + 11 * 20]
+    # 20*0.275 = 5.5: the shifted x jumps to 6
+    assert [L(0.275, 0.1, t) for t in (1, 2, 3, 4)] == [5 + 40, 6 + 40, 5 + 40, 6 + 40]
+    # last half cell: 20*0.98 = 19.6 -> shifted x = 20 -> -1 (one common bounds test)
+    assert [L(0.98, 0.5, t) for t in (1, 2, 3, 4)] == [19 + 200, -1, 19 + 200, -1]
+    assert [L(0.5, 0.99, t) for t in (1, 2, 3, 4)] == [10 + 380, 10 + 380, -1, -1]
+    # exact borders
+    assert L(0.0, 0.0, 1) == 0 and L(0.0, 0.0, 4) == 0
+    assert L(0.05, 0.05, 1) == 1 + 20  # 20 * fl32(0.05) = 1.0000000149 in fp32 -> rounds to 1.0
+    # the product is rounded to fp32 BEFORE the widening + 0.5: nx just below 0.475 whose fp32 product is 9.5
+    nx = np.nextafter(np.float32(0.475), np.float32(0))
+    prod = np.float32(20) * nx
+    want = int(math.floor(float(prod) + 0.5))
+    assert L(float(nx), 0.0, 2) == want
+
+
+def test_grid_index_right_has_no_bounds_test(oracle):
+    R = oracle.load().gms_ref_grid_index_right
+    assert R(0.26, 0.53, 20, 20) == 5 + 10 * 20
+    assert R(0.26, 0.53, 14, 14) == 3 + 7 * 14
+    assert R(0.999, 0.999, 40, 40) == 39 + 39 * 40
+    assert R(1.0, 0.0, 20, 20) == 20  # x == W spills into the next row in the reference: no test there
+
+
+def test_normalize_is_fp32_divide(oracle):
+    N = oracle.load().gms_ref_normalize
+    for v, e in [(1919.5, 1920), (0.1, 3), (1079.99, 1080), (123.456, 777)]:
+        assert N(v, e) == float(np.float32(v) / np.float32(e))
+
+
+def test_threshold_is_strict_greater_in_fp64(oracle):
+    T = oracle.load().gms_ref_threshold_rejects
+    assert T(36, 9, 12, 6.0) == 0  # 6 * sqrt(4) == 12: kept
+    assert T(36, 9, 11, 6.0) == 1
+    assert T(9, 9, 6, 6.0) == 0 and T(9, 9, 5, 6.0) == 1
+    assert T(2, 9, 2, 6.0) == 1  # 6 * sqrt(2/9) = 2.83
+    assert T(1, 4, 3, 6.0) == 0  # 6 * 0.5 == 3
+    rng = np.random.default_rng(9)
+    for _ in range(2000):
+        t, n, s = int(rng.integers(0, 5000)), int(rng.integers(1, 10)), int(rng.integers(0, 200))
+        assert T(t, n, s, 6.0) == int(math.sqrt(t / n) * 6.0 > s)
