@@ -1,0 +1,68 @@
+"""The header-only C++ shim (sfm-gms_amd/include/mi355_gms.hpp) with the reference's matchGMS signature.
+CPU: it compiles and links against libgms_hip.so and fails loudly without a device. GPU: same data
+through the oracle, same survivors."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "sfm-gms_amd", "csrc")
+
+
+def _build(tmp_path):
+    exe = str(tmp_path / "shim_main")
+    cmd = ["g++", "-std=c++17", "-O1", "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "sfm-gms_amd", "include"),
+           os.path.join(ROOT, "tests", "cpp", "shim_main.cpp"), "-L", CSRC, "-lgms_hip", "-Wl,-rpath," + CSRC,
+           "-Wl,-rpath,/opt/rocm/lib", "-o", exe]
+    subprocess.check_call(cmd)
+    return exe
+
+
+def _lcg_data():
+    s = np.uint64(12345)
+    def lcg():
+        nonlocal s
+        s = (s * np.uint64(1664525) + np.uint64(1013904223)) & np.uint64(0xFFFFFFFF)
+        return int(s) >> 8
+    w, h, n = 1280, 720, 4000
+    xy1 = np.zeros((n, 2), dtype=np.float32)
+    xy2 = np.zeros((n, 2), dtype=np.float32)
+    q, t, img = (np.zeros(n, dtype=np.int32) for _ in range(3))
+    dist = np.zeros(n, dtype=np.float32)
+    for i in range(n):
+        xy1[i, 0] = np.float32(lcg() % ((w - 1) * 16)) / np.float32(16.0)
+        xy1[i, 1] = np.float32(lcg() % ((h - 1) * 16)) / np.float32(16.0)
+        xy2[i, 0] = xy1[i, 0] * np.float32(0.98) + np.float32(7.25)
+        xy2[i, 1] = xy1[i, 1] * np.float32(0.98) + np.float32(3.5)
+        q[i] = i
+        t[i] = i if (lcg() % 100 < 55) else lcg() % n
+        img[i] = i % 3
+        dist[i] = np.float32(lcg() % 1024) / np.float32(4.0)
+    return (w, h), xy1, xy2, q, t, img, dist
+
+
+@pytest.mark.skipif(os.path.exists("/dev/kfd"), reason="this box has a GPU")
+def test_shim_compiles_links_and_fails_loudly_without_gpu(tmp_path):
+    exe = _build(tmp_path)
+    res = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert res.returncode == 3 and "no usable HIP device" in res.stderr
+
+
+@pytest.mark.gpu
+def test_shim_matches_oracle(tmp_path, oracle, pkg, synth):
+    exe = _build(tmp_path)
+    res = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr
+    lines = res.stdout.split()
+    size, xy1, xy2, q, t, img, dist = _lcg_data()
+    m = np.zeros(len(q), dtype=pkg.DMATCH_DTYPE)
+    m["queryIdx"], m["trainIdx"], m["imgIdx"], m["distance"] = q, t, img, dist
+    for k, flags in enumerate(((False, False), (True, True))):
+        rc, want, _, _ = oracle.match(size, size, synth.make_keypoints(xy1), synth.make_keypoints(xy2), m, *flags, 6.0)
+        assert rc == 0 and len(want) > 500
+        s = 1469598103934665603
+        for v in want.view(np.uint32).reshape(-1):
+            s = ((s ^ int(v)) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+        assert (int(lines[2 * k]), int(lines[2 * k + 1])) == (len(want), s)
