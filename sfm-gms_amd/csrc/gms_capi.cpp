@@ -5,6 +5,7 @@
 // filter in this library: without a working HIP device every compute entry point returns an error.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -76,7 +77,7 @@ struct gms_ctx {
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     std::mutex mu;  // serialises the one-shot path's scratch buffers
-    DevBuf kp, foff, wh, pts, pair, matches, out, result, aux;
+    DevBuf kp, foff, wh, pts, pair, matches, out, result, aux, big_ws;
 };
 
 extern "C" {
@@ -98,15 +99,7 @@ const char* gms_error_string(int code)
     }
 }
 
-int gms_max_matches(void)
-{
-    int lo = 0, hi = 1 << 20;
-    while (lo < hi) {
-        int mid = (lo + hi + 1) / 2;
-        if (gms::filter_pick_kpt(mid)) lo = mid; else hi = mid - 1;
-    }
-    return lo;
-}
+int gms_max_matches(void) { return gms::kBigMaxMatches; }
 
 int gms_ctx_create(int device, gms_ctx** out_ctx)
 {
@@ -139,7 +132,7 @@ int gms_ctx_destroy(gms_ctx* c)
     if (!c) return GMS_OK;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    DevBuf* bufs[] = {&c->kp, &c->foff, &c->wh, &c->pts, &c->pair, &c->matches, &c->out, &c->result, &c->aux};
+    DevBuf* bufs[] = {&c->kp, &c->foff, &c->wh, &c->pts, &c->pair, &c->matches, &c->out, &c->result, &c->aux, &c->big_ws};
     for (DevBuf* b : bufs) b->release();
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
@@ -182,10 +175,11 @@ int gms_filter_device(gms_ctx* c, const float* d_pts, const int64_t* d_frame_off
     if (!d_frame_off || !d_pairs || !d_results) return GMS_ERR_BAD_ARG;
     if (max_m > 0 && (!d_matches || !d_out || !d_pts)) return GMS_ERR_BAD_ARG;
     gms::FilterParams p;
-    const int kpt = gms::filter_pick_kpt(max_m);
-    if (!kpt) return GMS_ERR_CAPACITY;
-    p.table_slots = gms::filter_table_slots(kpt);
-    p.region_shift = gms::filter_region_shift(kpt);
+    const int kpt = gms::filter_pick_kpt(max_m);  // 0: too large for the register + LDS kernel
+    if (!kpt && max_m > gms::kBigMaxMatches) return GMS_ERR_CAPACITY;
+    p.table_slots = kpt ? gms::filter_table_slots(kpt) : 0;
+    p.region_shift = kpt ? gms::filter_region_shift(kpt) : 0;
+    if (const char* e = std::getenv("GMS_REGION_SHIFT")) p.region_shift = std::max(p.region_shift, std::atoi(e));  // tuning knob
     p.pts = reinterpret_cast<const float2*>(d_pts);
     p.frame_off = d_frame_off;
     p.n_frames = n_frames;
@@ -198,6 +192,13 @@ int gms_filter_device(gms_ctx* c, const float* d_pts, const int64_t* d_frame_off
         return e ? std::atoi(e) : 0;
     }();
     p.prefetch_stride = prefetch_stride;
+    // GMS_STAGGER_US: spread of the first dispatch round's start times (0 turns it off)
+    static const int stagger_us = [] {
+        const char* e = std::getenv("GMS_STAGGER_US");
+        return e ? std::atoi(e) : 72;
+    }();
+    p.stagger_blocks = 256;
+    p.stagger_cycles = (n_pairs >= 4 * p.stagger_blocks) ? stagger_us * 2400 : 0;
     p.matches = d_matches;
     p.out = d_out;
     p.results = d_results;
@@ -210,7 +211,21 @@ int gms_filter_device(gms_ctx* c, const float* d_pts, const int64_t* d_frame_off
     p.diag = g_diag;
 #endif
     GMS_HIP(hipSetDevice(c->device));
-    GMS_HIP(gms::launch_filter(p, kpt, n_pairs, c->stream));
+    if (kpt) {
+        GMS_HIP(gms::launch_filter(p, kpt, n_pairs, c->stream));
+    } else {
+        // Large pairs: a fixed crew of persistent workgroups, each with an HBM slab for the pair's code words
+        // and table. The slab is (re)allocated here when it has to grow -- this branch is not stream-capturable.
+        const int mcap = gms::big_mcap(max_m);
+        const int n_wg = n_pairs < 64 ? n_pairs : 64;
+        const size_t need = (size_t)n_wg * gms::big_ws_stride_dwords(mcap) * 4;
+        if (need > c->big_ws.cap) {
+            GMS_HIP(hipStreamSynchronize(c->stream));
+            GMS_HIP(c->big_ws.reserve(need));
+        }
+        p.stagger_cycles = 0;
+        GMS_HIP(gms::launch_filter_big(p, mcap, n_wg, (uint32_t*)c->big_ws.p, c->stream));
+    }
     return GMS_OK;
 }
 

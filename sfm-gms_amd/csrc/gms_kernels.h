@@ -20,6 +20,8 @@ struct FilterParams {
     const gms_pair* pairs;
     int n_pairs;
     int prefetch_stride;        // workgroup b touches the match array of pair b + stride (0 = off)
+    int stagger_cycles;         // first-round workgroups start spread over this many shader cycles (0 = off)
+    int stagger_blocks;         // how many leading workgroups count as the first round
     const gms_dmatch* matches;
     gms_dmatch* out;
     gms_pair_result* results;
@@ -41,6 +43,11 @@ size_t     filter_lds_bytes(int kpt, uint32_t table_slots);
 hipError_t launch_normalize(const gms_keypoint* d_kp, const int64_t* d_frame_off, const int32_t* d_wh,
                             int n_frames, int64_t total_kp, float* d_pts, hipStream_t stream);
 hipError_t launch_filter(const FilterParams& p, int kpt, int n_pairs, hipStream_t stream);
+// large pairs (gms_kernel_big.hip): code words and table in a per-workgroup HBM slab
+constexpr int kBigMaxMatches = 262144;
+int        big_mcap(int max_m);
+size_t     big_ws_stride_dwords(int mcap);
+hipError_t launch_filter_big(const FilterParams& p, int mcap, int n_workgroups, uint32_t* ws, hipStream_t stream);
 hipError_t launch_threshold(const int32_t* d_T, const int32_t* d_n, const int32_t* d_score, double factor,
                             int count, uint8_t* d_out, hipStream_t stream);
 

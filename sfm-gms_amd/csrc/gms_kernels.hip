@@ -40,9 +40,9 @@ constexpr uint32_t kEmpty = 0xFFFFFFFFu;
 // Diagnostic build only (-DGMS_PHASE_TIMING, libgms_hip_diag.so): thread 0 of each workgroup sums the
 // shader-clock cycles between phase boundaries into p.diag[block][phase]. No stamp exists in the product build.
 #ifdef GMS_PHASE_TIMING
-#define GMS_STAMP_DECL unsigned long long ph_[12] = {0}; unsigned long long t_prev_ = __builtin_readcyclecounter();
+#define GMS_STAMP_DECL unsigned long long ph_[16] = {0}; unsigned long long t_prev_ = __builtin_readcyclecounter();
 #define GMS_STAMP(k) do { unsigned long long t_ = __builtin_readcyclecounter(); ph_[k] += t_ - t_prev_; t_prev_ = t_; } while (0)
-#define GMS_STAMP_FLUSH do { if (tid == 0 && p.diag) { ph_[4] = misc[40]; for (int k_ = 0; k_ < 12; ++k_) p.diag[blockIdx.x * 12 + k_] = ph_[k_]; } } while (0)
+#define GMS_STAMP_FLUSH do { if (tid == 0 && p.diag) { for (int k_ = 0; k_ < 16; ++k_) p.diag[blockIdx.x * 16 + k_] = ph_[k_]; } } while (0)
 #else
 #define GMS_STAMP_DECL
 #define GMS_STAMP(k)
@@ -95,13 +95,6 @@ __device__ __forceinline__ int bucket_first_empty(const uint4& v)
     o = (v.y == kEmpty) ? 4 : o;
     o = (v.x == kEmpty) ? 0 : o;
     return o;
-}
-// first empty slot of bucket v, trying slot pref (0..3) first: different right cells that meet in an empty
-// bucket at the same moment then mostly go for different slots instead of racing for slot 0
-__device__ __forceinline__ int bucket_pref_empty(const uint4& v, uint32_t pref)
-{
-    const uint32_t vp = pref == 0 ? v.x : pref == 1 ? v.y : pref == 2 ? v.z : v.w;
-    return vp == kEmpty ? (int)(pref << 2) : bucket_first_empty(v);
 }
 __device__ __forceinline__ uint32_t bucket_count(const uint4& v, uint32_t kr)
 {
@@ -243,6 +236,14 @@ filter_kernel(FilterParams p)
                                                    // [0..63] add/CAS sink per lane, [64..127] min sink per lane,
                                                    // [128..131] an always-empty bucket (16-byte aligned)
 
+    // Every pair of a batch costs about the same, so the workgroups of one dispatch round would all read their
+    // match arrays at the same moment (an HBM burst, then a long quiet stretch) and stay in lockstep round after
+    // round. The first round's workgroups start spread over p.stagger_cycles; the spread then persists.
+    if (p.stagger_cycles > 0 && blockIdx.x < (unsigned)p.stagger_blocks) {
+        const unsigned slot = (blockIdx.x * 37u) & 63u;
+        const long long until = (long long)__builtin_readcyclecounter() + (long long)slot * (p.stagger_cycles >> 6);
+        while ((long long)__builtin_readcyclecounter() < until) __builtin_amdgcn_s_sleep(32);
+    }
     if (tid < 48) misc[tid] = 0;
     if (tid < 128) trash[tid] = 0;
     if (tid >= 128 && tid < 132) trash[tid] = kEmpty;
@@ -291,12 +292,20 @@ filter_kernel(FilterParams p)
             const int i = min(k * kThreads + tid, mm - 1);
             qt[k] = *reinterpret_cast<const int2*>(&matches[i]);
         }
+#ifdef GMS_PHASE_TIMING
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        GMS_STAMP(4);  // bin: (queryIdx, trainIdx) loads landed
+#endif
         float2 a[KPT], b[KPT];
 #pragma unroll
         for (int k = 0; k < KPT; ++k) {
             a[k] = ptsA[min((uint32_t)qt[k].x, (uint32_t)(nA - 1))];
             b[k] = ptsB[min((uint32_t)qt[k].y, (uint32_t)(nB - 1))];
         }
+#ifdef GMS_PHASE_TIMING
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        GMS_STAMP(12);  // bin: gathers landed
+#endif
         const int wr = p.right_w[0];
         const uint32_t nr = (uint32_t)(wr * p.right_h[0]);
         const float fwr = (float)wr, fhr = (float)p.right_h[0];
@@ -336,8 +345,9 @@ filter_kernel(FilterParams p)
                 (void)*reinterpret_cast<const volatile uint32_t*>(base + (size_t)ln * 128);
         }
     }
+    GMS_STAMP(13);    // bin: codes + half-cell histogram
     __syncthreads();  // nfine complete
-    GMS_STAMP(0);     // bin (HBM read + gathers + half-cell histogram)
+    GMS_STAMP(0);     // bin: wait for the other waves
 
     // ---- per grid type, once per pair: nLeft of every cell, its table region, and the half-cell view of it.
     //      Regions may sit in the table in any order, so a cell simply takes the next free buckets from a
@@ -436,7 +446,7 @@ filter_kernel(FilterParams p)
                         v[c] = *reinterpret_cast<const uint4*>(lds_at(tab, slot[c]));
                     }
                     // round 1: "+1" where the bucket already holds the right cell, CAS into its first empty slot
-                    // where it does not
+                    // where it does not. Slots of a bucket fill lowest-first, so the occupied slots are a prefix.
                     uint32_t o_add[kChunk], o_cas[kChunk];
                     uint32_t found = 0, canput = 0;
 #pragma unroll
@@ -444,7 +454,7 @@ filter_kernel(FilterParams p)
                         const bool valid = (d[k0 + c] & 0xFFFFu) != 0;
                         const uint32_t kr = (code[k0 + c] & kRMask) << kSlotRShift;
                         const int f = bucket_find(v[c], kr);
-                        const int e = bucket_pref_empty(v[c], (__umul24(code[k0 + c] & kRMask, 2531u) >> 12) & 3u);
+                        const int e = bucket_first_empty(v[c]);
                         const bool fnd = valid && f >= 0;
                         const bool put = valid && f < 0 && e >= 0;
                         if (valid && f < 0 && e < 0) pending |= 1u << (k0 + c);  // full bucket: leftovers
@@ -454,30 +464,38 @@ filter_kernel(FilterParams p)
                         o_add[c] = atomicAdd(lds_at(tab, fnd ? slot[c] : trash_add), 1u);
                         o_cas[c] = atomicCAS(lds_at(tab, put ? slot[c] : trash_add), kEmpty, kr | 1u);
                     }
+                    __builtin_amdgcn_sched_barrier(0);  // all of the chunk's atomics are issued before any result is read
                     // round 2: a lost CAS whose winner was the same right cell (common: the true matches of a
-                    // cell arrive together) becomes "+1" on that slot; any other winner sends us to the leftovers
-                    uint32_t o_again[kChunk];
-                    uint32_t won = 0, same = 0;
+                    // cell arrive together) becomes "+1" on that slot; if the winner was another right cell, the
+                    // next slot up (still empty in our copy of the bucket) gets one more CAS
+                    uint32_t o_again[kChunk], o_cas2[kChunk];
+                    uint32_t won = 0, same = 0, retry = 0;
 #pragma unroll
                     for (int c = 0; c < kChunk; ++c) {
                         const uint32_t kr = (code[k0 + c] & kRMask) << kSlotRShift;
                         const bool put = (canput >> c) & 1u;
                         const bool w = put && o_cas[c] == kEmpty;
                         const bool sm = put && !w && (o_cas[c] ^ kr) <= kSlotCountMask;
-                        if (put && !w && !sm) pending |= 1u << (k0 + c);
+                        const bool rt = put && !w && !sm && (slot[c] & 12u) != 12u;  // a higher slot exists (and was empty)
+                        if (put && !w && !sm && !rt) pending |= 1u << (k0 + c);
                         won |= (w ? 1u : 0u) << c;
                         same |= (sm ? 1u : 0u) << c;
+                        retry |= (rt ? 1u : 0u) << c;
                         o_again[c] = atomicAdd(lds_at(tab, sm ? slot[c] : trash_add), 1u);
+                        o_cas2[c] = atomicCAS(lds_at(tab, rt ? slot[c] + 4u : trash_add), kEmpty, kr | 1u);
                     }
+                    __builtin_amdgcn_sched_barrier(0);
                     // the count this match produced, folded into the cell's running arg-max
 #pragma unroll
                     for (int c = 0; c < kChunk; ++c) {
                         const bool fnd = (found >> c) & 1u, w = (won >> c) & 1u, sm = (same >> c) & 1u;
+                        const bool w2 = ((retry >> c) & 1u) && o_cas2[c] == kEmpty;
+                        if (((retry >> c) & 1u) && !w2) pending |= 1u << (k0 + c);
                         const uint32_t count = fnd ? (o_add[c] & kSlotCountMask) + 1u
-                                                   : (w ? 1u : (o_again[c] & kSlotCountMask) + 1u);
+                                                   : ((w || w2) ? 1u : (o_again[c] & kSlotCountMask) + 1u);
                         const uint32_t key = ~((count << 11) | (2047u - (code[k0 + c] & kRMask)));
                         const uint32_t hdr = (d[k0 + c] >> 16) << 4;
-                        atomicMin(lds_at(tab, (fnd || w || sm) ? hdr : trash_min), key);
+                        atomicMin(lds_at(tab, (fnd || w || sm || w2) ? hdr : trash_min), key);
                     }
                 }
                 GMS_STAMP(3);  // insert: first-probe rounds

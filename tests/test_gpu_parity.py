@@ -57,6 +57,55 @@ def test_match_counts_across_kernel_variants(ctx, oracle, n):
     _check(ctx, oracle, cases.random_pair(60 + n % 17, n=n, inlier_frac=0.5), True, True)
 
 
+# ---- BASELINE config 4 and the reference's dense call: pairs too large for the register + LDS kernel ------------
+@pytest.mark.parametrize("rot,scale", cases.FLAGS)
+def test_config4_4k_50k_features(ctx, oracle, rot, scale):
+    c = cases.random_pair(104, n=50000, size1=(3840, 2160), inlier_frac=0.5, theta_deg=0.0 if not rot else 90.0,
+                          scale=1.0 if not scale else 0.5)
+    kept = _check(ctx, oracle, c, rot, scale)
+    assert kept > 5000
+
+
+@pytest.mark.parametrize("n", [16385, 20000, 65536])
+def test_large_pairs_edges(ctx, oracle, n):
+    _check(ctx, oracle, cases.random_pair(70 + n % 13, n=n, inlier_frac=0.4), True, True)
+
+
+def test_dense_disparity_shape(ctx, oracle, synth, pkg):
+    """DisparityUtil.cpp:123-149: one keypoint per pixel (450 x 375 = 168 750 matches in raster order), default flags."""
+    w, h = 450, 375
+    ys, xs = np.mgrid[0:h, 0:w]
+    xy1 = np.stack([xs.ravel(), ys.ravel()], axis=1).astype(np.float32)
+    rng = np.random.default_rng(3)
+    disp = 12.0 + 6.0 * np.sin(xy1[:, 1] / 40.0)
+    xy2 = xy1.copy()
+    train = np.arange(len(xy1))
+    # the matcher's answer: most pixels find the pixel `disp` to the left, the rest something random
+    tx = np.clip(np.rint(xy1[:, 0] - disp), 0, w - 1).astype(np.int64)
+    train = (ys.ravel() * w + tx).astype(np.int64)
+    bad = rng.uniform(size=len(train)) < 0.3
+    train[bad] = rng.integers(0, len(train), int(bad.sum()))
+    c = dict(size1=(w, h), size2=(w, h), kp1=synth.make_keypoints(xy1), kp2=synth.make_keypoints(xy2),
+             matches=synth.make_matches(np.arange(len(xy1)), train, rng))
+    kept = _check(ctx, oracle, c, False, False)
+    assert kept > 50000
+
+
+def test_large_pairs_in_a_batch(ctx, oracle, pkg, synth):
+    batch = importlib.import_module("sfm-gms_amd.batch")
+    size = (1920, 1080)
+    frames, pairs, matches = _sequence_batch(pkg, synth, 4, 30000, 5, 33, ragged=True, size=size)
+    table = batch.FrameTable(ctx, frames, [size] * len(frames))
+    out, res, mask = batch.filter_pairs(ctx, table, pairs, matches, True, False, 6.0)
+    kp_all = np.concatenate(frames)
+    wh = np.array([size] * len(frames), dtype=np.int32).reshape(-1)
+    failed, wout, wres, wmask = oracle.batch(kp_all, table.frame_off_host, wh, pairs, matches, True, False, 6.0, 4)
+    assert failed == 0 and np.array_equal(mask, wmask) and res.tobytes() == wres.tobytes()
+    for i in range(len(pairs)):
+        o, k = int(pairs["match_off"][i]), int(res["n_inliers"][i])
+        assert out[o:o + k].tobytes() == wout[o:o + k].tobytes()
+
+
 def test_capacity_error_is_loud(ctx, pkg):
     n = ctx.max_matches + 1
     c = cases.random_pair(61, n=n, inlier_frac=0.5)

@@ -16,7 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 
-PHASES = ["bin", "region_tables", "clear", "insert_first", "n_leftover_items", "verify", "mark", "count_select", "out_scan", "copy_out", "insert_leftover", "insert_barrier"]
+PHASES = ["bin_barrier", "region_tables", "clear", "insert_first", "bin_qt_loads", "verify", "mark", "count_select", "out_scan", "copy_out", "insert_leftover", "insert_barrier", "bin_gathers", "bin_compute", "x14", "x15"]
 
 
 def main():
@@ -37,14 +37,14 @@ def main():
     ctx.set_stream(stream.cuda_stream)
     args = argparse.Namespace(pairs=a.pairs, frames=64, features=10000, inlier_frac=0.5)
     wl = bench.build_workload(args, 0, 1, dev, pkg, synth, ctx)
-    dbuf = torch.zeros(a.pairs * 12, dtype=torch.int64, device=dev)
+    dbuf = torch.zeros(a.pairs * 16, dtype=torch.int64, device=dev)
     lib.gms_diag_set_buffer.argtypes = [C.c_void_p]
     lib.gms_diag_set_buffer(dbuf.data_ptr())
     for _ in range(3):
         with torch.cuda.stream(stream):
             bench.launch(ctx, wl, bool(a.rot), bool(a.scale))
     torch.cuda.synchronize()
-    d = dbuf.cpu().numpy().reshape(-1, 12)[:, :12].astype(np.float64)
+    d = dbuf.cpu().numpy().reshape(-1, 16)[:, :16].astype(np.float64)
     mean = d.mean(axis=0)
     tot = mean.sum()
     out = {"pairs": a.pairs, "rot": a.rot, "scale": a.scale, "total_cycles": tot,
