@@ -166,6 +166,23 @@ __device__ __forceinline__ uint32_t region_lookup_general(const uint32_t* tab, u
     return 0;
 }
 
+// verifyCellPairs' test "thresh = sqrt(T / n) * factor; reject iff thresh > score" (divsd, sqrtsd, mulsd, comisd at
+// DLL@0x180049171). In exact arithmetic (factor > 0) it is T * factor^2 > score^2 * n. b = score^2 * n is exact in
+// fp64 (< 2^53) and a = fl(fl(T * factor) * factor) is within 2^-51 of exact, while the reference's three roundings
+// move thresh by less than 2^-50 relative: when a and b differ by more than 2^-40 relative, the reference's answer is
+// the sign of a - b. Only near-ties (exact ties, in practice) run the divide and the square root.
+__device__ __forceinline__ bool threshold_rejects(uint32_t T, uint32_t n, uint32_t score, double factor, bool fast_ok)
+{
+    const double dT = (double)T, dN = (double)n, dS = (double)score;
+    if (fast_ok) {
+        const double a = dT * factor * factor, b = dS * dS * dN;
+        if (fabs(a - b) > fmax(a, b) * 0x1p-40) return a > b;
+    }
+    return sqrt(dT / dN) * factor > dS;
+}
+// factor ranges where factor^2 neither overflows nor loses precision to underflow
+__device__ __forceinline__ bool threshold_fast_ok(double factor) { return factor > 1e-100 && factor < 1e100; }
+
 // lane ^ 1 exchange on the VALU (DPP quad_perm [1,0,3,2]), no LDS round trip
 __device__ __forceinline__ uint32_t dpp_xor1(uint32_t x)
 {
@@ -204,14 +221,15 @@ normalize_kernel(const gms_keypoint* __restrict__ kp, const int64_t* __restrict_
 // a match under grid type g is never computed per match -- a per-pair table indexed by the match's
 // half-cell index gives the table region (insert) and the verified cell result (mark) with one LDS read.
 // ------------------------------------------------------------------------------------------------
-template <int KPT, bool ROT>
-__global__ void __launch_bounds__(kThreads)
+template <int KPT, bool ROT, int NT>
+__global__ void __launch_bounds__(NT)
 filter_kernel(FilterParams p)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-    constexpr int kMcap = KPT * kThreads;
+    constexpr int kMcap = KPT * NT;
     constexpr int kNRot = ROT ? 8 : 1;
-    constexpr int kChunk = (KPT % 5 == 0) ? 5 : 4;  // matches a thread keeps in flight through the LDS stages
+    // matches a thread keeps in flight through the LDS stages: 5 (4) with 128 registers per thread, 10 with 256
+    constexpr int kChunk = (NT <= 512 && KPT % 10 == 0) ? 10 : (KPT % 5 == 0) ? 5 : 4;
     static_assert(KPT % kChunk == 0, "KPT must be a multiple of the chunk");
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -247,9 +265,9 @@ filter_kernel(FilterParams p)
     if (tid < 48) misc[tid] = 0;
     if (tid < 128) trash[tid] = 0;
     if (tid >= 128 && tid < 132) trash[tid] = kEmpty;
-    for (int i = tid; i < (kMcap >> 5); i += kThreads) bestmask[i] = 0;
-    for (int i = tid; i < kFineStride; i += kThreads) nfine[i] = 0;
-    for (int i = tid; i < 4 * kFineStride; i += kThreads) fdesc4[i] = 0;
+    for (int i = tid; i < (kMcap >> 5); i += NT) bestmask[i] = 0;
+    for (int i = tid; i < kFineStride; i += NT) nfine[i] = 0;
+    for (int i = tid; i < 4 * kFineStride; i += NT) fdesc4[i] = 0;
 
     const bool bad_pair = m < 0 || m > kMcap || pr.frame_a < 0 || pr.frame_a >= p.n_frames ||
                           pr.frame_b < 0 || pr.frame_b >= p.n_frames;
@@ -265,6 +283,7 @@ filter_kernel(FilterParams p)
     const float2* __restrict__ ptsB = p.pts + offB;
     const int mm = bad_pair ? 0 : m;
     const int n_scales = p.with_scale ? 5 : 1;
+    const bool thr_fast = threshold_fast_ok(p.threshold_factor);
     uint32_t best_count = 0;
     int best_scale = -1, best_rot = -1;
     GMS_STAMP_DECL
@@ -289,21 +308,34 @@ filter_kernel(FilterParams p)
         int2 qt[KPT];
 #pragma unroll
         for (int k = 0; k < KPT; ++k) {
-            const int i = min(k * kThreads + tid, mm - 1);
+            const int i = min(k * NT + tid, mm - 1);
             qt[k] = *reinterpret_cast<const int2*>(&matches[i]);
+        }
+        // The train-side gather is 8 bytes from a random line per match: the vector memory pipe takes it one
+        // line at a time. When frame B's normalised points fit the (still unused) table area, copy them into LDS
+        // with coalesced loads while the match loads are in flight, and gather from LDS instead.
+        const bool stage_b = (uint32_t)nB * 2u <= T && nB <= 4 * mm;  // workgroup-uniform
+        float2* lds_b = reinterpret_cast<float2*>(tab);
+        if (stage_b) {
+            for (int j = tid; j < nB; j += NT) lds_b[j] = ptsB[j];
+            __syncthreads();
         }
 #ifdef GMS_PHASE_TIMING
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        GMS_STAMP(4);  // bin: (queryIdx, trainIdx) loads landed
+        GMS_STAMP(4);  // bin: (queryIdx, trainIdx) loads landed, frame B staged
 #endif
         float2 a[KPT], b[KPT];
 #pragma unroll
-        for (int k = 0; k < KPT; ++k) {
-            a[k] = ptsA[min((uint32_t)qt[k].x, (uint32_t)(nA - 1))];
-            b[k] = ptsB[min((uint32_t)qt[k].y, (uint32_t)(nB - 1))];
+        for (int k = 0; k < KPT; ++k) a[k] = ptsA[min((uint32_t)qt[k].x, (uint32_t)(nA - 1))];
+        if (stage_b) {
+#pragma unroll
+            for (int k = 0; k < KPT; ++k) b[k] = lds_b[min((uint32_t)qt[k].y, (uint32_t)(nB - 1))];
+        } else {
+#pragma unroll
+            for (int k = 0; k < KPT; ++k) b[k] = ptsB[min((uint32_t)qt[k].y, (uint32_t)(nB - 1))];
         }
 #ifdef GMS_PHASE_TIMING
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         GMS_STAMP(12);  // bin: gathers landed
 #endif
         const int wr = p.right_w[0];
@@ -312,7 +344,7 @@ filter_kernel(FilterParams p)
         bool any_bad = false;
 #pragma unroll
         for (int k = 0; k < KPT; ++k) {
-            const bool live = k * kThreads + tid < mm;
+            const bool live = k * NT + tid < mm;
             // parity domain: indices in range; coordinates finite, non-negative, < 2^20 -- one unsigned
             // compare on the bit patterns (negative, NaN and Inf patterns are all above 0x49800000 = 2^20;
             // -0.0 was canonicalised away by normalize_kernel)
@@ -341,7 +373,7 @@ filter_kernel(FilterParams p)
             const gms_pair np = p.pairs[nxt];
             const volatile char* base = reinterpret_cast<const volatile char*>(p.matches + np.match_off);
             const int lines = (np.m > 0 && np.m <= kMcap) ? (np.m * 16 + 127) >> 7 : 0;
-            for (int ln = tid; ln < lines; ln += kThreads)
+            for (int ln = tid; ln < lines; ln += NT)
                 (void)*reinterpret_cast<const volatile uint32_t*>(base + (size_t)ln * 128);
         }
     }
@@ -352,7 +384,7 @@ filter_kernel(FilterParams p)
     // ---- per grid type, once per pair: nLeft of every cell, its table region, and the half-cell view of it.
     //      Regions may sit in the table in any order, so a cell simply takes the next free buckets from a
     //      per-grid-type counter (misc[12 + g]); 1600 (grid type, cell) items over the workgroup.
-    for (int item = tid; item < 4 * kLeftN; item += kThreads) {
+    for (int item = tid; item < 4 * kLeftN; item += NT) {
         const int g = item / kLeftN, cell = item - g * kLeftN;
         const int x = cell % kLeftW, y = cell / kLeftW;
         const int hx0 = 2 * x - (g & 1), hy0 = 2 * y - (g >> 1);
@@ -389,7 +421,7 @@ filter_kernel(FilterParams p)
             const float fwr = (float)wr, fhr = (float)hr;
             int t[KPT];
 #pragma unroll
-            for (int k = 0; k < KPT; ++k) t[k] = matches[min(k * kThreads + tid, mm - 1)].trainIdx;
+            for (int k = 0; k < KPT; ++k) t[k] = matches[min(k * NT + tid, mm - 1)].trainIdx;
             float2 b[KPT];
 #pragma unroll
             for (int k = 0; k < KPT; ++k) b[k] = ptsB[min((uint32_t)t[k], (uint32_t)(nB - 1))];
@@ -415,12 +447,12 @@ filter_kernel(FilterParams p)
             {
                 const uint4 e4 = make_uint4(kEmpty, kEmpty, kEmpty, kEmpty);
                 uint4* tab4 = reinterpret_cast<uint4*>(tab);
-                for (uint32_t i = tid; i < (T >> 2); i += kThreads) tab4[i] = e4;
+                for (uint32_t i = tid; i < (T >> 2); i += NT) tab4[i] = e4;
             }
             __syncthreads();
             GMS_STAMP(2);  // clear
             // every wave is past the previous grid type's mark (it reads fres): reset it before verify writes
-            for (int i = tid; i < kFineStride; i += kThreads) fres[i] = kNoMatch;
+            for (int i = tid; i < kFineStride; i += NT) fres[i] = kNoMatch;
 
             // ---- assignMatchPairs: motion[l][r]++, kChunk matches in flight per thread. Written without
             //      branches: every lane issues every atomic, and a lane the operation does not apply to is
@@ -517,7 +549,7 @@ filter_kernel(FilterParams p)
             //      by one DPP exchange. With rotation: one lane per (cell, rotation), eight look-ups in two rounds.
             {
                 constexpr int kItems = ROT ? kLeftN * 8 : kLeftN * 2;
-                for (int item = tid; item < ((kItems + 63) & ~63); item += kThreads) {
+                for (int item = tid; item < ((kItems + 63) & ~63); item += NT) {
                     const bool live = item < kItems;
                     const int i = live ? (ROT ? (item >> 3) : (item >> 1)) : 0;
                     const int rot = ROT ? (item & 7) : 0;
@@ -588,9 +620,7 @@ filter_kernel(FilterParams p)
                     tn += (ni << 4) | 1u;
                     uint32_t pass = 0;
                     if (ni != 0 && (ROT || half == 0)) {
-                        // divsd, sqrtsd, mulsd, comisd: reject iff thresh > score
-                        const double thresh = sqrt((double)(tn >> 4) / (double)(tn & 15u)) * p.threshold_factor;
-                        pass = (thresh > (double)score) ? 0u : 1u;
+                        pass = threshold_rejects(tn >> 4, tn & 15u, score, p.threshold_factor, thr_fast) ? 0u : 1u;
                     }
                     uint32_t bits = pass;
                     bool writer = ni != 0 && half == 0;
@@ -663,7 +693,7 @@ filter_kernel(FilterParams p)
             for (int k = 0; k < KPT; ++k) {
                 const unsigned long long b = __ballot((code[k] >> (kAccShift + winner)) & 1u);
                 if (lane == 0) {
-                    const int ch = k * (kThreads / 64) + wave;  // chunk of 64 consecutive matches
+                    const int ch = k * (NT / 64) + wave;  // chunk of 64 consecutive matches
                     bestmask[2 * ch] = (uint32_t)b;
                     bestmask[2 * ch + 1] = (uint32_t)(b >> 32);
                 }
@@ -681,9 +711,9 @@ filter_kernel(FilterParams p)
     const bool failed = misc[8] != 0;
     const int n_chunks = (mm + 63) >> 6;
     {
-        // exclusive scan of per-chunk popcounts; kThreads chunks per round, carry in misc[9]
+        // exclusive scan of per-chunk popcounts; NT chunks per round, carry in misc[9]
         uint32_t* wave_tot = misc + 16;
-        for (int base = 0; base < n_chunks; base += kThreads) {
+        for (int base = 0; base < n_chunks; base += NT) {
             const int c = base + tid;
             const uint32_t v = (c < n_chunks && !failed) ? __popc(bestmask[2 * c]) + __popc(bestmask[2 * c + 1]) : 0u;
             uint32_t incl = v;
@@ -698,7 +728,7 @@ filter_kernel(FilterParams p)
             for (int w = 0; w < wave; ++w) wave_off += wave_tot[w];
             if (c < n_chunks) chunk_base[c] = wave_off + incl - v;
             __syncthreads();
-            if (tid == kThreads - 1) misc[9] = wave_off + incl;
+            if (tid == NT - 1) misc[9] = wave_off + incl;
             __syncthreads();
         }
     }
@@ -714,7 +744,7 @@ filter_kernel(FilterParams p)
         uint32_t inm = 0;
 #pragma unroll
         for (int c = 0; c < kChunk; ++c) {
-            const int i = (k0 + c) * kThreads + tid;
+            const int i = (k0 + c) * NT + tid;
             const int ch = i >> 6;
             pos[c] = 0;
             v[c] = make_uint4(0, 0, 0, 0);
@@ -752,8 +782,7 @@ __global__ void threshold_kernel(const int32_t* T, const int32_t* n, const int32
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < count) {
-        const double thresh = sqrt((double)T[i] / (double)n[i]) * factor;
-        out[i] = thresh > (double)score[i] ? 1 : 0;
+        out[i] = threshold_rejects((uint32_t)T[i], (uint32_t)n[i], (uint32_t)score[i], factor, threshold_fast_ok(factor)) ? 1 : 0;
     }
 }
 
@@ -795,29 +824,31 @@ hipError_t launch_normalize(const gms_keypoint* d_kp, const int64_t* d_frame_off
     return hipGetLastError();
 }
 
-template <int KPT, bool ROT>
+template <int KPT, bool ROT, int NT>
 static hipError_t launch_filter_t(const FilterParams& p, int n_pairs, size_t lds_bytes, hipStream_t stream)
 {
     static bool attr_set = false;  // per instantiation; the largest request this variant can make
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(filter_kernel<KPT, ROT>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(filter_kernel<KPT, ROT, NT>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL((filter_kernel<KPT, ROT>), dim3((unsigned)n_pairs), dim3(kThreads), lds_bytes, stream, p);
+    hipLaunchKernelGGL((filter_kernel<KPT, ROT, NT>), dim3((unsigned)n_pairs), dim3(NT), lds_bytes, stream, p);
     return hipGetLastError();
 }
 
+// kpt = matches per thread of the 1024-thread workgroup. (A 512-thread build with twice the matches per thread and
+// twice the matches in flight was measured 27 % slower at 10k matches: the kernel wants waves, not registers.)
 hipError_t launch_filter(const FilterParams& p, int kpt, int n_pairs, hipStream_t stream)
 {
     if (n_pairs <= 0) return hipSuccess;
     const size_t lds = filter_lds_bytes(kpt, p.table_slots);
     const bool rot = p.with_rotation != 0;
     switch (kpt) {
-    case 4: return rot ? launch_filter_t<4, true>(p, n_pairs, lds, stream) : launch_filter_t<4, false>(p, n_pairs, lds, stream);
-    case 10: return rot ? launch_filter_t<10, true>(p, n_pairs, lds, stream) : launch_filter_t<10, false>(p, n_pairs, lds, stream);
-    case 16: return rot ? launch_filter_t<16, true>(p, n_pairs, lds, stream) : launch_filter_t<16, false>(p, n_pairs, lds, stream);
+    case 4: return rot ? launch_filter_t<4, true, 1024>(p, n_pairs, lds, stream) : launch_filter_t<4, false, 1024>(p, n_pairs, lds, stream);
+    case 10: return rot ? launch_filter_t<10, true, 1024>(p, n_pairs, lds, stream) : launch_filter_t<10, false, 1024>(p, n_pairs, lds, stream);
+    case 16: return rot ? launch_filter_t<16, true, 1024>(p, n_pairs, lds, stream) : launch_filter_t<16, false, 1024>(p, n_pairs, lds, stream);
     default: return hipErrorInvalidValue;
     }
 }

@@ -163,6 +163,13 @@ def test_threshold_fp64_matches_ieee(ctx, oracle):
         ok = Tt > 0
         g = ctx.selftest_threshold(Tt[ok], np.full(ok.sum(), nn, dtype=np.int32), (6 * k[ok]).astype(np.int32), 6.0)
         assert not g.any()
+    # other factors, including ones for which the squared form is not used (tiny / huge / zero / negative)
+    for f in (0.0, -1.0, 1e-150, 0.37, 2.5, 5.999999999999999, 6.000000000000001, 1e9, 1e150):
+        Tf = rng.integers(1, 100000, 50000).astype(np.int32)
+        nf = rng.integers(1, 10, 50000).astype(np.int32)
+        th = np.sqrt(Tf.astype(np.float64) / nf) * f
+        sf = np.clip(np.floor(np.clip(th, 0, 2e6)) + rng.integers(-1, 2, len(Tf)), 0, 2 ** 21).astype(np.int32)
+        assert np.array_equal(ctx.selftest_threshold(Tf, nf, sf, f), (th > sf).astype(np.uint8)), f
 
 
 def test_normalize_kernel_is_ieee_fp32_divide(ctx, pkg):

@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Side measurements quoted in DESIGN.md (not the headline metric): the one-shot host-pointer call (PCIe inclusive),
+and the large-pair kernel on BASELINE config 4. Run on the GPU box: python tools/measure_misc.py"""
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+pkg = importlib.import_module("sfm-gms_amd")
+import cases  # noqa: E402
+import gms_oracle  # noqa: E402
+
+ctx = pkg.GmsContext(0)
+out = {}
+
+
+def timeit(fn, reps):
+    fn()
+    t = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        fn()
+        t.append(time.perf_counter() - t0)
+    return float(np.median(t))
+
+
+c = cases.random_pair(100, n=10000, inlier_frac=0.5)
+for flags in ((False, False), (True, True)):
+    gpu = timeit(lambda: ctx.match(c["size1"], c["size2"], c["kp1"], c["kp2"], c["matches"], *flags), 20)
+    cpu = timeit(lambda: gms_oracle.match(c["size1"], c["size2"], c["kp1"], c["kp2"], c["matches"], *flags), 3)
+    out[f"one_shot_10k_rot{int(flags[0])}_scale{int(flags[1])}"] = {
+        "gpu_call_ms_incl_pcie": gpu * 1e3, "gpu_pairs_per_s": 1 / gpu, "cpu_oracle_ms_1thread": cpu * 1e3}
+c = cases.random_pair(104, n=50000, size1=(3840, 2160), inlier_frac=0.5)
+for flags in ((False, False), (True, True)):
+    gpu = timeit(lambda: ctx.match(c["size1"], c["size2"], c["kp1"], c["kp2"], c["matches"], *flags), 5)
+    cpu = timeit(lambda: gms_oracle.match(c["size1"], c["size2"], c["kp1"], c["kp2"], c["matches"], *flags), 2)
+    out[f"config4_50k_rot{int(flags[0])}_scale{int(flags[1])}"] = {
+        "gpu_call_ms_incl_pcie": gpu * 1e3, "cpu_oracle_ms_1thread": cpu * 1e3}
+print(json.dumps(out, indent=1))
