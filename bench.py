@@ -168,17 +168,24 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
+    # GMS_BENCH_ONE_DEVICE=1 is a rehearsal mode for a one-GPU box: every rank uses cuda:0 and the rendezvous
+    # runs over gloo (RCCL refuses two ranks on one device). The driver's multi-GPU runs do not set it.
+    one_device = os.environ.get("GMS_BENCH_ONE_DEVICE", "0") == "1"
+    dev_index = 0 if one_device else local_rank
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    dev = torch.device("cuda", local_rank)
+        torch.cuda.set_device(dev_index)
+        if one_device:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+    dev = torch.device("cuda", dev_index)
     torch.cuda.set_device(dev)
 
     pkg = importlib.import_module(PKG)
     synth = importlib.import_module(PKG + ".synth")
-    ctx = pkg.GmsContext(local_rank)  # raises if the HIP extension is missing: no fallback
+    ctx = pkg.GmsContext(dev_index)  # raises if the HIP extension is missing: no fallback
     stream = torch.cuda.Stream(device=dev)
     ctx.set_stream(stream.cuda_stream)
 
@@ -187,7 +194,7 @@ def main():
 
     wall, kern_ms = timed_steps(ctx, wl, stream, args.steps, args.warmup, False, False, dist)
     # whole-job aggregate: every rank ran the same number of pairs; time = max over ranks
-    t = torch.tensor([wall], dtype=torch.float64, device=dev)
+    t = torch.tensor([wall], dtype=torch.float64, device="cpu" if one_device else dev)
     if dist is not None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     wall_max = float(t.item())
