@@ -498,36 +498,30 @@ filter_kernel(FilterParams p)
                     }
                     __builtin_amdgcn_sched_barrier(0);  // all of the chunk's atomics are issued before any result is read
                     // round 2: a lost CAS whose winner was the same right cell (common: the true matches of a
-                    // cell arrive together) becomes "+1" on that slot; if the winner was another right cell, the
-                    // next slot up (still empty in our copy of the bucket) gets one more CAS
-                    uint32_t o_again[kChunk], o_cas2[kChunk];
-                    uint32_t won = 0, same = 0, retry = 0;
+                    // cell arrive together) becomes "+1" on that slot; any other winner sends us to the leftovers
+                    uint32_t o_again[kChunk];
+                    uint32_t won = 0, same = 0;
 #pragma unroll
                     for (int c = 0; c < kChunk; ++c) {
                         const uint32_t kr = (code[k0 + c] & kRMask) << kSlotRShift;
                         const bool put = (canput >> c) & 1u;
                         const bool w = put && o_cas[c] == kEmpty;
                         const bool sm = put && !w && (o_cas[c] ^ kr) <= kSlotCountMask;
-                        const bool rt = put && !w && !sm && (slot[c] & 12u) != 12u;  // a higher slot exists (and was empty)
-                        if (put && !w && !sm && !rt) pending |= 1u << (k0 + c);
+                        if (put && !w && !sm) pending |= 1u << (k0 + c);
                         won |= (w ? 1u : 0u) << c;
                         same |= (sm ? 1u : 0u) << c;
-                        retry |= (rt ? 1u : 0u) << c;
                         o_again[c] = atomicAdd(lds_at(tab, sm ? slot[c] : trash_add), 1u);
-                        o_cas2[c] = atomicCAS(lds_at(tab, rt ? slot[c] + 4u : trash_add), kEmpty, kr | 1u);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                     // the count this match produced, folded into the cell's running arg-max
 #pragma unroll
                     for (int c = 0; c < kChunk; ++c) {
                         const bool fnd = (found >> c) & 1u, w = (won >> c) & 1u, sm = (same >> c) & 1u;
-                        const bool w2 = ((retry >> c) & 1u) && o_cas2[c] == kEmpty;
-                        if (((retry >> c) & 1u) && !w2) pending |= 1u << (k0 + c);
                         const uint32_t count = fnd ? (o_add[c] & kSlotCountMask) + 1u
-                                                   : ((w || w2) ? 1u : (o_again[c] & kSlotCountMask) + 1u);
+                                                   : (w ? 1u : (o_again[c] & kSlotCountMask) + 1u);
                         const uint32_t key = ~((count << 11) | (2047u - (code[k0 + c] & kRMask)));
                         const uint32_t hdr = (d[k0 + c] >> 16) << 4;
-                        atomicMin(lds_at(tab, (fnd || w || sm || w2) ? hdr : trash_min), key);
+                        atomicMin(lds_at(tab, (fnd || w || sm) ? hdr : trash_min), key);
                     }
                 }
                 GMS_STAMP(3);  // insert: first-probe rounds
@@ -587,13 +581,15 @@ filter_kernel(FilterParams p)
                             }
                             const int lx = ix + ldx, ly = iy + ldy;
                             const int rx = jx + rdx, ry = jy + rdy;
-                            const bool okp = ni != 0 &&
-                                             (uint32_t)lx < (uint32_t)kLeftW && (uint32_t)ly < (uint32_t)kLeftH &&  // ll != -1
-                                             (uint32_t)rx < (uint32_t)wr && (uint32_t)ry < (uint32_t)hr;            // rr != -1
-                            const int ll = okp ? lx + ly * kLeftW : 0;
+                            // the left neighbour does not depend on j*: its two table reads go out together with the
+                            // header read instead of behind it
+                            const bool okl = ni != 0 && (uint32_t)lx < (uint32_t)kLeftW && (uint32_t)ly < (uint32_t)kLeftH;  // ll != -1
+                            const int ll = okl ? lx + ly * kLeftW : 0;
+                            const uint32_t nll = nleft[ll], dll = desc[ll];
+                            const bool okp = okl && (uint32_t)rx < (uint32_t)wr && (uint32_t)ry < (uint32_t)hr;             // rr != -1
                             rq[c] = okp ? (uint32_t)(rx + ry * wr) : 0u;  // 0: matches no slot of the all-empty stand-in
-                            tn += okp ? ((nleft[ll] << 4) | 1u) : 0u;
-                            dn[c] = okp ? desc[ll] : 0u;
+                            tn += okp ? ((nll << 4) | 1u) : 0u;
+                            dn[c] = okp ? dll : 0u;
                         }
                         uint4 v[4];
 #pragma unroll
