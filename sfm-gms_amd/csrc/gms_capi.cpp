@@ -211,7 +211,15 @@ int gms_filter_device(gms_ctx* c, const float* d_pts, const int64_t* d_frame_off
     p.diag = g_diag;
 #endif
     GMS_HIP(hipSetDevice(c->device));
-    if (kpt) {
+    static const bool use_occ2 = [] {  // GMS_OCC2=1: the two-workgroups-per-CU kernel for pairs it can hold
+        const char* e = std::getenv("GMS_OCC2");
+        return e && std::atoi(e) != 0;
+    }();
+    const int kpt2 = use_occ2 ? gms::occ2_pick_kpt(max_m) : 0;
+    if (kpt2) {
+        p.table_slots = gms::occ2_table_slots(kpt2);
+        GMS_HIP(gms::launch_filter_occ2(p, kpt2, n_pairs, c->stream));
+    } else if (kpt) {
         GMS_HIP(gms::launch_filter(p, kpt, n_pairs, c->stream));
     } else {
         // Large pairs: a fixed crew of persistent workgroups, each with an HBM slab for the pair's code words

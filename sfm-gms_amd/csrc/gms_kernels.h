@@ -43,6 +43,10 @@ size_t     filter_lds_bytes(int kpt, uint32_t table_slots);
 hipError_t launch_normalize(const gms_keypoint* d_kp, const int64_t* d_frame_off, const int32_t* d_wh,
                             int n_frames, int64_t total_kp, float* d_pts, hipStream_t stream);
 hipError_t launch_filter(const FilterParams& p, int kpt, int n_pairs, hipStream_t stream);
+// two-workgroups-per-CU variant (gms_kernel_occ2.hip), m <= 10 240
+int        occ2_pick_kpt(int max_m);
+uint32_t   occ2_table_slots(int kpt);
+hipError_t launch_filter_occ2(const FilterParams& p, int kpt, int n_pairs, hipStream_t stream);
 // large pairs (gms_kernel_big.hip): code words and table in a per-workgroup HBM slab
 constexpr int kBigMaxMatches = 262144;
 int        big_mcap(int max_m);
