@@ -2,26 +2,35 @@
 //
 // What the reference does per pair (cv::xfeatures2d::matchGMS, opencv_xfeatures2d452.dll; SURVEY.md
 // section 8a) is a dense 400 x N_right int32 "motion" matrix that is zeroed, filled and scanned 4 times
-// per hypothesis. That matrix has at most M non-zeros, so here it is never materialised: one workgroup
-// owns one image pair and keeps the pair's whole state in the CU's 160 KB LDS:
+// per hypothesis. That matrix has at most M non-zeros, so here it is never materialised: one 1024-thread
+// workgroup owns one image pair and keeps the pair's whole state in registers and in the CU's 160 KB LDS:
 //
-//   code[m]     one dword per match: right cell, unshifted left cell (x, y), the two half-cell shift
-//               bits that derive grid types 2..4, a valid bit, and 8 per-rotation inlier bits
-//   keys/cnt    open-addressing hash table  (left cell, right cell) -> count, i.e. the non-zeros of
-//               the motion matrix of the current (scale, grid type); built with LDS atomics
-//   nleft/best/accept  per-left-cell: match count, packed arg-max (count, lowest right cell),
-//               and the 8-bit "passes the threshold under rotation r" set
+//   code[KPT]   (registers) one dword per match: right cell of the current scale, half-cell index of the
+//               left point (it carries the left cell under all four grid types), 8 per-rotation inlier bits
+//   nfine       40 x 40 half-cell histogram of the left points: nLeft of any cell of any grid type is a
+//               sum of at most four entries, so there is no counting pass per grid type
+//   tab         the non-zeros of the motion matrix of the current (scale, grid type): every left cell owns
+//               a region = 1 header bucket + data buckets of four [right cell : 11 | count : 21] slots
+//               (one ds_read_b128 sees a bucket); built with LDS atomics, the header keeps the running
+//               arg-max of the row (highest count, lowest right cell) via atomicMin on the inverted key
+//   nleft4 / desc4 / fdesc4   per grid type: nLeft and region of every cell, and the same region seen from
+//               every half-cell (a match finds its region with one LDS read, no left-cell arithmetic)
+//   fres        per half-cell: (j*, rotation bits that pass the threshold) of the cell it falls in
 //
 // Rotation only changes which neighbour counts are summed, so one table build serves all 8 rotations;
-// the right cell only depends on the scale, the left cell only on the grid type. HBM sees each
-// match once on the way in (16 B, coalesced) plus the two 8-B keypoint gathers, and 16 B per survivor
-// on the way out. No MFMA: this is integer histogramming.
+// the right cell only depends on the scale, the left cell only on the grid type. HBM sees each match
+// once on the way in (16 B, coalesced) plus the two 8-B keypoint gathers, and 16 B per survivor on the
+// way out (today the 16-B records are read a second time at copy-out). No MFMA: integer histogramming.
+// Measured on MI355X the kernel is bound by chains of dependent LDS operations and by instruction issue
+// (one 16-wave workgroup per CU), not by HBM: the hot loops are written branch-free and staged (all of a
+// thread's independent LDS operations are issued before the first result is consumed).
 //
 // Bit-exactness notes (vs the DLL): fp32 multiply then floor for unshifted axes; widen the fp32
-// product to fp64, add 0.5, floor for shifted axes (DLL@0x180047bc0); fp64 div -> sqrt -> mul -> '>'
-// for the threshold (DLL@0x180049171); arg-max keeps the LOWEST right cell among maxima; hypotheses
-// are compared scale-outer / rotation-inner with strict '>' (DLL@0x180047dc0). Built with
-// -ffp-contract=off and HIP's default correctly rounded fp32 divide.
+// product to fp64, add 0.5, floor for shifted axes (DLL@0x180047bc0) -- both read off floor(2 * fl32(20 n));
+// fp64 div -> sqrt -> mul -> '>' for the threshold (DLL@0x180049171), decided by an exact squared form
+// unless it is a near-tie; arg-max keeps the LOWEST right cell among maxima; hypotheses are compared
+// scale-outer / rotation-inner with strict '>' (DLL@0x180047dc0). Built with -ffp-contract=off and
+// HIP's default correctly rounded fp32 divide.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
