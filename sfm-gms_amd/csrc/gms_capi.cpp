@@ -225,7 +225,7 @@ int gms_filter_device(gms_ctx* c, const float* d_pts, const int64_t* d_frame_off
         // Large pairs: a fixed crew of persistent workgroups, each with an HBM slab for the pair's code words
         // and table. The slab is (re)allocated here when it has to grow -- this branch is not stream-capturable.
         const int mcap = gms::big_mcap(max_m);
-        const int n_wg = n_pairs < 64 ? n_pairs : 64;
+        const int n_wg = n_pairs < c->n_cus ? n_pairs : c->n_cus;  // one persistent workgroup per CU at most
         const size_t need = (size_t)n_wg * gms::big_ws_stride_dwords(mcap) * 4;
         if (need > c->big_ws.cap) {
             GMS_HIP(hipStreamSynchronize(c->stream));

@@ -8,7 +8,7 @@
 //   table     the (left cell, right cell) -> count non-zeros -> the same slab; device-scope atomics, and every
 //             table read is an agent-scope atomic load (served by L2: the atomics never update the CU's L1)
 // The small per-cell and per-half-cell tables, the winner's bit mask and the copy-out scan stay in LDS.
-// A fixed number of persistent workgroups walks the pairs, so the workspace does not grow with the batch.
+// At most one persistent workgroup per CU walks the pairs, so the workspace does not grow with the batch.
 // This path is about coverage, not speed: it is latency-bound on L2 atomics.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
