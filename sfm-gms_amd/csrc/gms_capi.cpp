@@ -78,6 +78,7 @@ struct gms_ctx {
     hipStream_t stream = nullptr;
     std::mutex mu;  // serialises the one-shot path's scratch buffers
     DevBuf kp, foff, wh, pts, pair, matches, out, result, aux, big_ws;
+    int n_cus = 256;  // multiProcessorCount of the device
 };
 
 extern "C" {
@@ -123,6 +124,8 @@ int gms_ctx_create(int device, gms_ctx** out_ctx)
         return GMS_ERR_HIP;
     }
     c->stream = c->own_stream;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) c->n_cus = prop.multiProcessorCount;
     *out_ctx = c;
     return GMS_OK;
 }
