@@ -488,49 +488,45 @@ filter_kernel(FilterParams p)
                     }
                     // round 1: "+1" where the bucket already holds the right cell, CAS into its first empty slot
                     // where it does not. Slots of a bucket fill lowest-first, so the occupied slots are a prefix.
+                    // (A match that is not binned under this grid type was pointed at the trash bucket above and
+                    // simply plays there: nothing it does lands in the table, and d = 0 ends its general walk at once.)
                     uint32_t o_add[kChunk], o_cas[kChunk];
-                    uint32_t found = 0, canput = 0;
+                    bool fnd[kChunk], put[kChunk], pend[kChunk];
 #pragma unroll
                     for (int c = 0; c < kChunk; ++c) {
-                        const bool valid = (d[k0 + c] & 0xFFFFu) != 0;
                         const uint32_t kr = (code[k0 + c] & kRMask) << kSlotRShift;
                         const int f = bucket_find(v[c], kr);
                         const int e = bucket_first_empty(v[c]);
-                        const bool fnd = valid && f >= 0;
-                        const bool put = valid && f < 0 && e >= 0;
-                        if (valid && f < 0 && e < 0) pending |= 1u << (k0 + c);  // full bucket: leftovers
+                        fnd[c] = f >= 0;
+                        put[c] = f < 0 && e >= 0;
+                        pend[c] = f < 0 && e < 0;  // full bucket: leftovers
                         slot[c] += (uint32_t)(f >= 0 ? f : (e & 12));
-                        found |= (fnd ? 1u : 0u) << c;
-                        canput |= (put ? 1u : 0u) << c;
-                        o_add[c] = atomicAdd(lds_at(tab, fnd ? slot[c] : trash_add), 1u);
-                        o_cas[c] = atomicCAS(lds_at(tab, put ? slot[c] : trash_add), kEmpty, kr | 1u);
+                        o_add[c] = atomicAdd(lds_at(tab, fnd[c] ? slot[c] : trash_add), 1u);
+                        o_cas[c] = atomicCAS(lds_at(tab, put[c] ? slot[c] : trash_add), kEmpty, kr | 1u);
                     }
                     __builtin_amdgcn_sched_barrier(0);  // all of the chunk's atomics are issued before any result is read
                     // round 2: a lost CAS whose winner was the same right cell (common: the true matches of a
                     // cell arrive together) becomes "+1" on that slot; any other winner sends us to the leftovers
                     uint32_t o_again[kChunk];
-                    uint32_t won = 0, same = 0;
+                    bool won[kChunk];
 #pragma unroll
                     for (int c = 0; c < kChunk; ++c) {
                         const uint32_t kr = (code[k0 + c] & kRMask) << kSlotRShift;
-                        const bool put = (canput >> c) & 1u;
-                        const bool w = put && o_cas[c] == kEmpty;
-                        const bool sm = put && !w && (o_cas[c] ^ kr) <= kSlotCountMask;
-                        if (put && !w && !sm) pending |= 1u << (k0 + c);
-                        won |= (w ? 1u : 0u) << c;
-                        same |= (sm ? 1u : 0u) << c;
+                        won[c] = put[c] && o_cas[c] == kEmpty;
+                        const bool sm = put[c] && !won[c] && (o_cas[c] ^ kr) <= kSlotCountMask;
+                        pend[c] = pend[c] || (put[c] && !won[c] && !sm);
                         o_again[c] = atomicAdd(lds_at(tab, sm ? slot[c] : trash_add), 1u);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                     // the count this match produced, folded into the cell's running arg-max
 #pragma unroll
                     for (int c = 0; c < kChunk; ++c) {
-                        const bool fnd = (found >> c) & 1u, w = (won >> c) & 1u, sm = (same >> c) & 1u;
-                        const uint32_t count = fnd ? (o_add[c] & kSlotCountMask) + 1u
-                                                   : (w ? 1u : (o_again[c] & kSlotCountMask) + 1u);
+                        const uint32_t count = fnd[c] ? (o_add[c] & kSlotCountMask) + 1u
+                                                      : (won[c] ? 1u : (o_again[c] & kSlotCountMask) + 1u);
                         const uint32_t key = ~((count << 11) | (2047u - (code[k0 + c] & kRMask)));
                         const uint32_t hdr = (d[k0 + c] >> 16) << 4;
-                        atomicMin(lds_at(tab, (fnd || w || sm) ? hdr : trash_min), key);
+                        atomicMin(lds_at(tab, (pend[c] || (d[k0 + c] & 0xFFFFu) == 0) ? trash_min : hdr), key);
+                        pending |= pend[c] ? (1u << (k0 + c)) : 0u;
                     }
                 }
                 GMS_STAMP(3);  // insert: first-probe rounds
