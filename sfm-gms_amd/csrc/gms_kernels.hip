@@ -606,11 +606,11 @@ filter_kernel(FilterParams p)
 #pragma unroll
                         for (int c = 0; c < 4; ++c) {
                             const uint32_t kr = rq[c] << kSlotRShift;
-                            if (bucket_find(v[c], kr) >= 0) {
-                                score += bucket_count(v[c], kr);
-                            } else if (bucket_first_empty(v[c]) < 0) {  // full bucket without the key: walk on
-                                score += region_lookup_general(tab, dn[c], rq[c]);
-                            }
+                            const uint32_t cnt = bucket_count(v[c], kr);  // 0 when the bucket does not hold the right cell
+                            score += cnt;
+                            // slots fill lowest-first: the bucket is full iff its last slot is taken. Full and
+                            // without the key: the key may sit further along the region
+                            if (cnt == 0 && v[c].w != kEmpty) score += region_lookup_general(tab, dn[c], rq[c]);
                         }
                     }
                     if (!ROT) {
