@@ -38,12 +38,6 @@
 
 namespace gms {
 
-// mRotationPatterns - 1 (DLL .rdata 0x18012f520).
-__constant__ int8_t c_rot[8][9] = {
-    {0, 1, 2, 3, 4, 5, 6, 7, 8}, {3, 0, 1, 6, 4, 2, 7, 8, 5}, {6, 3, 0, 7, 4, 1, 8, 5, 2},
-    {7, 6, 3, 8, 4, 0, 5, 2, 1}, {8, 7, 6, 5, 4, 3, 2, 1, 0}, {5, 8, 7, 2, 4, 6, 1, 0, 3},
-    {2, 5, 8, 1, 4, 7, 0, 3, 6}, {1, 2, 5, 0, 4, 8, 3, 6, 7}};
-
 constexpr uint32_t kEmpty = 0xFFFFFFFFu;
 
 // Diagnostic build only (-DGMS_PHASE_TIMING, libgms_hip_diag.so): thread 0 of each workgroup sums the
@@ -191,6 +185,14 @@ __device__ __forceinline__ bool threshold_rejects(uint32_t T, uint32_t n, uint32
 }
 // factor ranges where factor^2 neither overflows nor loses precision to underflow
 __device__ __forceinline__ bool threshold_fast_ok(double factor) { return factor > 1e-100 && factor < 1e100; }
+
+// mRotationPatterns without a table: the eight outer positions of the 3 x 3 block form a ring
+// (0,1,2,5,8,7,6,3 clockwise); pattern rot sends the position with ring index u to the one with ring index
+// (u - rot) mod 8, the centre stays (checked against the DLL's table in tests/test_oracle_pins.py). A per-lane
+// rotation would otherwise index constant memory per lane, which the compiler serialises over the distinct values.
+__device__ __forceinline__ int rotated_position(int rot, int u) { return (int)((0x36785210u >> (((u - rot) & 7) << 2)) & 15u); }
+__device__ __forceinline__ int position_dx(int q) { return (int)((0x24924u >> (q << 1)) & 3u) - 1; }  // q % 3 - 1
+__device__ __forceinline__ int position_dy(int q) { return (int)((0x2a540u >> (q << 1)) & 3u) - 1; }  // q / 3 - 1
 
 // lane ^ 1 exchange on the VALU (DPP quad_perm [1,0,3,2]), no LDS round trip
 __device__ __forceinline__ uint32_t dpp_xor1(uint32_t x)
@@ -573,11 +575,12 @@ filter_kernel(FilterParams p)
                             } else {
                                 k = half ? c + 5 : c;  // lane 0: neighbours 0..3, lane 1: neighbours 5..8
                             }
-                            const int q = ROT ? c_rot[rot][k] : k;
                             int ldx, ldy, rdx, rdy;
                             if (ROT) {
-                                ldx = (k % 3) - 1; ldy = (k / 3) - 1;  // compile-time
-                                rdx = (q % 3) - 1; rdy = (q / 3) - 1;
+                                constexpr int kRingIndex[9] = {0, 1, 2, 7, -1, 3, 6, 5, 4};  // position -> ring index
+                                const int q = rotated_position(rot, kRingIndex[k]);          // k is a compile-time constant here
+                                ldx = (k % 3) - 1; ldy = (k / 3) - 1;
+                                rdx = position_dx(q); rdy = position_dy(q);
                             } else {
                                 // k = c or c + 5, both compile-time: select by lane parity
                                 ldx = half ? ((c + 5) % 3) - 1 : (c % 3) - 1;

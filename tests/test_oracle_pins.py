@@ -41,6 +41,20 @@ def test_rotation_patterns_are_rotations_of_the_ring(oracle):
         assert [pat[rot][ring[(k + rot) % 8]] for k in range(8)] == [pat[0][ring[k]] for k in range(8)]
 
 
+def test_rotation_patterns_arithmetic_form(oracle):
+    """The closed form the HIP kernel uses instead of the table (gms_kernels.hip: rotated_position)."""
+    import ctypes as C
+    pat = np.array((C.c_int * 72).in_dll(oracle.load(), "gms_ref_rotation_patterns")).reshape(8, 9)
+    ring_index = [0, 1, 2, 7, -1, 3, 6, 5, 4]
+    for rot in range(8):
+        for k in range(9):
+            if k == 4:
+                continue
+            q = (0x36785210 >> ((((ring_index[k] - rot) & 7)) << 2)) & 15
+            assert q == pat[rot][k] - 1
+            assert ((0x24924 >> (q << 1)) & 3) - 1 == q % 3 - 1 and ((0x2a540 >> (q << 1)) & 3) - 1 == q // 3 - 1
+
+
 def test_right_grids(oracle):
     import ctypes as C
     lib = oracle.load()
