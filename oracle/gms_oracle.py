@@ -1,7 +1,7 @@
 """oracle/gms_oracle.py -- TEST INFRASTRUCTURE, NOT PRODUCT.
 
-ctypes loader for oracle/libgms_oracle.so (the C restatement of the reference's matchGMS; parity
-unpinned -- see gms_ref.c). Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg
+ctypes loader for oracle/libgms_oracle.so (the C restatement of the reference's matchGMS; parity pinned
+only in part -- see gms_ref.c). Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg
 may import this module."""
 import ctypes as C
 import os

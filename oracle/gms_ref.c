@@ -6,13 +6,20 @@
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this; the product
  * path (sfm-gms_amd/csrc) never links, calls or falls back to it.
  *
- * PARITY UNPINNED: the reference holds no tests, golden vectors or recorded outputs for this path
- *  and its implementation exists only as a Windows PE32+ DLL that cannot
- * be loaded here. This file follows the DLL's disassembly address by address (cited per function,
- * "DLL@0x..." = virtual address in that DLL, image base 0x180000000) and keeps the reference's
- * dense 400 x N_right motion matrix and loop order on purpose, so that it is an obviously faithful,
- * structurally independent checker for the sparse GPU formulation. The constant tables below are
- * checked byte for byte against the DLL by tests/test_oracle_pins.py when /root/reference exists.
+ * PARITY: PINNED ONLY IN PART. The reference holds no tests, golden vectors or recorded outputs for this path
+ *  and its implementation exists only as a Windows PE32+ DLL whose imports
+ * (opencv_core452.dll, ...) are not vendored, so the function as a whole cannot be run here: end-to-end
+ * parity is UNPINNED. What is pinned against the reference itself:
+ *   - grid_index_left / grid_index_right (the float -> cell arithmetic, where bit-exactness is decided): the two
+ *     corresponding leaf functions of the DLL were executed here on 6.7k points and their outputs are committed as
+ *     tests/golden/refdll_grid_index.npz (generator: tests/golden/refdll_runner.c, make_refdll_vectors.py);
+ *     tests/test_oracle_pins.py requires this file to reproduce every integer;
+ *   - the rotation-pattern table, the scale-ratio table and the 0.5 constant: compared byte for byte with the DLL
+ *     by tests/test_oracle_pins.py when /root/reference exists.
+ * Everything else follows the DLL's disassembly address by address (cited per function, "DLL@0x..." = virtual
+ * address in that DLL, image base 0x180000000) and keeps the reference's dense 400 x N_right motion matrix and
+ * loop order on purpose, so that it is an obviously faithful, structurally independent checker for the sparse
+ * GPU formulation; a second restatement (gms_ref_sparse.py) must agree with it bit for bit.
  *
  * Build: gcc -O2 -ffp-contract=off -fno-fast-math (x86-64 SSE2: float ops are true fp32, no x87).
  */

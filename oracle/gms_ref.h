@@ -1,5 +1,5 @@
 /*
- * oracle/gms_ref.h -- TEST INFRASTRUCTURE, NOT PRODUCT (see gms_ref.c header; parity unpinned).
+ * oracle/gms_ref.h -- TEST INFRASTRUCTURE, NOT PRODUCT (see gms_ref.c header: parity pinned only in part).
  * CPU restatement of the reference's cv::xfeatures2d::matchGMS (opencv_xfeatures2d452.dll).
  */
 #ifndef GMS_REF_H

@@ -1,4 +1,4 @@
-"""oracle/gms_ref_sparse.py -- TEST INFRASTRUCTURE, NOT PRODUCT (parity unpinned, see gms_ref.c).
+"""oracle/gms_ref_sparse.py -- TEST INFRASTRUCTURE, NOT PRODUCT (parity pinned only in part, see gms_ref.c).
 
 A second, independently structured restatement of the reference's cv::xfeatures2d::matchGMS
 (SfM-GMS/bin/opencv_xfeatures2d452.dll, GMSMatcher, DLL@0x180046900..0x1800491ec), used only to

@@ -1,0 +1,75 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/refdll_grid_index.npz: (nx, ny) -> cell indices AS RETURNED BY THE REFERENCE'S OWN BINARY.
+
+refdll_runner.c maps SfM-GMS/bin/opencv_xfeatures2d452.dll and calls its GMSMatcher::getGridIndexLeft /
+getGridIndexRight (two leaf functions) on the inputs built here. Needs /root/reference; run in the build container:
+    python tests/golden/make_refdll_vectors.py
+The fixture pins the float -> cell mapping (the bit-exactness-critical arithmetic) of oracle/gms_ref.c to the reference."""
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+DLL = "/root/reference/SfM-GMS/bin/opencv_xfeatures2d452.dll"
+
+
+def inputs():
+    rng = np.random.default_rng(0x5F3759DF)
+    f32 = np.float32
+    pts = [np.stack([rng.uniform(0, 1, 3000), rng.uniform(0, 1, 3000)], axis=1)]
+    # pixel coordinates divided by real image extents (what normalizePoints produces)
+    for w, h in ((1920, 1080), (640, 480), (3840, 2160), (450, 375), (2016, 1512), (1390, 1110)):
+        x = rng.uniform(0, w, 400).astype(f32)
+        y = rng.uniform(0, h, 400).astype(f32)
+        x[:40] = np.rint(x[:40])  # integer pixels
+        pts.append(np.stack([x / f32(w), y / f32(h)], axis=1))
+        # pixels whose products land on / next to cell and half-cell borders
+        k = np.arange(0, 41, dtype=np.float64)
+        bx = (k * w / 40.0).astype(f32)
+        by = (k * h / 40.0).astype(f32)
+        for d in (-1, 0, 1):
+            xx = bx.copy()
+            yy = by.copy()
+            for _ in range(abs(d)):
+                xx = np.nextafter(xx, f32(np.inf) if d > 0 else f32(-np.inf))
+                yy = np.nextafter(yy, f32(np.inf) if d > 0 else f32(-np.inf))
+            keep = (xx >= 0) & (xx < w) & (yy >= 0) & (yy < h)
+            pts.append(np.stack([xx[keep] / f32(w), yy[keep] / f32(h)], axis=1))
+    # normalised values right at k/20, k/40 and their neighbours in fp32, all four combinations with a random partner
+    k = np.arange(0, 40)
+    edge = np.concatenate([(k / 40.0).astype(f32)] + [np.nextafter((k / 40.0).astype(f32), f32(s)) for s in (0, 1)]
+                          + [np.nextafter(np.nextafter((k / 40.0).astype(f32), f32(s)), f32(s)) for s in (0, 1)])
+    edge = edge[(edge >= 0) & (edge < 1)]
+    other = rng.uniform(0, 1, len(edge)).astype(f32)
+    pts += [np.stack([edge, other], axis=1), np.stack([other, edge], axis=1), np.stack([edge, edge[::-1]], axis=1)]
+    pts.append(np.array([[0, 0], [0.99999994, 0.99999994], [1e-30, 1e-30], [0.5, 0.5], [0.975, 0.975], [0.97500002, 0.025]]))
+    a = np.concatenate([p.astype(f32) for p in pts])
+    a = a[(a[:, 0] >= 0) & (a[:, 0] < 1) & (a[:, 1] >= 0) & (a[:, 1] < 1)]
+    return np.ascontiguousarray(a, dtype=f32)
+
+
+def main():
+    if not os.path.exists(DLL):
+        sys.exit("reference DLL not present: this generator runs only where /root/reference is mounted")
+    pts = inputs()
+    with tempfile.TemporaryDirectory() as tmp:
+        exe = os.path.join(tmp, "refdll_runner")
+        subprocess.check_call(["gcc", "-O1", "-o", exe, os.path.join(HERE, "refdll_runner.c")])
+        fin, fout = os.path.join(tmp, "in.bin"), os.path.join(tmp, "out.bin")
+        with open(fin, "wb") as f:
+            f.write(np.int32(len(pts)).tobytes())
+            f.write(pts.tobytes())
+        subprocess.check_call([exe, DLL, fin, fout])
+        res = np.fromfile(fout, dtype=np.int32).reshape(-1, 9)
+    assert len(res) == len(pts)
+    np.savez_compressed(os.path.join(HERE, "refdll_grid_index.npz"), nxy=pts, left=res[:, :4], right=res[:, 4:],
+                        right_dims=np.array([20, 10, 14, 28, 40], dtype=np.int32))
+    print(len(pts), "points;", "left range", res[:, :4].min(), res[:, :4].max(), "; file",
+          os.path.getsize(os.path.join(HERE, "refdll_grid_index.npz")), "bytes")
+
+
+if __name__ == "__main__":
+    main()

@@ -111,3 +111,22 @@ def test_threshold_is_strict_greater_in_fp64(oracle):
     for _ in range(2000):
         t, n, s = int(rng.integers(0, 5000)), int(rng.integers(1, 10)), int(rng.integers(0, 200))
         assert T(t, n, s, 6.0) == int(math.sqrt(t / n) * 6.0 > s)
+
+
+def test_cell_mapping_matches_the_reference_binary(oracle):
+    """tests/golden/refdll_grid_index.npz holds what the reference's OWN DLL code returned for 6.7k points
+    (GMSMatcher::getGridIndexLeft / getGridIndexRight executed out of opencv_xfeatures2d452.dll by
+    tests/golden/refdll_runner.c). Both restatements must reproduce every integer."""
+    import gms_ref_sparse
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "refdll_grid_index.npz"))
+    nxy, left, right, dims = z["nxy"], z["left"], z["right"], z["right_dims"]
+    assert len(nxy) > 6000 and left.min() == -1 and left.max() == 399
+    lib = oracle.load()
+    for i in range(len(nxy)):
+        nx, ny = float(nxy[i, 0]), float(nxy[i, 1])
+        assert [lib.gms_ref_grid_index_left(nx, ny, t) for t in (1, 2, 3, 4)] == left[i].tolist(), (i, nx, ny)
+        assert [lib.gms_ref_grid_index_right(nx, ny, int(d), int(d)) for d in dims] == right[i].tolist(), (i, nx, ny)
+    for t in (1, 2, 3, 4):
+        assert np.array_equal(gms_ref_sparse._left_cells(nxy, t), left[:, t - 1])
+    for k, d in enumerate(dims):
+        assert np.array_equal(gms_ref_sparse._right_cells(nxy, int(d), int(d)), right[:, k])
