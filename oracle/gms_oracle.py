@@ -48,6 +48,8 @@ def load():
     lib.gms_ref_normalize.restype = C.c_float
     lib.gms_ref_threshold_rejects.argtypes = [i32, i32, i32, dbl]
     lib.gms_ref_threshold_rejects.restype = i32
+    lib.gms_ref_assign_pairs.argtypes = [vp, vp, vp, i32, i32, i32, vp, vp, vp]
+    lib.gms_ref_assign_pairs.restype = i32
     lib.gms_ref_scale_ratio.argtypes = [i32]
     lib.gms_ref_scale_ratio.restype = dbl
     _lib = lib
@@ -89,3 +91,18 @@ def batch(kp_all, frame_off, wh, pairs, matches, with_rotation=False, with_scale
                                int(bool(with_scale)), float(threshold_factor), out.ctypes.data,
                                res.ctypes.data, mask.ctypes.data, int(n_threads))
     return failed, out[: len(mt)], res[: len(pairs)], mask[: len(mt)]
+
+
+def assign_pairs(p1, p2, matches, wr, hr):
+    """assignMatchPairs for grid types 1..4 on normalised points: (rc, pairs[4][m][2], nleft[4][400], motion[4][400][wr*hr])."""
+    lib = load()
+    p1 = np.ascontiguousarray(p1, dtype=np.float32)
+    p2 = np.ascontiguousarray(p2, dtype=np.float32)
+    mt = np.ascontiguousarray(matches, dtype=np.int32)
+    m = len(mt)
+    pairs = np.zeros((4, m, 2), dtype=np.int32)
+    nleft = np.zeros((4, 400), dtype=np.int32)
+    motion = np.zeros((4, 400, wr * hr), dtype=np.int32)
+    rc = lib.gms_ref_assign_pairs(p1.ctypes.data, p2.ctypes.data, mt.ctypes.data, m, int(wr), int(hr),
+                                  pairs.ctypes.data, nleft.ctypes.data, motion.ctypes.data)
+    return rc, pairs, nleft, motion

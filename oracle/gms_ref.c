@@ -14,6 +14,10 @@
  *     corresponding leaf functions of the DLL were executed here on 6.7k points and their outputs are committed as
  *     tests/golden/refdll_grid_index.npz (generator: tests/golden/refdll_runner.c, make_refdll_vectors.py);
  *     tests/test_oracle_pins.py requires this file to reproduce every integer;
+ *   - assign_match_pairs (binning: the skip rule, the right cell cached by grid type 1, motion[l][r]++ and the
+ *     per-cell counts): GMSMatcher::assignMatchPairs was executed out of the DLL (its only call is
+ *     getGridIndexLeft) for grid types 1..4 on three right grids; tests/golden/refdll_assign_pairs.npz holds
+ *     what it wrote, and gms_ref_assign_pairs() must reproduce it;
  *   - the rotation-pattern table, the scale-ratio table and the 0.5 constant: compared byte for byte with the DLL
  *     by tests/test_oracle_pins.py when /root/reference exists.
  * Everything else follows the DLL's disassembly address by address (cited per function, "DLL@0x..." = virtual
@@ -392,4 +396,47 @@ int gms_ref_threshold_rejects(int T, int n, int score, double factor)
 {
     double thresh = sqrt((double)T / (double)n) * factor;
     return thresh > (double)score;
+}
+
+/* assignMatchPairs for grid types 1..4 in sequence, exactly as run() drives it (motion and nLeft zeroed before each
+ * type, the right cell cached by type 1), on ALREADY NORMALISED points. Outputs per grid type t (0-based):
+ * pairs[t][m][2] = mvMatchPairs, nleft[t][400], motion[t][400 * wr * hr] (dense). Returns 0, or -1 on allocation
+ * failure / -2 if a right cell leaves the grid. Pinned against the DLL's own assignMatchPairs (DLL@0x180047880). */
+int gms_ref_assign_pairs(const float* p1, const float* p2, const int* matches, int m, int wr, int hr,
+                         int* pairs, int* nleft, int* motion)
+{
+    gms_ref_state st;
+    memset(&st, 0, sizeof st);
+    st.wl = st.hl = 20;
+    st.n_left = 400;
+    st.wr = wr;
+    st.hr = hr;
+    st.n_right = wr * hr;
+    st.n_matches = m;
+    st.p1 = (float*)p1;
+    st.p2 = (float*)p2;
+    gms_dmatch* dm = (gms_dmatch*)calloc((size_t)(m ? m : 1), sizeof(gms_dmatch));
+    st.pair_first = (int*)calloc((size_t)(m ? m : 1), sizeof(int));
+    st.pair_second = (int*)calloc((size_t)(m ? m : 1), sizeof(int));
+    if (!dm || !st.pair_first || !st.pair_second) return -1;
+    for (int i = 0; i < m; i++) {
+        dm[i].queryIdx = matches[2 * i];
+        dm[i].trainIdx = matches[2 * i + 1];
+    }
+    st.matches = dm;
+    for (int t = 1; t <= 4; t++) {
+        st.motion = motion + (size_t)(t - 1) * 400 * st.n_right;
+        st.n_per_cell_left = nleft + (t - 1) * 400;
+        memset(st.motion, 0, sizeof(int) * 400 * (size_t)st.n_right);
+        memset(st.n_per_cell_left, 0, sizeof(int) * 400);
+        assign_match_pairs(&st, t);
+        for (int i = 0; i < m; i++) {
+            pairs[((size_t)(t - 1) * m + i) * 2 + 0] = st.pair_first[i];
+            pairs[((size_t)(t - 1) * m + i) * 2 + 1] = st.pair_second[i];
+        }
+    }
+    free(dm);
+    free(st.pair_first);
+    free(st.pair_second);
+    return st.domain_error ? -2 : 0;
 }

@@ -27,6 +27,9 @@ void  gms_ref_right_grid(int scale, int* wr, int* hr);                /* DLL@0x1
 float gms_ref_normalize(float v, int extent);                         /* DLL@0x180048420 */
 int   gms_ref_threshold_rejects(int T, int n, int score, double factor); /* DLL@0x180049171 */
 
+int   gms_ref_assign_pairs(const float* p1, const float* p2, const int* matches, int m, int wr, int hr,
+                           int* pairs, int* nleft, int* motion);                 /* DLL@0x180047880 */
+
 /* gms_ref_mt.c: the same call over a batch of pairs, one pair per thread at a time (the algorithm
  * itself stays serial, as in the reference). Frames are (kp pointer, n, w, h) tables. Returns the
  * number of pairs that failed. Used only by bench.py's cpu_baseline leg and tests. */

@@ -51,6 +51,44 @@ def inputs():
     return np.ascontiguousarray(a, dtype=f32)
 
 
+def assign_fixture():
+    """GMSMatcher::assignMatchPairs run out of the DLL for grid types 1..4 on two right grids: the pairs it records,
+    the per-cell counts and the motion matrix (kept as its non-zeros)."""
+    rng = np.random.default_rng(0x5F3759DF ^ 2)
+    out = {}
+    for tag, (wr, n1, n2, m) in {"g20": (20, 1200, 1100, 1500), "g14": (14, 900, 900, 1000), "g40": (40, 700, 800, 900)}.items():
+        p1 = np.stack([rng.uniform(0, 1, n1), rng.uniform(0, 1, n1)], axis=1).astype(np.float32)
+        p1[: n1 // 4] = (np.round(p1[: n1 // 4] * 40) / 40).astype(np.float32).clip(0, 0.999)  # on cell / half-cell borders
+        p1[n1 // 4: n1 // 3, 0] = rng.uniform(0.95, 1, n1 // 3 - n1 // 4).astype(np.float32)   # the last half cell
+        p2 = np.stack([rng.uniform(0, 1, n2), rng.uniform(0, 1, n2)], axis=1).astype(np.float32)
+        p2 = np.minimum(p2, np.float32(0.99999))
+        mt = np.stack([rng.integers(0, n1, m), rng.integers(0, n2, m)], axis=1).astype(np.int32)
+        mt[: m // 2, 1] = np.minimum(mt[: m // 2, 0], n2 - 1)  # repeated partners
+        with tempfile.TemporaryDirectory() as tmp:
+            exe = os.path.join(tmp, "refdll_runner")
+            subprocess.check_call(["gcc", "-O1", "-o", exe, os.path.join(HERE, "refdll_runner.c")])
+            fin, fout = os.path.join(tmp, "in.bin"), os.path.join(tmp, "out.bin")
+            with open(fin, "wb") as f:
+                f.write(np.array([wr, wr, n1, n2, m], dtype=np.int32).tobytes())
+                f.write(p1.tobytes()); f.write(p2.tobytes()); f.write(mt.tobytes())
+            subprocess.check_call([exe, DLL, fin, fout, "assign"])
+            raw = np.fromfile(fout, dtype=np.int32)
+        per = 2 * m + 400 + 400 * wr * wr
+        assert len(raw) == 4 * per
+        out[tag + "_dims"] = np.array([wr, n1, n2, m], dtype=np.int32)
+        out[tag + "_p1"], out[tag + "_p2"], out[tag + "_matches"] = p1, p2, mt
+        for t in range(4):
+            blk = raw[t * per:(t + 1) * per]
+            out[f"{tag}_pairs{t + 1}"] = blk[: 2 * m].reshape(m, 2).copy()
+            out[f"{tag}_nleft{t + 1}"] = blk[2 * m: 2 * m + 400].copy()
+            motion = blk[2 * m + 400:].reshape(400, wr * wr)
+            l, r = np.nonzero(motion)
+            out[f"{tag}_motion{t + 1}"] = np.stack([l, r, motion[l, r]], axis=1).astype(np.int32)
+            assert motion.sum() == blk[2 * m: 2 * m + 400].sum()
+    np.savez_compressed(os.path.join(HERE, "refdll_assign_pairs.npz"), **out)
+    print("assign fixture", os.path.getsize(os.path.join(HERE, "refdll_assign_pairs.npz")), "bytes")
+
+
 def main():
     if not os.path.exists(DLL):
         sys.exit("reference DLL not present: this generator runs only where /root/reference is mounted")
@@ -67,6 +105,7 @@ def main():
     assert len(res) == len(pts)
     np.savez_compressed(os.path.join(HERE, "refdll_grid_index.npz"), nxy=pts, left=res[:, :4], right=res[:, 4:],
                         right_dims=np.array([20, 10, 14, 28, 40], dtype=np.int32))
+    assign_fixture()
     print(len(pts), "points;", "left range", res[:, :4].min(), res[:, :4].max(), "; file",
           os.path.getsize(os.path.join(HERE, "refdll_grid_index.npz")), "bytes")
 

@@ -12,6 +12,15 @@
  * usage: refdll_runner <dll> <in.bin> <out.bin>
  *   in.bin : int32 n, then n x (float nx, float ny)
  *   out.bin: n x 9 int32: left cell for grid types 1..4, right cell for right grids 20, 10, 14, 28, 40
+ *
+ * usage: refdll_runner <dll> <in.bin> <out.bin> assign
+ *   A third function, GMSMatcher::assignMatchPairs (RVA 0x47880; its only call is getGridIndexLeft), driven for grid
+ *   types 1..4 the way GMSMatcher::run does (motion matrix and per-cell counts zeroed before each type). The object it
+ *   works on is laid out by hand from the disassembly: mvP1.begin @+0x00, mvP2.begin @+0x18, mvMatches.begin @+0x30,
+ *   mNumberMatches @+0x48, grid sizes @+0x50..0x5c, Mat data pointer @+0x78, pointer to the row step @+0xb0,
+ *   mNumberPointsInPerCellLeft.begin @+0xc8, mvMatchPairs.begin @+0xf8.
+ *   in.bin : int32 wr, hr, n1, n2, m; n1 x float2 (normalised), n2 x float2, m x (int32 query, int32 train)
+ *   out.bin: per grid type: m x 2 int32 (mvMatchPairs), 400 int32 (per-cell counts), 400 * wr * hr int32 (motion)
  */
 #define _GNU_SOURCE
 #include <stdint.h>
@@ -28,7 +37,7 @@ static uint16_t rd16(const unsigned char* p) { uint16_t v; memcpy(&v, p, 2); ret
 
 int main(int argc, char** argv)
 {
-    if (argc != 4) return 2;
+    if (argc != 4 && argc != 5) return 2;
     FILE* f = fopen(argv[1], "rb");
     if (!f) return 3;
     fseek(f, 0, SEEK_END);
@@ -54,6 +63,51 @@ int main(int argc, char** argv)
         const uint32_t n = rsize < vsize ? rsize : vsize;
         if ((uint64_t)va + n > size_image || (uint64_t)rptr + n > (uint64_t)fsz) return 4;
         memcpy(img + va, file + rptr, n);
+    }
+    typedef void(__attribute__((ms_abi)) * assign_fn)(void* self, int grid_type);
+    if (argc == 5 && strcmp(argv[4], "assign") == 0) {
+        assign_fn assign = (assign_fn)(img + 0x47880);
+        FILE* in = fopen(argv[2], "rb");
+        FILE* out = fopen(argv[3], "wb");
+        if (!in || !out) return 6;
+        int32_t hdr[5];
+        if (fread(hdr, 4, 5, in) != 5) return 6;
+        const int wr = hdr[0], hr = hdr[1], n1 = hdr[2], n2 = hdr[3], m = hdr[4];
+        float* p1 = malloc(sizeof(float) * 2 * (size_t)n1);
+        float* p2 = malloc(sizeof(float) * 2 * (size_t)n2);
+        int32_t* mt = malloc(sizeof(int32_t) * 2 * (size_t)m);
+        int32_t* mp = calloc(2 * (size_t)m, sizeof(int32_t));
+        int32_t* motion = malloc(sizeof(int32_t) * 400 * (size_t)wr * hr);
+        int32_t nleft[400];
+        if (fread(p1, 8, (size_t)n1, in) != (size_t)n1 || fread(p2, 8, (size_t)n2, in) != (size_t)n2 ||
+            fread(mt, 8, (size_t)m, in) != (size_t)m)
+            return 6;
+        uint64_t step = (uint64_t)wr * hr * 4;  /* bytes per motion row */
+        unsigned char self[0x200];
+        memset(self, 0, sizeof self);
+        *(void**)(self + 0x00) = p1;
+        *(void**)(self + 0x18) = p2;
+        *(void**)(self + 0x30) = mt;
+        *(uint64_t*)(self + 0x48) = (uint64_t)m;
+        *(int32_t*)(self + 0x50) = 20;
+        *(int32_t*)(self + 0x54) = 20;
+        *(int32_t*)(self + 0x58) = wr;
+        *(int32_t*)(self + 0x5c) = hr;
+        *(void**)(self + 0x78) = motion;
+        *(void**)(self + 0xb0) = &step;
+        *(void**)(self + 0xc8) = nleft;
+        *(void**)(self + 0xf8) = mp;
+        for (int t = 1; t <= 4; t++) {
+            memset(motion, 0, sizeof(int32_t) * 400 * (size_t)wr * hr);
+            memset(nleft, 0, sizeof nleft);
+            assign(self, t);
+            fwrite(mp, 8, (size_t)m, out);
+            fwrite(nleft, 4, 400, out);
+            fwrite(motion, 4, 400 * (size_t)wr * hr, out);
+        }
+        fclose(in);
+        fclose(out);
+        return 0;
     }
     left_fn get_left = (left_fn)(img + 0x47bc0);
     right_fn get_right = (right_fn)(img + 0x47d60);

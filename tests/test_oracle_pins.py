@@ -130,3 +130,23 @@ def test_cell_mapping_matches_the_reference_binary(oracle):
         assert np.array_equal(gms_ref_sparse._left_cells(nxy, t), left[:, t - 1])
     for k, d in enumerate(dims):
         assert np.array_equal(gms_ref_sparse._right_cells(nxy, int(d), int(d)), right[:, k])
+
+
+def test_binning_matches_the_reference_binary(oracle):
+    """tests/golden/refdll_assign_pairs.npz: GMSMatcher::assignMatchPairs executed out of the reference DLL for grid
+    types 1..4 (driven as run() drives it) on three right grids -- the (left cell, right cell) it records per match,
+    the per-cell counts and every non-zero of the motion matrix. The oracle's assign_match_pairs must agree."""
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "refdll_assign_pairs.npz"))
+    for tag in ("g20", "g14", "g40"):
+        wr, n1, n2, m = (int(v) for v in z[tag + "_dims"])
+        rc, pairs, nleft, motion = oracle.assign_pairs(z[tag + "_p1"], z[tag + "_p2"], z[tag + "_matches"], wr, wr)
+        assert rc == 0
+        for t in range(4):
+            assert np.array_equal(pairs[t], z[f"{tag}_pairs{t + 1}"]), (tag, t)
+            assert np.array_equal(nleft[t], z[f"{tag}_nleft{t + 1}"]), (tag, t)
+            l, r = np.nonzero(motion[t])
+            got = np.stack([l, r, motion[t][l, r]], axis=1).astype(np.int32)
+            assert np.array_equal(got, z[f"{tag}_motion{t + 1}"]), (tag, t)
+        # the shifted grid types really do reject the last half cell, and type 1's right cell is reused
+        assert (z[f"{tag}_pairs2"][:, 0] == -1).any() and (z[f"{tag}_pairs1"][:, 0] >= 0).all()
+        assert np.array_equal(z[f"{tag}_pairs1"][:, 1], z[f"{tag}_pairs4"][:, 1])
