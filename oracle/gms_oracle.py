@@ -50,6 +50,8 @@ def load():
     lib.gms_ref_threshold_rejects.restype = i32
     lib.gms_ref_assign_pairs.argtypes = [vp, vp, vp, i32, i32, i32, vp, vp, vp]
     lib.gms_ref_assign_pairs.restype = i32
+    lib.gms_ref_verify_cells.argtypes = [vp, vp, i32, i32, i32, dbl, vp]
+    lib.gms_ref_verify_cells.restype = i32
     lib.gms_ref_scale_ratio.argtypes = [i32]
     lib.gms_ref_scale_ratio.restype = dbl
     _lib = lib
@@ -106,3 +108,16 @@ def assign_pairs(p1, p2, matches, wr, hr):
     rc = lib.gms_ref_assign_pairs(p1.ctypes.data, p2.ctypes.data, mt.ctypes.data, m, int(wr), int(hr),
                                   pairs.ctypes.data, nleft.ctypes.data, motion.ctypes.data)
     return rc, pairs, nleft, motion
+
+
+def verify_cells(motion, nleft, wr, hr, rotation_type, factor=6.0):
+    """verifyCellPairs on a dense [400, wr*hr] motion matrix and [400] per-cell counts -> int32[400] cell pairs."""
+    lib = load()
+    motion = np.ascontiguousarray(motion, dtype=np.int32)
+    nleft = np.ascontiguousarray(nleft, dtype=np.int32)
+    assert motion.size == 400 * wr * hr and nleft.size == 400
+    out = np.empty(400, dtype=np.int32)
+    rc = lib.gms_ref_verify_cells(motion.ctypes.data, nleft.ctypes.data, int(wr), int(hr), int(rotation_type),
+                                  float(factor), out.ctypes.data)
+    assert rc == 0
+    return out

@@ -18,10 +18,15 @@
  *     per-cell counts): GMSMatcher::assignMatchPairs was executed out of the DLL (its only call is
  *     getGridIndexLeft) for grid types 1..4 on three right grids; tests/golden/refdll_assign_pairs.npz holds
  *     what it wrote, and gms_ref_assign_pairs() must reproduce it;
+ *   - verify_cell_pairs (arg-max, rotated 3 x 3 neighbour sums, sqrt(T / n) * factor, '>'): the body of
+ *     GMSMatcher::verifyCellPairs after its cv::sum(row) test (DLL@0x180048e12) was executed out of the DLL one
+ *     cell at a time for rotation types 1..8 on nine motion matrices (all five right grids, four factors);
+ *     tests/golden/refdll_verify_cells.npz holds mCellPairs and gms_ref_verify_cells() must reproduce it;
  *   - the rotation-pattern table, the scale-ratio table and the 0.5 constant: compared byte for byte with the DLL
  *     by tests/test_oracle_pins.py when /root/reference exists.
- * Everything else follows the DLL's disassembly address by address (cited per function, "DLL@0x..." = virtual
- * address in that DLL, image base 0x180000000) and keeps the reference's dense 400 x N_right motion matrix and
+ * Everything else (normalizePoints, getNB9, setScale, the loops of run and getInlierMask) follows the DLL's
+ * disassembly address by address (cited per function, "DLL@0x..." = virtual address in that DLL, image base
+ * 0x180000000) and keeps the reference's dense 400 x N_right motion matrix and
  * loop order on purpose, so that it is an obviously faithful, structurally independent checker for the sparse
  * GPU formulation; a second restatement (gms_ref_sparse.py) must agree with it bit for bit.
  *
@@ -439,4 +444,33 @@ int gms_ref_assign_pairs(const float* p1, const float* p2, const int* matches, i
     free(st.pair_first);
     free(st.pair_second);
     return st.domain_error ? -2 : 0;
+}
+
+/* verifyCellPairs for one rotation type on a given dense motion matrix and per-cell counts (what assignMatchPairs
+ * left behind): cell_pairs_out[400] as run() would see them (-1 empty, -2 rejected, else the right cell).
+ * Pinned against the body of the DLL's own verifyCellPairs (DLL@0x180048e12 onwards, see tests/golden/refdll_runner.c). */
+int gms_ref_verify_cells(const int* motion, const int* nleft, int wr, int hr, int rotation_type, double factor,
+                         int* cell_pairs_out)
+{
+    gms_ref_state st;
+    memset(&st, 0, sizeof st);
+    st.wl = st.hl = 20;
+    st.n_left = 400;
+    st.wr = wr;
+    st.hr = hr;
+    st.n_right = wr * hr;
+    st.threshold_factor = factor;
+    st.motion = (int*)motion;
+    st.n_per_cell_left = (int*)nleft;
+    st.cell_pairs = cell_pairs_out;
+    st.nb_left = (int*)malloc(sizeof(int) * 9 * 400);
+    st.nb_right = (int*)malloc(sizeof(int) * 9 * (size_t)st.n_right);
+    if (!st.nb_left || !st.nb_right) return -1;
+    init_neighbors(st.nb_left, 20, 20);
+    init_neighbors(st.nb_right, wr, hr);
+    for (int i = 0; i < 400; i++) cell_pairs_out[i] = -1;
+    verify_cell_pairs(&st, rotation_type);
+    free(st.nb_left);
+    free(st.nb_right);
+    return 0;
 }

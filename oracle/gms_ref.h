@@ -29,6 +29,8 @@ int   gms_ref_threshold_rejects(int T, int n, int score, double factor); /* DLL@
 
 int   gms_ref_assign_pairs(const float* p1, const float* p2, const int* matches, int m, int wr, int hr,
                            int* pairs, int* nleft, int* motion);                 /* DLL@0x180047880 */
+int   gms_ref_verify_cells(const int* motion, const int* nleft, int wr, int hr, int rotation_type, double factor,
+                           int* cell_pairs_out);                                  /* DLL@0x180048d10 */
 
 /* gms_ref_mt.c: the same call over a batch of pairs, one pair per thread at a time (the algorithm
  * itself stays serial, as in the reference). Frames are (kp pointer, n, w, h) tables. Returns the

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Generates tests/golden/refdll_grid_index.npz: (nx, ny) -> cell indices AS RETURNED BY THE REFERENCE'S OWN BINARY.
+"""Generates tests/golden/refdll_*.npz (grid index, assign pairs, verify cells). refdll_grid_index.npz: (nx, ny) -> cell indices AS RETURNED BY THE REFERENCE'S OWN BINARY.
 
 refdll_runner.c maps SfM-GMS/bin/opencv_xfeatures2d452.dll and calls its GMSMatcher::getGridIndexLeft /
 getGridIndexRight (two leaf functions) on the inputs built here. Needs /root/reference; run in the build container:
@@ -89,6 +89,66 @@ def assign_fixture():
     print("assign fixture", os.path.getsize(os.path.join(HERE, "refdll_assign_pairs.npz")), "bytes")
 
 
+def verify_motion(rng, wr, quarter_turns, lam, noise):
+    """A motion matrix with structure: most left cells vote for the cell a rotated, shrunk copy of the grid puts them
+    in (Poisson counts around the threshold), some with a second right cell tied for the maximum, plus scattered votes."""
+    nr = wr * wr
+    mo = np.zeros((400, nr), dtype=np.int32)
+    a = quarter_turns * np.pi / 4
+    for i in range(400):
+        cx, cy = (i % 20 + 0.5) / 20 - 0.5, (i // 20 + 0.5) / 20 - 0.5
+        rx = (cx * np.cos(a) - cy * np.sin(a)) * 0.7 + 0.5
+        ry = (cx * np.sin(a) + cy * np.cos(a)) * 0.7 + 0.5
+        j = int(rx * wr) + int(ry * wr) * wr
+        if rng.random() < 0.85:
+            mo[i, j] += rng.poisson(lam)
+            if rng.random() < 0.3:
+                mo[i, rng.integers(0, nr)] = mo[i, j]
+        for _ in range(rng.poisson(noise)):
+            mo[i, rng.integers(0, nr)] += 1
+    return mo
+
+
+def verify_fixture():
+    """The body of GMSMatcher::verifyCellPairs run out of the DLL (refdll_runner.c "verify") for rotation types 1..8:
+    mCellPairs for every left cell of several motion matrices / right grids / threshold factors."""
+    rng = np.random.default_rng(0x5F3759DF ^ 3)
+    cases = {}
+    for tag, (wr, turns, lam, noise, factor) in {
+            "a": (20, 0, 4, 1, 6.0), "b": (20, 2, 5, 2, 6.0), "c": (10, 1, 6, 1, 6.0), "d": (14, 3, 3, 2, 4.0),
+            "e": (28, 5, 5, 1, 6.0), "f": (40, 7, 4, 1, 2.5), "g": (20, 4, 30, 3, 6.0), "h": (40, 6, 9, 0, 0.1)}.items():
+        mo = verify_motion(rng, wr, turns, lam, noise)
+        cases[tag] = (wr, factor, mo, mo.sum(axis=1).astype(np.int32))
+    # threshold met with equality: 36 matches per cell, 4 of them on the diagonal -> interior score 36 = 6 * sqrt(36);
+    # one vote fewer in a neighbour tips its whole 3 x 3 surroundings
+    mo = np.zeros((400, 400), dtype=np.int32)
+    mo[np.arange(400), np.arange(400)] = 4
+    mo[210, 210] = 3
+    mo[0, 0] = 0  # an empty row next to the corner
+    cases["eq"] = (20, 6.0, mo, np.full(400, 36, dtype=np.int32))
+    out = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        exe = os.path.join(tmp, "refdll_runner")
+        subprocess.check_call(["gcc", "-O1", "-o", exe, os.path.join(HERE, "refdll_runner.c")])
+        for tag, (wr, factor, mo, nleft) in cases.items():
+            fin, fout = os.path.join(tmp, "in.bin"), os.path.join(tmp, "out.bin")
+            with open(fin, "wb") as f:
+                f.write(np.array([wr, wr], dtype=np.int32).tobytes())
+                f.write(np.float64(factor).tobytes())
+                f.write(nleft.tobytes()); f.write(mo.tobytes())
+            subprocess.check_call([exe, DLL, fin, fout, "verify"])
+            cp = np.fromfile(fout, dtype=np.int32).reshape(8, 400)
+            l, r = np.nonzero(mo)
+            out[tag + "_dims"] = np.array([wr, wr], dtype=np.int32)
+            out[tag + "_factor"] = np.float64(factor)
+            out[tag + "_nleft"] = nleft
+            out[tag + "_motion"] = np.stack([l, r, mo[l, r]], axis=1).astype(np.int32)
+            out[tag + "_cell_pairs"] = cp
+            print("verify", tag, "accepted per rotation", (cp >= 0).sum(axis=1).tolist(), "empty", int((cp[0] == -1).sum()))
+    np.savez_compressed(os.path.join(HERE, "refdll_verify_cells.npz"), **out)
+    print("verify fixture", os.path.getsize(os.path.join(HERE, "refdll_verify_cells.npz")), "bytes")
+
+
 def main():
     if not os.path.exists(DLL):
         sys.exit("reference DLL not present: this generator runs only where /root/reference is mounted")
@@ -106,6 +166,7 @@ def main():
     np.savez_compressed(os.path.join(HERE, "refdll_grid_index.npz"), nxy=pts, left=res[:, :4], right=res[:, 4:],
                         right_dims=np.array([20, 10, 14, 28, 40], dtype=np.int32))
     assign_fixture()
+    verify_fixture()
     print(len(pts), "points;", "left range", res[:, :4].min(), res[:, :4].max(), "; file",
           os.path.getsize(os.path.join(HERE, "refdll_grid_index.npz")), "bytes")
 

@@ -21,6 +21,22 @@
  *   mNumberPointsInPerCellLeft.begin @+0xc8, mvMatchPairs.begin @+0xf8.
  *   in.bin : int32 wr, hr, n1, n2, m; n1 x float2 (normalised), n2 x float2, m x (int32 query, int32 train)
  *   out.bin: per grid type: m x 2 int32 (mvMatchPairs), 400 int32 (per-cell counts), 400 * wr * hr int32 (motion)
+ *
+ * usage: refdll_runner <dll> <in.bin> <out.bin> verify
+ *   The body of GMSMatcher::verifyCellPairs (RVA 0x48d10) for one left cell at a time. The function's first act per
+ *   cell is cv::sum(row) through opencv_core (an import this image does not have), so it cannot be called from its
+ *   entry; but everything after that test -- the arg-max scan, the nine neighbour sums through the rotation pattern,
+ *   sqrt(T / n) * factor and the '>' -- is self-contained code from RVA 0x48e12 on. The trampoline below rebuilds the
+ *   function's own prologue state (frame, saved registers, security cookie, rbx = this, rsi = cell, r13d = cell + 1,
+ *   rbp = 9 * rotation, xmm7 = 0) and jumps there; with mGridNumberLeft set to cell + 1 the loop ends after that one
+ *   cell and the function's own epilogue returns. The "row sum == 0 -> -1" branch is the driver's (cells with no
+ *   match never reach the fragment). Object layout from the disassembly: mGridNumberLeft @+0x60, mGridNumberRight
+ *   @+0x64, motion data @+0x78 / row-step pointer @+0xb0, per-cell counts @+0xc8, mCellPairs.begin @+0xe0, left
+ *   neighbour table data @+0x140 / step pointer @+0x178, right neighbour table data @+0x1a0 / step pointer @+0x1d8,
+ *   mThresholdFactor @+0x1f0. The two neighbour tables are filled by this file (getNB9 allocates through the CRT and
+ *   cannot be run).
+ *   in.bin : int32 wr, hr; double factor; 400 int32 counts; 400 * wr * hr int32 motion
+ *   out.bin: 8 x 400 int32 mCellPairs (rotation types 1..8)
  */
 #define _GNU_SOURCE
 #include <stdint.h>
@@ -28,6 +44,34 @@
 #include <stdlib.h>
 #include <string.h>
 #include <sys/mman.h>
+
+/* see "verify" above: emulates verifyCellPairs' prologue, then jumps into its body */
+void __attribute__((ms_abi)) verify_fragment(void* self, int rotation_type, long long cell, void* body, void* cookie);
+__asm__(".intel_syntax noprefix\n"
+        ".globl verify_fragment\n"
+        "verify_fragment:\n"
+        "  mov rax, rsp\n"
+        "  mov [rax+0x10], rbx\n"
+        "  mov [rax+0x18], rbp\n"
+        "  mov [rax+0x20], rsi\n"
+        "  push rdi\n  push r12\n  push r13\n  push r14\n  push r15\n"
+        "  sub rsp, 0x100\n"
+        "  movaps [rax-0x38], xmm6\n"
+        "  movaps [rax-0x48], xmm7\n"
+        "  mov r10, [rax+0x28]\n"          /* fifth argument: address of the image's security cookie */
+        "  mov r10, [r10]\n"
+        "  xor r10, rsp\n"
+        "  mov [rsp+0xd0], r10\n"
+        "  mov rbx, rcx\n"
+        "  xor r15d, r15d\n"
+        "  mov [rsp+0x20], r15d\n"
+        "  movsxd rax, edx\n"
+        "  lea rbp, [rax+8*rax]\n"
+        "  mov rsi, r8\n"
+        "  lea r13d, [r8d+1]\n"
+        "  xorps xmm7, xmm7\n"
+        "  jmp r9\n"
+        ".att_syntax prefix\n");
 
 typedef int(__attribute__((ms_abi)) * left_fn)(void* self, const float* pt, int type);
 typedef int(__attribute__((ms_abi)) * right_fn)(void* self, const float* pt);
@@ -104,6 +148,60 @@ int main(int argc, char** argv)
             fwrite(mp, 8, (size_t)m, out);
             fwrite(nleft, 4, 400, out);
             fwrite(motion, 4, 400 * (size_t)wr * hr, out);
+        }
+        fclose(in);
+        fclose(out);
+        return 0;
+    }
+    if (argc == 5 && strcmp(argv[4], "verify") == 0) {
+        FILE* in = fopen(argv[2], "rb");
+        FILE* out = fopen(argv[3], "wb");
+        if (!in || !out) return 6;
+        int32_t hdr[2];
+        double factor;
+        if (fread(hdr, 4, 2, in) != 2 || fread(&factor, 8, 1, in) != 1) return 6;
+        const int wr = hdr[0], hr = hdr[1], nr = wr * hr;
+        int32_t nleft[400], cell_pairs[400];
+        int32_t* motion = malloc(sizeof(int32_t) * 400 * (size_t)nr);
+        if (fread(nleft, 4, 400, in) != 400 || fread(motion, 4, 400 * (size_t)nr, in) != 400 * (size_t)nr) return 6;
+        int32_t* nb_left = malloc(sizeof(int32_t) * 9 * 400);
+        int32_t* nb_right = malloc(sizeof(int32_t) * 9 * (size_t)nr);
+        for (int pass = 0; pass < 2; pass++) {  /* getNB9 by restatement (DLL@0x180048030) */
+            int32_t* nb = pass ? nb_right : nb_left;
+            const int gw = pass ? wr : 20, gh = pass ? hr : 20;
+            for (int idx = 0; idx < gw * gh; idx++) {
+                for (int k = 0; k < 9; k++) nb[9 * idx + k] = -1;
+                for (int yi = -1; yi <= 1; yi++)
+                    for (int xi = -1; xi <= 1; xi++) {
+                        const int xx = idx % gw + xi, yy = idx / gw + yi;
+                        if (xx < 0 || xx >= gw || yy < 0 || yy >= gh) continue;
+                        nb[9 * idx + xi + 4 + yi * 3] = xx + yy * gw;
+                    }
+            }
+        }
+        uint64_t step_motion = (uint64_t)nr * 4, step_nb = 36;
+        unsigned char self[0x200];
+        memset(self, 0, sizeof self);
+        *(int32_t*)(self + 0x64) = nr;
+        *(void**)(self + 0x78) = motion;
+        *(void**)(self + 0xb0) = &step_motion;
+        *(void**)(self + 0xc8) = nleft;
+        *(void**)(self + 0xe0) = cell_pairs;
+        *(void**)(self + 0x140) = nb_left;
+        *(void**)(self + 0x178) = &step_nb;
+        *(void**)(self + 0x1a0) = nb_right;
+        *(void**)(self + 0x1d8) = &step_nb;
+        *(double*)(self + 0x1f0) = factor;
+        for (int rot = 1; rot <= 8; rot++) {
+            for (int i = 0; i < 400; i++) {
+                cell_pairs[i] = -1; /* run(): mCellPairs.assign(400, -1) */
+                long long rowsum = 0;
+                for (int j = 0; j < nr; j++) rowsum += motion[(size_t)i * nr + j];
+                if (rowsum == 0) continue; /* the cv::sum(row) == 0 branch keeps -1 */
+                *(int32_t*)(self + 0x60) = i + 1; /* mGridNumberLeft: the loop ends after this cell */
+                verify_fragment(self, rot, i, img + 0x48e12, img + 0x2c5068);
+            }
+            fwrite(cell_pairs, 4, 400, out);
         }
         fclose(in);
         fclose(out);

@@ -150,3 +150,31 @@ def test_binning_matches_the_reference_binary(oracle):
         # the shifted grid types really do reject the last half cell, and type 1's right cell is reused
         assert (z[f"{tag}_pairs2"][:, 0] == -1).any() and (z[f"{tag}_pairs1"][:, 0] >= 0).all()
         assert np.array_equal(z[f"{tag}_pairs1"][:, 1], z[f"{tag}_pairs4"][:, 1])
+
+
+def test_cell_verification_matches_the_reference_binary(oracle):
+    """tests/golden/refdll_verify_cells.npz: the body of GMSMatcher::verifyCellPairs (arg-max scan, rotated 3 x 3
+    neighbour sums, sqrt(T / n) * factor, the '>' test) executed out of the reference DLL for rotation types 1..8 on
+    nine motion matrices over all five right-grid sizes and four threshold factors, one of them meeting the threshold
+    with equality. The oracle's verify_cell_pairs must return the same mCellPairs for every left cell."""
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "refdll_verify_cells.npz"))
+    tags = sorted(k[:-5] for k in z.files if k.endswith("_dims"))
+    assert len(tags) == 9
+    seen_grids, accepted, rejected = set(), 0, 0
+    for tag in tags:
+        wr, hr = (int(v) for v in z[tag + "_dims"])
+        seen_grids.add(wr)
+        motion = np.zeros((400, wr * hr), dtype=np.int32)
+        nz = z[tag + "_motion"]
+        motion[nz[:, 0], nz[:, 1]] = nz[:, 2]
+        want = z[tag + "_cell_pairs"]
+        for rot in range(1, 9):
+            got = oracle.verify_cells(motion, z[tag + "_nleft"], wr, hr, rot, float(z[tag + "_factor"]))
+            assert np.array_equal(got, want[rot - 1]), (tag, rot, np.nonzero(got != want[rot - 1])[0][:8])
+        accepted += int((want >= 0).sum())
+        rejected += int((want == -2).sum())
+    assert seen_grids == {10, 14, 20, 28, 40} and accepted > 3000 and rejected > 10000
+    eq = z["eq_cell_pairs"][0].reshape(20, 20)
+    assert eq[5, 5] == 5 * 20 + 5          # 36 == 6 * sqrt(324 / 9): equality is not a rejection
+    assert eq[10, 10] == -2 and eq[9, 11] == -2 and eq[12, 10] == 12 * 20 + 10   # one vote short around cell 210
+    assert eq[0, 0] == -1 and eq[1, 1] == -2 and eq[0, 5] == -2                   # empty row; its neighbour; a border
