@@ -210,6 +210,13 @@ int gms_filter_device(gms_ctx* c, const float* d_pts, const int64_t* d_frame_off
     p.with_scale = with_scale ? 1 : 0;
     p.threshold_factor = threshold_factor;
     right_grids(p.right_w, p.right_h);
+    // GMS_DENSE=0 keeps every pair on the hashed path (diagnostics); by default the byte-matrix path is tried first
+    // whenever there are no scale hypotheses (the reference's default flags, DisparityUtil.cpp:149,299)
+    static const bool dense_on = [] {
+        const char* e = std::getenv("GMS_DENSE");
+        return !e || std::atoi(e) != 0;
+    }();
+    p.dense = (dense_on && !with_scale) ? 1 : 0;
 #ifdef GMS_PHASE_TIMING
     p.diag = g_diag;
 #endif

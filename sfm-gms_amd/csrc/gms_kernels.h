@@ -29,6 +29,7 @@ struct FilterParams {
     uint32_t table_slots;       // multiple of 4: data + header buckets of all 400 regions
     int region_shift;           // region slots per match = 1 + 2^-shift
     int with_rotation, with_scale;
+    int dense;                  // try the byte-matrix path first (no scale hypotheses only); the general path is the fallback
     double threshold_factor;
     int right_w[5], right_h[5]; // setScale (DLL@0x180048c10): cvRound(20 * ratio[s])
 #ifdef GMS_PHASE_TIMING

@@ -226,6 +226,18 @@ normalize_kernel(const gms_keypoint* __restrict__ kp, const int64_t* __restrict_
     }
 }
 
+// Every pair of a batch costs about the same, so the workgroups of one dispatch round would all read their
+// match arrays at the same moment (an HBM burst, then a long quiet stretch) and stay in lockstep round after
+// round. The first round's workgroups start spread over p.stagger_cycles; the spread then persists.
+__device__ __forceinline__ void first_round_stagger(const FilterParams& p)
+{
+    if (p.stagger_cycles > 0 && blockIdx.x < (unsigned)p.stagger_blocks) {
+        const unsigned slot = (blockIdx.x * 37u) & 63u;
+        const long long until = (long long)__builtin_readcyclecounter() + (long long)slot * (p.stagger_cycles >> 6);
+        while ((long long)__builtin_readcyclecounter() < until) __builtin_amdgcn_s_sleep(32);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // The filter: one 1024-thread workgroup per pair, KPT matches per thread held in registers.
 // The kernel is VALU-issue bound, so the per-match work is kept to a few instructions: the left cell of
@@ -233,10 +245,8 @@ normalize_kernel(const gms_keypoint* __restrict__ kp, const int64_t* __restrict_
 // half-cell index gives the table region (insert) and the verified cell result (mark) with one LDS read.
 // ------------------------------------------------------------------------------------------------
 template <int KPT, bool ROT, int NT>
-__global__ void __launch_bounds__(NT)
-filter_kernel(FilterParams p)
+__device__ __forceinline__ void hash_pair(const FilterParams& p, uint32_t* smem)
 {
-    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     constexpr int kMcap = KPT * NT;
     constexpr int kNRot = ROT ? 8 : 1;
     // matches a thread keeps in flight through the LDS stages: 5 (4) with 128 registers per thread, 10 with 256
@@ -265,14 +275,6 @@ filter_kernel(FilterParams p)
                                                    // [0..63] add/CAS sink per lane, [64..127] min sink per lane,
                                                    // [128..131] an always-empty bucket (16-byte aligned)
 
-    // Every pair of a batch costs about the same, so the workgroups of one dispatch round would all read their
-    // match arrays at the same moment (an HBM burst, then a long quiet stretch) and stay in lockstep round after
-    // round. The first round's workgroups start spread over p.stagger_cycles; the spread then persists.
-    if (p.stagger_cycles > 0 && blockIdx.x < (unsigned)p.stagger_blocks) {
-        const unsigned slot = (blockIdx.x * 37u) & 63u;
-        const long long until = (long long)__builtin_readcyclecounter() + (long long)slot * (p.stagger_cycles >> 6);
-        while ((long long)__builtin_readcyclecounter() < until) __builtin_amdgcn_s_sleep(32);
-    }
     if (tid < 48) misc[tid] = 0;
     if (tid < 128) trash[tid] = 0;
     if (tid >= 128 && tid < 132) trash[tid] = kEmpty;
@@ -780,6 +782,368 @@ filter_kernel(FilterParams p)
     }
 }
 
+template <int KPT, bool ROT, int NT>
+__global__ void __launch_bounds__(NT)
+filter_kernel(FilterParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    first_round_stagger(p);
+    hash_pair<KPT, ROT, NT>(p, smem);
+}
+
+// ------------------------------------------------------------------------------------------------
+// The dense path: pairs whose motion matrix fits the LDS as BYTES.
+//
+// Without scale hypotheses the right grid is 20 x 20, so the reference's 400 x 400 matrix is 160 000 entries; an
+// entry never exceeds the number of matches of its left cell, so when no left cell (of any grid type) holds more
+// than 255 matches the whole matrix fits the CU's LDS as one byte per entry -- 160 000 of the 163 840 bytes.
+// assignMatchPairs then is one returning LDS atomic per match (+1 on the entry's byte; the value it returns
+// is the count this match produced, folded into the row's running arg-max with one atomicMin as in the hashed
+// path) and verifyCellPairs reads neighbour counts directly: no hashing, no bucket scans, no probe chains --
+// about a quarter of the hashed path's instructions per match. Everything else has to live in the remaining
+// 3.8 KB: the half-cell histogram as bytes, one header dword per left cell (arg-max while binning, cellPairs
+// after verification), the rotation counters and 32 dwords of sinks. The surviving DMatch records are kept in
+// registers from the first load, so the match array is read exactly once.
+// A pair that does not qualify (a cell above 255 matches, a frame too large to stage, any input outside the
+// parity domain, scale hypotheses) is handed to hash_pair() by the same workgroup; results are identical.
+// ------------------------------------------------------------------------------------------------
+constexpr uint32_t kDenseBytes = 160000u;                       // 400 left cells x (<= 400 right cells) x 1 byte
+constexpr uint32_t kDenseHdrOff = kDenseBytes;                  // [400] dwords
+constexpr uint32_t kDenseFineOff = kDenseHdrOff + 4u * kLeftN;  // [1600] bytes
+constexpr uint32_t kDenseMiscOff = kDenseFineOff + kFineN;      // [48] dwords: [0..7] rotation counts, [8] domain error,
+                                                                //   [9] carry, [11] not eligible, [16..] scan scratch
+constexpr uint32_t kDenseTrashOff = kDenseMiscOff + 4u * 48u;   // [32] dwords: [0..15] add sinks, [16..31] min sinks
+constexpr uint32_t kDenseLdsBytes = kDenseTrashOff + 4u * 32u;  // 163 520
+static_assert(kDenseLdsBytes <= kLdsBytes, "dense layout exceeds the LDS");
+
+// dense code word: right cell : 11 | hx : 6 | hy : 6 | rotation bits : 8 (hx = hy = 63: never binned)
+constexpr int kDHxShift = 11, kDHyShift = 17, kDAccShift = 23;
+constexpr uint32_t kDNever = (63u << kDHxShift) | (63u << kDHyShift);
+
+// mNumberPointsInPerCellLeft of cell (x, y) under the grid type shifted by (gx, gy) half cells
+__device__ __forceinline__ uint32_t dense_nleft(const uint8_t* nfine8, int x, int y, int gx, int gy)
+{
+    const int hx0 = 2 * x - gx, hy0 = 2 * y - gy;  // hx0 + 1, hy0 + 1 <= 39
+    uint32_t n = 0;
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 2; ++dx) {
+            const int hx = hx0 + dx, hy = hy0 + dy;
+            const uint32_t v = nfine8[max(hy, 0) * kFineW + max(hx, 0)];
+            n += (hx >= 0 && hy >= 0) ? v : 0u;
+        }
+    return n;
+}
+
+// false (workgroup-uniform, nothing written to global memory): the pair has to take the general path
+template <int KPT, bool ROT, int NT>
+__device__ __forceinline__ bool dense_pair(const FilterParams& p, uint32_t* smem)
+{
+    constexpr int kMcap = KPT * NT;
+    constexpr int kNRot = ROT ? 8 : 1;
+    constexpr int kChunk = (KPT % 5 == 0) ? 5 : 4;
+    static_assert(KPT % kChunk == 0, "KPT must be a multiple of the chunk");
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+
+    const gms_pair pr = p.pairs[blockIdx.x];
+    const int m = pr.m;
+    if (p.with_scale || m <= 0 || m > kMcap || pr.frame_a < 0 || pr.frame_a >= p.n_frames || pr.frame_b < 0 ||
+        pr.frame_b >= p.n_frames)
+        return false;
+    const int64_t offA = p.frame_off[pr.frame_a], offB = p.frame_off[pr.frame_b];
+    const int nA = (int)(p.frame_off[pr.frame_a + 1] - offA), nB = (int)(p.frame_off[pr.frame_b + 1] - offB);
+    const int wr = p.right_w[0], hr = p.right_h[0];
+    const uint32_t nr = (uint32_t)(wr * hr);
+    if (nA <= 0 || nB <= 0 || (uint32_t)nB * 8u > kDenseBytes || nr == 0 || nr * (uint32_t)kLeftN > kDenseBytes) return false;
+    const float2* __restrict__ ptsA = p.pts + offA;
+    const float2* __restrict__ ptsB = p.pts + offB;
+    const gms_dmatch* __restrict__ matches = p.matches + pr.match_off;
+
+    uint8_t* dense8 = reinterpret_cast<uint8_t*>(smem);
+    uint32_t* hdr = smem + kDenseHdrOff / 4;        // row arg-max ((255 - count) << 11 | right cell, atomicMin), then cellPairs
+    uint32_t* nfine32 = smem + kDenseFineOff / 4;   // 40 x 40 byte counters, four to a dword
+    const uint8_t* nfine8 = reinterpret_cast<const uint8_t*>(nfine32);
+    uint32_t* misc = smem + kDenseMiscOff / 4;
+    uint32_t* trash = smem + kDenseTrashOff / 4;
+
+    if (tid < 48) misc[tid] = 0;
+    if (tid < 32) trash[tid] = 0;
+    if (tid < kFineN / 4) nfine32[tid] = 0;
+
+    // ---- the pair's DMatch records, whole (they stay in registers until copy-out), and frame B staged in the
+    //      still unused matrix area for the train-side gather
+    uint4 rec[KPT];
+#pragma unroll
+    for (int k = 0; k < KPT; ++k) rec[k] = *reinterpret_cast<const uint4*>(&matches[min(k * NT + tid, m - 1)]);
+    float2* lds_b = reinterpret_cast<float2*>(smem);
+    for (int j = tid; j < nB; j += NT) lds_b[j] = ptsB[j];
+    __syncthreads();
+
+    uint32_t code[KPT];
+    {
+        float2 a[KPT], b[KPT];
+#pragma unroll
+        for (int k = 0; k < KPT; ++k) a[k] = ptsA[min(rec[k].x, (uint32_t)(nA - 1))];
+#pragma unroll
+        for (int k = 0; k < KPT; ++k) b[k] = lds_b[min(rec[k].y, (uint32_t)(nB - 1))];
+        const float fwr = (float)wr, fhr = (float)hr;
+        bool any_bad = false, spill = false;
+#pragma unroll
+        for (int k = 0; k < KPT; ++k) {
+            const bool live = k * NT + tid < m;
+            const uint32_t worst = max(max(__float_as_uint(a[k].x), __float_as_uint(a[k].y)),
+                                       max(__float_as_uint(b[k].x), __float_as_uint(b[k].y)));
+            const float fx = 20.0f * a[k].x, fy = 20.0f * a[k].y;   // mulss, rounded to fp32
+            const uint32_t hx = (uint32_t)(int)(fx + fx), hy = (uint32_t)(int)(fy + fy);
+            const uint32_t r = (uint32_t)((int)(fwr * b[k].x) + (int)(fhr * b[k].y) * wr);
+            const bool ok = rec[k].x < (uint32_t)nA && rec[k].y < (uint32_t)nB && worst < 0x49800000u && r < nr;
+            const bool binned = live && ok && hx < 40u && hy < 40u;
+            const uint32_t f = binned ? hy * kFineW + hx : 0u;
+            const uint32_t fs = (f & 3u) << 3;
+            const uint32_t old = atomicAdd(binned ? &nfine32[f >> 2] : &trash[lane & 15], 1u << fs);
+            spill |= binned && ((old >> fs) & 255u) == 255u;  // the byte wrapped: more than 255 in one half cell
+            any_bad |= live && !ok;
+            code[k] = binned ? (r | (hx << kDHxShift) | (hy << kDHyShift)) : kDNever;
+        }
+        if (any_bad) misc[8] = 1;   // benign races: every writer stores 1
+        if (spill) misc[11] = 1;
+    }
+    __syncthreads();  // histogram complete; every read of the staged frame is done
+
+    // a left cell above 255 matches under any grid type: not representable
+    for (int item = tid; item < 4 * kLeftN; item += NT) {
+        const int g = item / kLeftN, cell = item - g * kLeftN;
+        if (dense_nleft(nfine8, cell % kLeftW, cell / kLeftW, g & 1, g >> 1) > 255u) misc[11] = 1;
+    }
+
+    const bool thr_fast = threshold_fast_ok(p.threshold_factor);
+    const uint32_t clear_n = 25u * nr;  // uint4s in 400 rows of nr bytes
+    const uint32_t trash_add = kDenseTrashOff + (uint32_t)((lane & 15) << 2), trash_min = trash_add + 64u;
+    for (int g = 0; g < 4; ++g) {
+        const int gx = g & 1, gy = g >> 1;
+        // ---- motion.setTo(0); row headers back to "no arg-max yet"
+        {
+            const uint4 z4 = make_uint4(0, 0, 0, 0);
+            uint4* d4 = reinterpret_cast<uint4*>(smem);
+            for (uint32_t i = tid; i < clear_n; i += NT) d4[i] = z4;
+            if (tid < kLeftN) hdr[tid] = kEmpty;
+        }
+        __syncthreads();
+        if (g == 0 && (misc[8] | misc[11]) != 0) {  // workgroup-uniform
+            __syncthreads();                        // everybody has read the flags before the general path reuses the LDS
+            return false;
+        }
+
+        // ---- assignMatchPairs: motion[l][r]++ on the byte, the produced count into the row's arg-max
+#pragma unroll
+        for (int k0 = 0; k0 < KPT; k0 += kChunk) {
+            uint32_t old[kChunk], sh[kChunk], hoff[kChunk];
+#pragma unroll
+            for (int c = 0; c < kChunk; ++c) {
+                const uint32_t cw = code[k0 + c];
+                const uint32_t lx = (((cw >> kDHxShift) & 63u) + (uint32_t)gx) >> 1;
+                const uint32_t ly = (((cw >> kDHyShift) & 63u) + (uint32_t)gy) >> 1;
+                const bool valid = max(lx, ly) < (uint32_t)kLeftW;  // x >= 20 || y >= 20 -> -1 (DLL@0x180047d3d)
+                const uint32_t l = __umul24(ly, (uint32_t)kLeftW) + lx;
+                const uint32_t a = __umul24(l, nr) + (cw & kRMask);
+                sh[c] = (a & 3u) << 3;
+                old[c] = atomicAdd(lds_at(smem, valid ? (a & ~3u) : trash_add), 1u << sh[c]);
+                hoff[c] = valid ? kDenseHdrOff + (l << 2) : trash_min;
+            }
+            __builtin_amdgcn_sched_barrier(0);  // all of the chunk's atomics are issued before any result is read
+#pragma unroll
+            for (int c = 0; c < kChunk; ++c) {
+                const uint32_t before = (old[c] >> sh[c]) & 255u;  // <= 254 on every binned match
+                atomicMin(lds_at(smem, hoff[c]), ((254u - before) << 11) | (code[k0 + c] & kRMask));
+            }
+        }
+        __syncthreads();
+
+        // ---- verifyCellPairs. Without rotation: two lanes per left cell, four neighbours each, joined by one DPP
+        //      exchange; with rotation: one lane per (cell, rotation).
+        {
+            constexpr int kItems = ROT ? kLeftN * 8 : kLeftN * 2;
+            for (int item = tid; item < ((kItems + 63) & ~63); item += NT) {
+                const bool live = item < kItems;
+                const int i = live ? (ROT ? (item >> 3) : (item >> 1)) : 0;
+                const int rot = ROT ? (item & 7) : 0;
+                const int half = item & 1;  // !ROT only
+                const int ix = i % kLeftW, iy = i / kLeftW;
+                const uint32_t ni = live ? dense_nleft(nfine8, ix, iy, gx, gy) : 0u;
+                const uint32_t best = hdr[i];                // ((255 - max count) << 11) | j*, lowest j* among maxima
+                const int j = ni ? (int)(best & kRMask) : 0;
+                const int jx = j % wr, jy = j / wr;
+                uint32_t score = 0, tn = 0;  // tn = (sum of nLeft << 4) | numpair
+#pragma unroll
+                for (int h = 0; h < (ROT ? 8 : 4); h += 4) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        int ldx, ldy, rdx, rdy;
+                        if (ROT) {
+                            const int k8 = h + c;
+                            const int k = k8 < 4 ? k8 : k8 + 1;
+                            constexpr int kRingIndex[9] = {0, 1, 2, 7, -1, 3, 6, 5, 4};  // position -> ring index
+                            const int q = rotated_position(rot, kRingIndex[k]);
+                            ldx = (k % 3) - 1; ldy = (k / 3) - 1;
+                            rdx = position_dx(q); rdy = position_dy(q);
+                        } else {
+                            ldx = half ? ((c + 5) % 3) - 1 : (c % 3) - 1;  // lane 0: neighbours 0..3, lane 1: 5..8
+                            ldy = half ? ((c + 5) / 3) - 1 : (c / 3) - 1;
+                            rdx = ldx; rdy = ldy;
+                        }
+                        const int lx = ix + ldx, ly = iy + ldy;
+                        const int rx = jx + rdx, ry = jy + rdy;
+                        const bool okl = ni != 0 && (uint32_t)lx < (uint32_t)kLeftW && (uint32_t)ly < (uint32_t)kLeftH;  // ll != -1
+                        const bool okp = okl && (uint32_t)rx < (uint32_t)wr && (uint32_t)ry < (uint32_t)hr;             // rr != -1
+                        const int cx = okl ? lx : 0, cy = okl ? ly : 0;
+                        const uint32_t nll = dense_nleft(nfine8, cx, cy, gx, gy);
+                        const uint32_t cnt = dense8[(uint32_t)(cx + cy * kLeftW) * nr + (okp ? (uint32_t)(rx + ry * wr) : 0u)];
+                        score += okp ? cnt : 0u;
+                        tn += okp ? ((nll << 4) | 1u) : 0u;
+                    }
+                }
+                if (!ROT) {
+                    score += dpp_xor1(score);
+                    tn += dpp_xor1(tn);
+                }
+                score += 255u - (best >> 11);  // centre pair (k = 4): ll = i, rr = j*, the arg-max count itself
+                tn += (ni << 4) | 1u;
+                uint32_t pass = 0;
+                if (ni != 0 && (ROT || half == 0))
+                    pass = threshold_rejects(tn >> 4, tn & 15u, score, p.threshold_factor, thr_fast) ? 0u : 1u;
+                uint32_t bits = pass;
+                bool writer = ni != 0 && half == 0;
+                if (ROT) {
+                    const unsigned long long bal = __ballot(pass);
+                    bits = (uint32_t)(bal >> (lane & 56)) & 0xFFu;
+                    writer = ni != 0 && (lane & 7) == 0;
+                }
+                // every lane of the cell has read hdr[i] above (same wave, program order): it now holds cellPairs[i]
+                if (writer) hdr[i] = ((uint32_t)j << 8) | bits;
+            }
+        }
+        __syncthreads();
+
+        // ---- mark inliers: cellPairs[l] == r, all rotations at once
+        {
+            uint32_t cr[KPT];
+            bool valid[KPT];
+#pragma unroll
+            for (int k = 0; k < KPT; ++k) {
+                const uint32_t cw = code[k];
+                const uint32_t lx = (((cw >> kDHxShift) & 63u) + (uint32_t)gx) >> 1;
+                const uint32_t ly = (((cw >> kDHyShift) & 63u) + (uint32_t)gy) >> 1;
+                valid[k] = max(lx, ly) < (uint32_t)kLeftW;
+                cr[k] = hdr[valid[k] ? __umul24(ly, (uint32_t)kLeftW) + lx : 0u];
+            }
+#pragma unroll
+            for (int k = 0; k < KPT; ++k)
+                if (valid[k] && (cr[k] >> 8) == (code[k] & kRMask)) code[k] |= (cr[k] & 0xFFu) << kDAccShift;
+        }
+        __syncthreads();  // hdr is cleared next; after the last grid type the matrix area is reused below
+    }
+
+    // ---- run() return value per rotation, getInlierMask's strict '>' over the rotations (one scale)
+    {
+        uint32_t cnt[kNRot];
+#pragma unroll
+        for (int r = 0; r < kNRot; ++r) cnt[r] = 0;
+#pragma unroll
+        for (int k = 0; k < KPT; ++k)
+#pragma unroll
+            for (int r = 0; r < kNRot; ++r)
+                cnt[r] += (uint32_t)__popcll(__ballot((code[k] >> (kDAccShift + r)) & 1u));
+        if (lane == 0) {
+#pragma unroll
+            for (int r = 0; r < kNRot; ++r)
+                if (cnt[r]) atomicAdd(&misc[r], cnt[r]);
+        }
+    }
+    __syncthreads();
+    uint32_t best_count = 0;
+    int winner = -1;
+#pragma unroll
+    for (int r = 0; r < kNRot; ++r) {
+        const uint32_t c = misc[r];
+        if (c > best_count) {
+            best_count = c;
+            winner = r;
+        }
+    }
+    uint32_t* bestmask = smem;                       // kMcap / 32 dwords, in the matrix area
+    uint32_t* chunk_base = bestmask + (kMcap >> 5);  // kMcap / 64
+    uint32_t* wave_tot = misc + 16;
+    const int n_chunks = (m + 63) >> 6;
+#pragma unroll
+    for (int k = 0; k < KPT; ++k) {
+        const unsigned long long bsel = winner >= 0 ? __ballot((code[k] >> (kDAccShift + max(winner, 0))) & 1u) : 0ull;
+        if (lane == 0) {
+            const int ch = k * (NT / 64) + wave;  // chunk of 64 consecutive matches
+            bestmask[2 * ch] = (uint32_t)bsel;
+            bestmask[2 * ch + 1] = (uint32_t)(bsel >> 32);
+        }
+    }
+    __syncthreads();
+
+    // ---- copy-out: surviving DMatch verbatim, in input order (DLL@0x180048340), from the registers
+    for (int base = 0; base < n_chunks; base += NT) {
+        const int c = base + tid;
+        const uint32_t v = c < n_chunks ? __popc(bestmask[2 * c]) + __popc(bestmask[2 * c + 1]) : 0u;
+        uint32_t incl = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t t = __shfl_up(incl, d);
+            if (lane >= d) incl += t;
+        }
+        if (lane == 63) wave_tot[wave] = incl;
+        __syncthreads();
+        uint32_t wave_off = misc[9];
+        for (int w = 0; w < wave; ++w) wave_off += wave_tot[w];
+        if (c < n_chunks) chunk_base[c] = wave_off + incl - v;
+        __syncthreads();
+        if (tid == NT - 1) misc[9] = wave_off + incl;
+        __syncthreads();
+    }
+    const uint32_t total = misc[9];
+    gms_dmatch* __restrict__ out = p.out + pr.match_off;
+    uint8_t* mask_out = p.mask ? p.mask + pr.match_off : nullptr;
+#pragma unroll
+    for (int k = 0; k < KPT; ++k) {
+        const int i = k * NT + tid;
+        const int ch = i >> 6;
+        if (i < m) {
+            const unsigned long long bits = (unsigned long long)bestmask[2 * ch] | ((unsigned long long)bestmask[2 * ch + 1] << 32);
+            const bool in = (bits >> lane) & 1ull;
+            if (mask_out) mask_out[i] = in ? 1 : 0;
+            if (in) {
+                const uint32_t pos = chunk_base[ch] + (uint32_t)__popcll(bits & ((1ull << lane) - 1ull));
+                *reinterpret_cast<uint4*>(&out[pos]) = rec[k];
+            }
+        }
+    }
+    if (tid == 0) {
+        gms_pair_result r;
+        r.n_inliers = (int)total;
+        r.best_scale = winner >= 0 ? 0 : -1;
+        r.best_rot = winner >= 0 ? winner + 1 : -1;
+        r.status = GMS_OK;
+        p.results[blockIdx.x] = r;
+    }
+    return true;
+}
+
+template <int KPT, bool ROT, int NT>
+__global__ void __launch_bounds__(NT)
+filter_kernel_dense(FilterParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    first_round_stagger(p);
+    if (!dense_pair<KPT, ROT, NT>(p, smem)) hash_pair<KPT, ROT, NT>(p, smem);
+}
+
 // Test hook: the threshold comparison in device fp64.
 __global__ void threshold_kernel(const int32_t* T, const int32_t* n, const int32_t* score, double factor,
                                  int count, uint8_t* out)
@@ -836,14 +1200,23 @@ static hipError_t launch_filter_t(const FilterParams& p, int n_pairs, size_t lds
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(filter_kernel<KPT, ROT, NT>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes);
         if (e != hipSuccess) return e;
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(filter_kernel_dense<KPT, ROT, NT>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes);
+        if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL((filter_kernel<KPT, ROT, NT>), dim3((unsigned)n_pairs), dim3(NT), lds_bytes, stream, p);
+    if (p.dense) {
+        const size_t lds = lds_bytes > kDenseLdsBytes ? lds_bytes : (size_t)kDenseLdsBytes;
+        hipLaunchKernelGGL((filter_kernel_dense<KPT, ROT, NT>), dim3((unsigned)n_pairs), dim3(NT), lds, stream, p);
+    } else {
+        hipLaunchKernelGGL((filter_kernel<KPT, ROT, NT>), dim3((unsigned)n_pairs), dim3(NT), lds_bytes, stream, p);
+    }
     return hipGetLastError();
 }
 
 // kpt = matches per thread of the 1024-thread workgroup. (A 512-thread build with twice the matches per thread and
 // twice the matches in flight was measured 27 % slower at 10k matches: the kernel wants waves, not registers.)
+// p.dense selects the kernel that tries the byte-matrix path first (only meaningful without scale hypotheses).
 hipError_t launch_filter(const FilterParams& p, int kpt, int n_pairs, hipStream_t stream)
 {
     if (n_pairs <= 0) return hipSuccess;
