@@ -810,10 +810,11 @@ filter_kernel(FilterParams p)
 constexpr uint32_t kDenseBytes = 160000u;                       // 400 left cells x (<= 400 right cells) x 1 byte
 constexpr uint32_t kDenseHdrOff = kDenseBytes;                  // [400] dwords
 constexpr uint32_t kDenseFineOff = kDenseHdrOff + 4u * kLeftN;  // [1600] bytes
-constexpr uint32_t kDenseMiscOff = kDenseFineOff + kFineN;      // [48] dwords: [0..7] rotation counts, [8] domain error,
-                                                                //   [9] carry, [11] not eligible, [16..] scan scratch
-constexpr uint32_t kDenseTrashOff = kDenseMiscOff + 4u * 48u;   // [32] dwords: [0..15] add sinks, [16..31] min sinks
-constexpr uint32_t kDenseLdsBytes = kDenseTrashOff + 4u * 32u;  // 163 520
+constexpr uint32_t kDenseNleftOff = kDenseFineOff + kFineN;     // [400] bytes: nLeft of every cell under the current grid type
+constexpr uint32_t kDenseMiscOff = kDenseNleftOff + kLeftN;     // [32] dwords: [0..7] rotation counts, [8] domain error,
+                                                                //   [9] carry, [11] not eligible, [16..31] scan scratch
+constexpr uint32_t kDenseTrashOff = kDenseMiscOff + 4u * 32u;   // [16] dwords: [0..7] add sinks, [8..15] min sinks
+constexpr uint32_t kDenseLdsBytes = kDenseTrashOff + 4u * 16u;  // 163 792
 static_assert(kDenseLdsBytes <= kLdsBytes, "dense layout exceeds the LDS");
 
 // dense code word: right cell : 11 | hx : 6 | hy : 6 | rotation bits : 8 (hx = hy = 63: never binned)
@@ -857,7 +858,9 @@ __device__ __forceinline__ bool dense_pair(const FilterParams& p, uint32_t* smem
     const int nA = (int)(p.frame_off[pr.frame_a + 1] - offA), nB = (int)(p.frame_off[pr.frame_b + 1] - offB);
     const int wr = p.right_w[0], hr = p.right_h[0];
     const uint32_t nr = (uint32_t)(wr * hr);
-    if (nA <= 0 || nB <= 0 || (uint32_t)nB * 8u > kDenseBytes || nr == 0 || nr * (uint32_t)kLeftN > kDenseBytes) return false;
+    if (nA <= 0 || nB <= 0 || (uint32_t)nB * 8u > kDenseBytes || wr <= 0 || hr <= 0 || wr > 64 || hr > 64 ||
+        nr * (uint32_t)kLeftN > kDenseBytes)
+        return false;
     const float2* __restrict__ ptsA = p.pts + offA;
     const float2* __restrict__ ptsB = p.pts + offB;
     const gms_dmatch* __restrict__ matches = p.matches + pr.match_off;
@@ -866,11 +869,13 @@ __device__ __forceinline__ bool dense_pair(const FilterParams& p, uint32_t* smem
     uint32_t* hdr = smem + kDenseHdrOff / 4;        // row arg-max ((255 - count) << 11 | right cell, atomicMin), then cellPairs
     uint32_t* nfine32 = smem + kDenseFineOff / 4;   // 40 x 40 byte counters, four to a dword
     const uint8_t* nfine8 = reinterpret_cast<const uint8_t*>(nfine32);
+    uint8_t* nleft8 = reinterpret_cast<uint8_t*>(smem) + kDenseNleftOff;
     uint32_t* misc = smem + kDenseMiscOff / 4;
     uint32_t* trash = smem + kDenseTrashOff / 4;
 
-    if (tid < 48) misc[tid] = 0;
-    if (tid < 32) trash[tid] = 0;
+    GMS_STAMP_DECL
+    if (tid < 32) misc[tid] = 0;
+    if (tid < 16) trash[tid] = 0;
     if (tid < kFineN / 4) nfine32[tid] = 0;
 
     // ---- the pair's DMatch records, whole (they stay in registers until copy-out), and frame B staged in the
@@ -881,6 +886,10 @@ __device__ __forceinline__ bool dense_pair(const FilterParams& p, uint32_t* smem
     float2* lds_b = reinterpret_cast<float2*>(smem);
     for (int j = tid; j < nB; j += NT) lds_b[j] = ptsB[j];
     __syncthreads();
+#ifdef GMS_PHASE_TIMING
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    GMS_STAMP(4);  // bin: records landed, frame B staged
+#endif
 
     uint32_t code[KPT];
     {
@@ -889,6 +898,10 @@ __device__ __forceinline__ bool dense_pair(const FilterParams& p, uint32_t* smem
         for (int k = 0; k < KPT; ++k) a[k] = ptsA[min(rec[k].x, (uint32_t)(nA - 1))];
 #pragma unroll
         for (int k = 0; k < KPT; ++k) b[k] = lds_b[min(rec[k].y, (uint32_t)(nB - 1))];
+#ifdef GMS_PHASE_TIMING
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        GMS_STAMP(12);  // bin: gathers landed
+#endif
         const float fwr = (float)wr, fhr = (float)hr;
         bool any_bad = false, spill = false;
 #pragma unroll
@@ -903,7 +916,7 @@ __device__ __forceinline__ bool dense_pair(const FilterParams& p, uint32_t* smem
             const bool binned = live && ok && hx < 40u && hy < 40u;
             const uint32_t f = binned ? hy * kFineW + hx : 0u;
             const uint32_t fs = (f & 3u) << 3;
-            const uint32_t old = atomicAdd(binned ? &nfine32[f >> 2] : &trash[lane & 15], 1u << fs);
+            const uint32_t old = atomicAdd(binned ? &nfine32[f >> 2] : &trash[lane & 7], 1u << fs);
             spill |= binned && ((old >> fs) & 255u) == 255u;  // the byte wrapped: more than 255 in one half cell
             any_bad |= live && !ok;
             code[k] = binned ? (r | (hx << kDHxShift) | (hy << kDHyShift)) : kDNever;
@@ -911,17 +924,14 @@ __device__ __forceinline__ bool dense_pair(const FilterParams& p, uint32_t* smem
         if (any_bad) misc[8] = 1;   // benign races: every writer stores 1
         if (spill) misc[11] = 1;
     }
+    GMS_STAMP(13);    // bin: codes + half-cell histogram
     __syncthreads();  // histogram complete; every read of the staged frame is done
-
-    // a left cell above 255 matches under any grid type: not representable
-    for (int item = tid; item < 4 * kLeftN; item += NT) {
-        const int g = item / kLeftN, cell = item - g * kLeftN;
-        if (dense_nleft(nfine8, cell % kLeftW, cell / kLeftW, g & 1, g >> 1) > 255u) misc[11] = 1;
-    }
+    GMS_STAMP(0);     // bin: wait for the other waves
 
     const bool thr_fast = threshold_fast_ok(p.threshold_factor);
     const uint32_t clear_n = 25u * nr;  // uint4s in 400 rows of nr bytes
-    const uint32_t trash_add = kDenseTrashOff + (uint32_t)((lane & 15) << 2), trash_min = trash_add + 64u;
+    const uint32_t trash_add = kDenseTrashOff + (uint32_t)((lane & 7) << 2), trash_min = trash_add + 32u;
+    const uint32_t wr_magic = 65535u / (uint32_t)wr + 1u;  // j / wr == (j * magic) >> 16 for j * wr < 65536
     for (int g = 0; g < 4; ++g) {
         const int gx = g & 1, gy = g >> 1;
         // ---- motion.setTo(0); row headers back to "no arg-max yet"
@@ -929,10 +939,17 @@ __device__ __forceinline__ bool dense_pair(const FilterParams& p, uint32_t* smem
             const uint4 z4 = make_uint4(0, 0, 0, 0);
             uint4* d4 = reinterpret_cast<uint4*>(smem);
             for (uint32_t i = tid; i < clear_n; i += NT) d4[i] = z4;
-            if (tid < kLeftN) hdr[tid] = kEmpty;
+            if (tid < kLeftN) {
+                hdr[tid] = kEmpty;
+                // nLeft of this grid type, once per cell; above 255 the byte matrix cannot hold the cell's row
+                const uint32_t n = dense_nleft(nfine8, tid % kLeftW, tid / kLeftW, gx, gy);
+                if (n > 255u) misc[11] = 1;
+                nleft8[tid] = (uint8_t)n;
+            }
         }
         __syncthreads();
-        if (g == 0 && (misc[8] | misc[11]) != 0) {  // workgroup-uniform
+        GMS_STAMP(2);  // clear
+        if ((misc[8] | misc[11]) != 0) {  // workgroup-uniform; nothing has been written to global memory yet
             __syncthreads();                        // everybody has read the flags before the general path reuses the LDS
             return false;
         }
@@ -960,7 +977,9 @@ __device__ __forceinline__ bool dense_pair(const FilterParams& p, uint32_t* smem
                 atomicMin(lds_at(smem, hoff[c]), ((254u - before) << 11) | (code[k0 + c] & kRMask));
             }
         }
+        GMS_STAMP(3);  // insert
         __syncthreads();
+        GMS_STAMP(11);  // insert: wait for the other waves
 
         // ---- verifyCellPairs. Without rotation: two lanes per left cell, four neighbours each, joined by one DPP
         //      exchange; with rotation: one lane per (cell, rotation).
@@ -972,10 +991,10 @@ __device__ __forceinline__ bool dense_pair(const FilterParams& p, uint32_t* smem
                 const int rot = ROT ? (item & 7) : 0;
                 const int half = item & 1;  // !ROT only
                 const int ix = i % kLeftW, iy = i / kLeftW;
-                const uint32_t ni = live ? dense_nleft(nfine8, ix, iy, gx, gy) : 0u;
+                const uint32_t ni = live ? nleft8[i] : 0u;
                 const uint32_t best = hdr[i];                // ((255 - max count) << 11) | j*, lowest j* among maxima
                 const int j = ni ? (int)(best & kRMask) : 0;
-                const int jx = j % wr, jy = j / wr;
+                const int jy = (int)(((uint32_t)j * wr_magic) >> 16), jx = j - jy * wr;
                 uint32_t score = 0, tn = 0;  // tn = (sum of nLeft << 4) | numpair
 #pragma unroll
                 for (int h = 0; h < (ROT ? 8 : 4); h += 4) {
@@ -998,9 +1017,9 @@ __device__ __forceinline__ bool dense_pair(const FilterParams& p, uint32_t* smem
                         const int rx = jx + rdx, ry = jy + rdy;
                         const bool okl = ni != 0 && (uint32_t)lx < (uint32_t)kLeftW && (uint32_t)ly < (uint32_t)kLeftH;  // ll != -1
                         const bool okp = okl && (uint32_t)rx < (uint32_t)wr && (uint32_t)ry < (uint32_t)hr;             // rr != -1
-                        const int cx = okl ? lx : 0, cy = okl ? ly : 0;
-                        const uint32_t nll = dense_nleft(nfine8, cx, cy, gx, gy);
-                        const uint32_t cnt = dense8[(uint32_t)(cx + cy * kLeftW) * nr + (okp ? (uint32_t)(rx + ry * wr) : 0u)];
+                        const uint32_t ll = okl ? (uint32_t)(lx + ly * kLeftW) : 0u;
+                        const uint32_t nll = nleft8[ll];
+                        const uint32_t cnt = dense8[ll * nr + (okp ? (uint32_t)(rx + ry * wr) : 0u)];
                         score += okp ? cnt : 0u;
                         tn += okp ? ((nll << 4) | 1u) : 0u;
                     }
@@ -1026,6 +1045,7 @@ __device__ __forceinline__ bool dense_pair(const FilterParams& p, uint32_t* smem
             }
         }
         __syncthreads();
+        GMS_STAMP(5);  // verify
 
         // ---- mark inliers: cellPairs[l] == r, all rotations at once
         {
@@ -1044,6 +1064,7 @@ __device__ __forceinline__ bool dense_pair(const FilterParams& p, uint32_t* smem
                 if (valid[k] && (cr[k] >> 8) == (code[k] & kRMask)) code[k] |= (cr[k] & 0xFFu) << kDAccShift;
         }
         __syncthreads();  // hdr is cleared next; after the last grid type the matrix area is reused below
+        GMS_STAMP(6);  // mark
     }
 
     // ---- run() return value per rotation, getInlierMask's strict '>' over the rotations (one scale)
@@ -1087,6 +1108,7 @@ __device__ __forceinline__ bool dense_pair(const FilterParams& p, uint32_t* smem
         }
     }
     __syncthreads();
+    GMS_STAMP(7);  // count + select
 
     // ---- copy-out: surviving DMatch verbatim, in input order (DLL@0x180048340), from the registers
     for (int base = 0; base < n_chunks; base += NT) {
@@ -1108,6 +1130,7 @@ __device__ __forceinline__ bool dense_pair(const FilterParams& p, uint32_t* smem
         __syncthreads();
     }
     const uint32_t total = misc[9];
+    GMS_STAMP(8);  // out scan
     gms_dmatch* __restrict__ out = p.out + pr.match_off;
     uint8_t* mask_out = p.mask ? p.mask + pr.match_off : nullptr;
 #pragma unroll
@@ -1124,6 +1147,8 @@ __device__ __forceinline__ bool dense_pair(const FilterParams& p, uint32_t* smem
             }
         }
     }
+    GMS_STAMP(9);  // copy-out
+    GMS_STAMP_FLUSH;
     if (tid == 0) {
         gms_pair_result r;
         r.n_inliers = (int)total;

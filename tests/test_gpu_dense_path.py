@@ -1,0 +1,134 @@
+"""-m gpu: the byte-matrix fast path of the filter (no scale hypotheses, every left cell <= 255 matches) and the
+hand-over to the hashed path on the other side of each of its limits, against the CPU oracle, bit-exact. The cases
+sit right at the limits: 255 / 256 matches in a cell of the unshifted grid, in a cell that only exists under a shifted
+grid type, in one half cell (the byte histogram wraps at 256), one matrix entry reaching 255, a frame too large to
+stage, and eligible and ineligible pairs side by side in one launch."""
+import importlib
+
+import numpy as np
+import pytest
+
+import cases
+
+pytestmark = pytest.mark.gpu
+
+W, H = 2000, 1000  # 100 x 50 pixels per left cell
+
+
+def _blob(rng, cx, cy, n, half_w=0.2, half_h=0.2):
+    """n points around (cx, cy), in units of left cells."""
+    return np.stack([(cx + rng.uniform(-half_w, half_w, n)) * W / 20.0, (cy + rng.uniform(-half_h, half_h, n)) * H / 20.0], axis=1)
+
+
+def _case(groups, seed=5, background=True, shuffle=True):
+    """groups: [(left (cx, cy) in cells, right (cx, cy) in cells, n, half extents)], plus an identity background of
+    coherent matches (so that cells pass the threshold) and a little noise."""
+    rng = np.random.default_rng(seed)
+    left, right = [], []
+    for (lc, rc, n, ext) in groups:
+        left.append(_blob(rng, lc[0], lc[1], n, *ext))
+        right.append(_blob(rng, rc[0], rc[1], n, *ext))
+    if background:
+        for cy in range(2, 18):
+            for cx in range(2, 18):
+                n = int(rng.integers(8, 24))
+                d = rng.uniform(-0.45, 0.45, (n, 2))
+                left.append(np.stack([(cx + 0.5 + d[:, 0]) * W / 20.0, (cy + 0.5 + d[:, 1]) * H / 20.0], axis=1))
+                right.append(left[-1] + rng.uniform(-3, 3, (n, 2)))
+        left.append(np.stack([rng.uniform(0, W - 1, 400), rng.uniform(0, H - 1, 400)], axis=1))
+        right.append(np.stack([rng.uniform(0, W - 1, 400), rng.uniform(0, H - 1, 400)], axis=1))
+    xy1 = np.clip(np.concatenate(left), 0, [W - 0.01, H - 0.01]).astype(np.float32)
+    xy2 = np.clip(np.concatenate(right), 0, [W - 0.01, H - 0.01]).astype(np.float32)
+    idx = np.arange(len(xy1))
+    c = cases._pair(xy1, xy2, idx, idx, (W, H), (W, H))
+    if shuffle:
+        c["matches"] = c["matches"][rng.permutation(len(idx))]
+    return c
+
+
+def _check(ctx, oracle, c, rot, scale=False, thr=6.0):
+    got, res = ctx.match(c["size1"], c["size2"], c["kp1"], c["kp2"], c["matches"], rot, scale, thr, return_result=True)
+    rc, want, _, wres = oracle.match(c["size1"], c["size2"], c["kp1"], c["kp2"], c["matches"], rot, scale, thr)
+    assert rc == 0
+    assert got.tobytes() == want.tobytes(), (len(got), len(want), res, wres)
+    assert (res["n_inliers"], res["best_scale"], res["best_rot"]) == (wres["n_inliers"], wres["best_scale"], wres["best_rot"])
+    return len(got)
+
+
+TIGHT = (0.2, 0.2)       # stays inside one quarter of a cell when centred on x.25 / x.75
+CELL = (0.45, 0.45)      # spread over the whole unshifted cell
+
+
+@pytest.mark.parametrize("rot", [False, True])
+@pytest.mark.parametrize("n", [254, 255, 256, 257, 400])
+def test_cell_population_at_the_byte_limit(ctx, oracle, n, rot):
+    """One cell of the unshifted grid with n matches (the background leaves cells 0 and 1 of the grid empty)."""
+    kept = _check(ctx, oracle, _case([((0.5, 0.5), (3.5, 7.5), n, CELL)], background=True), rot)
+    assert kept >= n  # the crowded cell itself passes: its n coherent matches are kept
+
+
+@pytest.mark.parametrize("n", [127, 128, 200])
+def test_cell_that_only_a_shifted_grid_type_overfills(ctx, oracle, n):
+    """Two neighbouring unshifted cells hold n matches each in their facing halves: every cell of grid type 1 stays
+    at n <= 255, the grid-type-2 cell across the border holds 2n."""
+    groups = [((0.75, 0.5), (5.75, 9.5), n, (0.2, 0.4)), ((1.25, 0.5), (6.25, 9.5), n, (0.2, 0.4))]
+    _check(ctx, oracle, _case(groups), False)
+    _check(ctx, oracle, _case(groups), True)
+
+
+@pytest.mark.parametrize("n", [255, 256, 300, 513, 1030])
+def test_half_cell_histogram_wrap(ctx, oracle, n):
+    """n matches inside ONE half cell: the byte histogram wraps at 256 (and again at 512, 768, 1024); a wrapped pair must
+    still be recognised as not representable."""
+    _check(ctx, oracle, _case([((0.25, 0.25), (10.25, 10.25), n, TIGHT)]), False)
+
+
+def test_one_matrix_entry_reaches_255(ctx, oracle):
+    """255 matches from one left cell into one right cell: the byte of that entry ends at its maximum, and the row's
+    arg-max key at (255 - 255) << 11."""
+    c = _case([((0.5, 0.5), (12.5, 3.5), 255, (0.3, 0.3))], background=True)
+    kept = _check(ctx, oracle, c, False)
+    assert kept >= 255
+
+
+def test_all_matches_in_the_last_half_cell(ctx, oracle):
+    """Points with x, y in the last half cell: binned under grid type 1 only (x >= 20 || y >= 20 elsewhere)."""
+    _check(ctx, oracle, _case([((19.8, 19.8), (19.8, 19.8), 200, (0.15, 0.15))], background=False), False)
+    _check(ctx, oracle, _case([((19.8, 5.5), (19.8, 5.5), 200, (0.15, 0.3)), ((5.5, 19.8), (5.5, 19.8), 200, (0.3, 0.15))]), True)
+
+
+def test_frame_too_large_to_stage(ctx, oracle):
+    """Frame B with more keypoints than the matrix area can stage (20 000): handed to the general path."""
+    rng = np.random.default_rng(9)
+    n2, m = 20500, 6000
+    xy2 = np.stack([rng.uniform(0, W - 1, n2), rng.uniform(0, H - 1, n2)], axis=1).astype(np.float32)
+    train = rng.permutation(n2)[:m]
+    xy1 = np.clip(xy2[train] + rng.uniform(-2, 2, (m, 2)), 0, [W - 0.01, H - 0.01]).astype(np.float32)
+    xy1[m // 2:] = np.stack([rng.uniform(0, W - 1, m - m // 2), rng.uniform(0, H - 1, m - m // 2)], axis=1)
+    c = cases._pair(xy1, xy2, np.arange(m), train, (W, H), (W, H))
+    assert _check(ctx, oracle, c, False) > 1000
+
+
+def test_eligible_and_ineligible_pairs_share_a_launch(ctx, oracle):
+    """A batch whose pairs alternate between the byte-matrix path and the general path (a 300-match cell)."""
+    batch = importlib.import_module("sfm-gms_amd.batch")
+    types = importlib.import_module("sfm-gms_amd.types")
+    cs = []
+    for i in range(12):
+        groups = [((0.5, 0.5), (3.5 + i, 7.5), 300 if i % 3 == 1 else 40 + i, CELL)]
+        cs.append(_case(groups, seed=20 + i))
+    frames = batch.FrameTable(ctx, [c["kp1"] for c in cs] + [c["kp2"] for c in cs], [c["size1"] for c in cs] + [c["size2"] for c in cs])
+    pairs = np.zeros(len(cs), dtype=types.PAIR_DTYPE)
+    off = 0
+    for i, c in enumerate(cs):
+        pairs[i]["frame_a"], pairs[i]["frame_b"], pairs[i]["m"], pairs[i]["match_off"] = i, len(cs) + i, len(c["matches"]), off
+        off += len(c["matches"])
+    matches = np.concatenate([c["matches"] for c in cs])
+    for rot in (False, True):
+        out, results, mask = batch.filter_pairs(ctx, frames, pairs, matches, rot, False, 6.0)
+        for i, c in enumerate(cs):
+            rc, want, wmask, wres = oracle.match(c["size1"], c["size2"], c["kp1"], c["kp2"], c["matches"], rot, False, 6.0)
+            o, k = int(pairs[i]["match_off"]), int(results[i]["n_inliers"])
+            assert rc == 0 and results[i]["status"] == 0 and k == wres["n_inliers"] and results[i]["best_rot"] == wres["best_rot"]
+            assert out[o:o + k].tobytes() == want.tobytes()
+            assert np.array_equal(mask[o:o + len(c["matches"])], np.asarray(wmask, dtype=np.uint8))
