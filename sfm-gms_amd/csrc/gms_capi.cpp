@@ -195,13 +195,13 @@ int gms_filter_device(gms_ctx* c, const float* d_pts, const int64_t* d_frame_off
         return e ? std::atoi(e) : 0;
     }();
     p.prefetch_stride = prefetch_stride;
-    // GMS_STAGGER_US: spread of the first dispatch round's start times (0 turns it off)
+    // GMS_STAGGER_US: spread of the first dispatch round's start times (0 turns it off); by default about one
+    // pair's duration at the benchmark shape on the path the launch will mostly take
     static const int stagger_us = [] {
         const char* e = std::getenv("GMS_STAGGER_US");
-        return e ? std::atoi(e) : 72;
+        return e ? std::atoi(e) : -1;
     }();
     p.stagger_blocks = 256;
-    p.stagger_cycles = (n_pairs >= 4 * p.stagger_blocks) ? stagger_us * 2400 : 0;
     p.matches = d_matches;
     p.out = d_out;
     p.results = d_results;
@@ -217,6 +217,7 @@ int gms_filter_device(gms_ctx* c, const float* d_pts, const int64_t* d_frame_off
         return !e || std::atoi(e) != 0;
     }();
     p.dense = (dense_on && !with_scale) ? 1 : 0;
+    p.stagger_cycles = (n_pairs >= 4 * p.stagger_blocks) ? (stagger_us >= 0 ? stagger_us : (p.dense ? 36 : 72)) * 2400 : 0;
 #ifdef GMS_PHASE_TIMING
     p.diag = g_diag;
 #endif

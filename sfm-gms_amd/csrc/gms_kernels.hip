@@ -794,32 +794,47 @@ filter_kernel(FilterParams p)
 // ------------------------------------------------------------------------------------------------
 // The dense path: pairs whose motion matrix fits the LDS as BYTES.
 //
-// Without scale hypotheses the right grid is 20 x 20, so the reference's 400 x 400 matrix is 160 000 entries; an
-// entry never exceeds the number of matches of its left cell, so when no left cell (of any grid type) holds more
-// than 255 matches the whole matrix fits the CU's LDS as one byte per entry -- 160 000 of the 163 840 bytes.
-// assignMatchPairs then is one returning LDS atomic per match (+1 on the entry's byte; the value it returns
-// is the count this match produced, folded into the row's running arg-max with one atomicMin as in the hashed
-// path) and verifyCellPairs reads neighbour counts directly: no hashing, no bucket scans, no probe chains --
-// about a quarter of the hashed path's instructions per match. Everything else has to live in the remaining
-// 3.8 KB: the half-cell histogram as bytes, one header dword per left cell (arg-max while binning, cellPairs
-// after verification), the rotation counters and 32 dwords of sinks. The surviving DMatch records are kept in
-// registers from the first load, so the match array is read exactly once.
-// A pair that does not qualify (a cell above 255 matches, a frame too large to stage, any input outside the
-// parity domain, scale hypotheses) is handed to hash_pair() by the same workgroup; results are identical.
+// Without scale hypotheses the right grid is 20 x 20, so the reference's motion matrix is 400 x 400; an entry never
+// exceeds the number of matches of its left cell, so when no left cell (of any grid type) holds more than 255
+// matches the whole matrix fits the CU's LDS as one byte per entry -- 160 000 of the 163 840 bytes.
+// assignMatchPairs then is one returning LDS atomic per match (+1 on the entry's byte; the value it returns is the
+// count this match produced, folded into the row's running arg-max with one atomicMax) and verifyCellPairs reads
+// neighbour counts directly: no hashing, no bucket scans, no probe chains. The kernel is VALU-issue bound (16
+// cycles of a SIMD per instruction of the 16-wave workgroup), so the per-match work is cut to the bone:
+//   * a row is [header dword | 400 count bytes], the byte of right cell r at offset E(r) = 403 - r; the header
+//     holds the running arg-max ((count - 1) << 11) | E(j) while binning (max = highest count, then lowest right
+//     cell: the reference's ascending scan with strict '>') and cellPairs after verification;
+//   * per match, two registers: the row start of its left cell under grid type 1, and a code word with E(r), the
+//     half-cell parities q = (hx & 1) + 20 (hy & 1) and three "not binned under ..." bits. The left cell under grid
+//     type g is l1 + (q & M_g), M_g = gx + 20 gy, so the row start is one multiply-add away;
+//   * the matrix is zeroed once per pair; after each grid type every match takes its own increment back
+//     (one non-returning atomic) instead of 160 KB being cleared again.
+// Everything else has to live in the remaining 2.2 KB: the half-cell histogram and the current grid type's nLeft as
+// bytes, the rotation counters and a few sink dwords. The DMatch records stay in registers from the first load to
+// copy-out, so the match array is read exactly once.
+// A pair that does not qualify (a cell above 255 matches, a frame too large to stage, any input outside the parity
+// domain, scale hypotheses) is handed to hash_pair() by the same workgroup; results are identical.
 // ------------------------------------------------------------------------------------------------
-constexpr uint32_t kDenseBytes = 160000u;                       // 400 left cells x (<= 400 right cells) x 1 byte
-constexpr uint32_t kDenseHdrOff = kDenseBytes;                  // [400] dwords
-constexpr uint32_t kDenseFineOff = kDenseHdrOff + 4u * kLeftN;  // [1600] bytes
+constexpr int kDenseRightW = 20, kDenseRightN = 400;            // right grid of scale 0: cvRound(20 * 1.0)
+constexpr uint32_t kDenseRow = 4u + kDenseRightN;               // header dword + one byte per right cell
+constexpr uint32_t kDenseBytes = kLeftN * kDenseRow;            // 161 600
+constexpr uint32_t kDenseFineOff = kDenseBytes;                 // [1600] bytes: half-cell histogram of the left points
 constexpr uint32_t kDenseNleftOff = kDenseFineOff + kFineN;     // [400] bytes: nLeft of every cell under the current grid type
 constexpr uint32_t kDenseMiscOff = kDenseNleftOff + kLeftN;     // [32] dwords: [0..7] rotation counts, [8] domain error,
                                                                 //   [9] carry, [11] not eligible, [16..31] scan scratch
-constexpr uint32_t kDenseTrashOff = kDenseMiscOff + 4u * 32u;   // [16] dwords: [0..7] add sinks, [8..15] min sinks
+constexpr uint32_t kDenseTrashOff = kDenseMiscOff + 4u * 32u;   // [16] dwords: sinks
 constexpr uint32_t kDenseLdsBytes = kDenseTrashOff + 4u * 16u;  // 163 792
 static_assert(kDenseLdsBytes <= kLdsBytes, "dense layout exceeds the LDS");
+static_assert(kDenseBytes % 16 == 0 && kDenseRow % 4 == 0, "rows are dword aligned, the matrix is cleared in uint4s");
 
-// dense code word: right cell : 11 | hx : 6 | hy : 6 | rotation bits : 8 (hx = hy = 63: never binned)
-constexpr int kDHxShift = 11, kDHyShift = 17, kDAccShift = 23;
-constexpr uint32_t kDNever = (63u << kDHxShift) | (63u << kDHyShift);
+// dense code word
+                                                     // bits 0..4   q = (hx & 1) + 20 * (hy & 1)
+constexpr uint32_t kDNever = 1u << 5;                // bit 5       not binned under any grid type
+constexpr uint32_t kDEdgeX = 1u << 6;                // bit 6       hx == 39: x >= 20 under the x-shifted grid types
+constexpr uint32_t kDEdgeY = 1u << 7;                // bit 7       hy == 39
+constexpr int kDEShift = 8;                          // bits 8..18  E(r) = 403 - r, the byte's offset in its row
+constexpr uint32_t kDEMask = 0x7FFu;
+constexpr int kDAccShift = 20;                       // bits 20..27 inlier-under-rotation bits
 
 // mNumberPointsInPerCellLeft of cell (x, y) under the grid type shifted by (gx, gy) half cells
 __device__ __forceinline__ uint32_t dense_nleft(const uint8_t* nfine8, int x, int y, int gx, int gy)
@@ -851,22 +866,17 @@ __device__ __forceinline__ bool dense_pair(const FilterParams& p, uint32_t* smem
 
     const gms_pair pr = p.pairs[blockIdx.x];
     const int m = pr.m;
-    if (p.with_scale || m <= 0 || m > kMcap || pr.frame_a < 0 || pr.frame_a >= p.n_frames || pr.frame_b < 0 ||
-        pr.frame_b >= p.n_frames)
+    if (p.with_scale || p.right_w[0] != kDenseRightW || p.right_h[0] != kDenseRightW || m <= 0 || m > kMcap ||
+        pr.frame_a < 0 || pr.frame_a >= p.n_frames || pr.frame_b < 0 || pr.frame_b >= p.n_frames)
         return false;
     const int64_t offA = p.frame_off[pr.frame_a], offB = p.frame_off[pr.frame_b];
     const int nA = (int)(p.frame_off[pr.frame_a + 1] - offA), nB = (int)(p.frame_off[pr.frame_b + 1] - offB);
-    const int wr = p.right_w[0], hr = p.right_h[0];
-    const uint32_t nr = (uint32_t)(wr * hr);
-    if (nA <= 0 || nB <= 0 || (uint32_t)nB * 8u > kDenseBytes || wr <= 0 || hr <= 0 || wr > 64 || hr > 64 ||
-        nr * (uint32_t)kLeftN > kDenseBytes)
-        return false;
+    if (nA <= 0 || nB <= 0 || (uint32_t)nB * 8u > kDenseBytes) return false;
     const float2* __restrict__ ptsA = p.pts + offA;
     const float2* __restrict__ ptsB = p.pts + offB;
     const gms_dmatch* __restrict__ matches = p.matches + pr.match_off;
 
-    uint8_t* dense8 = reinterpret_cast<uint8_t*>(smem);
-    uint32_t* hdr = smem + kDenseHdrOff / 4;        // row arg-max ((255 - count) << 11 | right cell, atomicMin), then cellPairs
+    const uint8_t* dense8 = reinterpret_cast<const uint8_t*>(smem);
     uint32_t* nfine32 = smem + kDenseFineOff / 4;   // 40 x 40 byte counters, four to a dword
     const uint8_t* nfine8 = reinterpret_cast<const uint8_t*>(nfine32);
     uint8_t* nleft8 = reinterpret_cast<uint8_t*>(smem) + kDenseNleftOff;
@@ -891,7 +901,7 @@ __device__ __forceinline__ bool dense_pair(const FilterParams& p, uint32_t* smem
     GMS_STAMP(4);  // bin: records landed, frame B staged
 #endif
 
-    uint32_t code[KPT];
+    uint32_t code[KPT], row1[KPT];  // row1: byte offset of the left cell's row under grid type 1
     {
         float2 a[KPT], b[KPT];
 #pragma unroll
@@ -902,24 +912,26 @@ __device__ __forceinline__ bool dense_pair(const FilterParams& p, uint32_t* smem
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         GMS_STAMP(12);  // bin: gathers landed
 #endif
-        const float fwr = (float)wr, fhr = (float)hr;
         bool any_bad = false, spill = false;
 #pragma unroll
         for (int k = 0; k < KPT; ++k) {
             const bool live = k * NT + tid < m;
+            // parity domain: coordinates finite, non-negative, < 2^20 (one unsigned compare on the bit patterns)
             const uint32_t worst = max(max(__float_as_uint(a[k].x), __float_as_uint(a[k].y)),
                                        max(__float_as_uint(b[k].x), __float_as_uint(b[k].y)));
             const float fx = 20.0f * a[k].x, fy = 20.0f * a[k].y;   // mulss, rounded to fp32
-            const uint32_t hx = (uint32_t)(int)(fx + fx), hy = (uint32_t)(int)(fy + fy);
-            const uint32_t r = (uint32_t)((int)(fwr * b[k].x) + (int)(fhr * b[k].y) * wr);
-            const bool ok = rec[k].x < (uint32_t)nA && rec[k].y < (uint32_t)nB && worst < 0x49800000u && r < nr;
+            const uint32_t hx = (uint32_t)(int)(fx + fx), hy = (uint32_t)(int)(fy + fy);  // floor(2f), 2f exact
+            const uint32_t r = (uint32_t)((int)(20.0f * b[k].x) + (int)(20.0f * b[k].y) * kDenseRightW);
+            const bool ok = rec[k].x < (uint32_t)nA && rec[k].y < (uint32_t)nB && worst < 0x49800000u && r < (uint32_t)kDenseRightN;
             const bool binned = live && ok && hx < 40u && hy < 40u;
             const uint32_t f = binned ? hy * kFineW + hx : 0u;
-            const uint32_t fs = (f & 3u) << 3;
-            const uint32_t old = atomicAdd(binned ? &nfine32[f >> 2] : &trash[lane & 7], 1u << fs);
-            spill |= binned && ((old >> fs) & 255u) == 255u;  // the byte wrapped: more than 255 in one half cell
+            const uint32_t old = atomicAdd(binned ? &nfine32[f >> 2] : &trash[lane & 7], 1u << ((f & 3u) << 3));
+            spill |= binned && ((old >> ((f & 3u) << 3)) & 255u) == 255u;  // the byte wrapped: > 255 in one half cell
             any_bad |= live && !ok;
-            code[k] = binned ? (r | (hx << kDHxShift) | (hy << kDHyShift)) : kDNever;
+            const uint32_t q = (hx & 1u) + 20u * (hy & 1u);
+            const uint32_t edge = (hx == 39u ? kDEdgeX : 0u) | (hy == 39u ? kDEdgeY : 0u);
+            code[k] = binned ? (q | edge | ((uint32_t)(kDenseRightN + 3) - r) << kDEShift) : kDNever;
+            row1[k] = binned ? ((hy >> 1) * kLeftW + (hx >> 1)) * kDenseRow : 0u;
         }
         if (any_bad) misc[8] = 1;   // benign races: every writer stores 1
         if (spill) misc[11] = 1;
@@ -928,53 +940,51 @@ __device__ __forceinline__ bool dense_pair(const FilterParams& p, uint32_t* smem
     __syncthreads();  // histogram complete; every read of the staged frame is done
     GMS_STAMP(0);     // bin: wait for the other waves
 
+    // ---- motion.setTo(0), once: from here on every grid type leaves the matrix as it found it
+    {
+        const uint4 z4 = make_uint4(0, 0, 0, 0);
+        uint4* d4 = reinterpret_cast<uint4*>(smem);
+        for (uint32_t i = tid; i < kDenseBytes / 16; i += NT) d4[i] = z4;
+    }
+
     const bool thr_fast = threshold_fast_ok(p.threshold_factor);
-    const uint32_t clear_n = 25u * nr;  // uint4s in 400 rows of nr bytes
-    const uint32_t trash_add = kDenseTrashOff + (uint32_t)((lane & 7) << 2), trash_min = trash_add + 32u;
-    const uint32_t wr_magic = 65535u / (uint32_t)wr + 1u;  // j / wr == (j * magic) >> 16 for j * wr < 65536
     for (int g = 0; g < 4; ++g) {
         const int gx = g & 1, gy = g >> 1;
-        // ---- motion.setTo(0); row headers back to "no arg-max yet"
-        {
-            const uint4 z4 = make_uint4(0, 0, 0, 0);
-            uint4* d4 = reinterpret_cast<uint4*>(smem);
-            for (uint32_t i = tid; i < clear_n; i += NT) d4[i] = z4;
-            if (tid < kLeftN) {
-                hdr[tid] = kEmpty;
-                // nLeft of this grid type, once per cell; above 255 the byte matrix cannot hold the cell's row
-                const uint32_t n = dense_nleft(nfine8, tid % kLeftW, tid / kLeftW, gx, gy);
-                if (n > 255u) misc[11] = 1;
-                nleft8[tid] = (uint8_t)n;
-            }
+        const uint32_t q_mask = (uint32_t)(gx + 20 * gy);                                 // l = l1 + (q & q_mask)
+        const uint32_t out_mask = kDNever | (gx ? kDEdgeX : 0u) | (gy ? kDEdgeY : 0u);    // x >= 20 || y >= 20 -> -1 (DLL@0x180047d3d)
+        if (tid < kLeftN) {
+            if (g > 0) smem[tid * (kDenseRow / 4)] = 0;  // row header back to "no arg-max yet"
+            // nLeft of this grid type, once per cell; above 255 the byte matrix cannot hold the cell's row
+            const uint32_t n = dense_nleft(nfine8, tid % kLeftW, tid / kLeftW, gx, gy);
+            if (n > 255u) misc[11] = 1;
+            nleft8[tid] = (uint8_t)n;
         }
         __syncthreads();
-        GMS_STAMP(2);  // clear
+        GMS_STAMP(2);  // clear / reset
         if ((misc[8] | misc[11]) != 0) {  // workgroup-uniform; nothing has been written to global memory yet
-            __syncthreads();                        // everybody has read the flags before the general path reuses the LDS
+            __syncthreads();              // everybody has read the flags before the general path reuses the LDS
             return false;
         }
 
-        // ---- assignMatchPairs: motion[l][r]++ on the byte, the produced count into the row's arg-max
+        // ---- assignMatchPairs: motion[l][r]++ on the byte; the count it produced goes into the row's arg-max
 #pragma unroll
         for (int k0 = 0; k0 < KPT; k0 += kChunk) {
-            uint32_t old[kChunk], sh[kChunk], hoff[kChunk];
+            uint32_t old[kChunk], at[kChunk], row[kChunk];
 #pragma unroll
             for (int c = 0; c < kChunk; ++c) {
                 const uint32_t cw = code[k0 + c];
-                const uint32_t lx = (((cw >> kDHxShift) & 63u) + (uint32_t)gx) >> 1;
-                const uint32_t ly = (((cw >> kDHyShift) & 63u) + (uint32_t)gy) >> 1;
-                const bool valid = max(lx, ly) < (uint32_t)kLeftW;  // x >= 20 || y >= 20 -> -1 (DLL@0x180047d3d)
-                const uint32_t l = __umul24(ly, (uint32_t)kLeftW) + lx;
-                const uint32_t a = __umul24(l, nr) + (cw & kRMask);
-                sh[c] = (a & 3u) << 3;
-                old[c] = atomicAdd(lds_at(smem, valid ? (a & ~3u) : trash_add), 1u << sh[c]);
-                hoff[c] = valid ? kDenseHdrOff + (l << 2) : trash_min;
+                row[c] = __umul24(cw & q_mask, kDenseRow) + row1[k0 + c];
+                at[c] = row[c] + ((cw >> kDEShift) & kDEMask);
+                old[c] = 0;
+                // shift counts are taken modulo 32: at << 3 selects the byte (at & 3)
+                if ((cw & out_mask) == 0) old[c] = atomicAdd(lds_at(smem, at[c] & ~3u), 1u << ((at[c] << 3) & 31u));
             }
             __builtin_amdgcn_sched_barrier(0);  // all of the chunk's atomics are issued before any result is read
 #pragma unroll
             for (int c = 0; c < kChunk; ++c) {
-                const uint32_t before = (old[c] >> sh[c]) & 255u;  // <= 254 on every binned match
-                atomicMin(lds_at(smem, hoff[c]), ((254u - before) << 11) | (code[k0 + c] & kRMask));
+                const uint32_t cw = code[k0 + c];
+                const uint32_t before = (old[c] >> ((at[c] << 3) & 31u)) & 255u;  // <= 254
+                if ((cw & out_mask) == 0) atomicMax(lds_at(smem, row[c]), (before << 11) | ((cw >> kDEShift) & kDEMask));
             }
         }
         GMS_STAMP(3);  // insert
@@ -992,9 +1002,10 @@ __device__ __forceinline__ bool dense_pair(const FilterParams& p, uint32_t* smem
                 const int half = item & 1;  // !ROT only
                 const int ix = i % kLeftW, iy = i / kLeftW;
                 const uint32_t ni = live ? nleft8[i] : 0u;
-                const uint32_t best = hdr[i];                // ((255 - max count) << 11) | j*, lowest j* among maxima
-                const int j = ni ? (int)(best & kRMask) : 0;
-                const int jy = (int)(((uint32_t)j * wr_magic) >> 16), jx = j - jy * wr;
+                const uint32_t best = smem[i * (kDenseRow / 4)];  // ((max count - 1) << 11) | E(j*), lowest j* among maxima
+                const uint32_t ej = ni ? (best & kDEMask) : (uint32_t)(kDenseRightN + 3);
+                const int j = kDenseRightN + 3 - (int)ej;
+                const int jx = j % kDenseRightW, jy = j / kDenseRightW;
                 uint32_t score = 0, tn = 0;  // tn = (sum of nLeft << 4) | numpair
 #pragma unroll
                 for (int h = 0; h < (ROT ? 8 : 4); h += 4) {
@@ -1016,10 +1027,10 @@ __device__ __forceinline__ bool dense_pair(const FilterParams& p, uint32_t* smem
                         const int lx = ix + ldx, ly = iy + ldy;
                         const int rx = jx + rdx, ry = jy + rdy;
                         const bool okl = ni != 0 && (uint32_t)lx < (uint32_t)kLeftW && (uint32_t)ly < (uint32_t)kLeftH;  // ll != -1
-                        const bool okp = okl && (uint32_t)rx < (uint32_t)wr && (uint32_t)ry < (uint32_t)hr;             // rr != -1
+                        const bool okp = okl && (uint32_t)rx < (uint32_t)kDenseRightW && (uint32_t)ry < (uint32_t)kDenseRightW;  // rr != -1
                         const uint32_t ll = okl ? (uint32_t)(lx + ly * kLeftW) : 0u;
                         const uint32_t nll = nleft8[ll];
-                        const uint32_t cnt = dense8[ll * nr + (okp ? (uint32_t)(rx + ry * wr) : 0u)];
+                        const uint32_t cnt = dense8[ll * kDenseRow + (okp ? (uint32_t)(kDenseRightN + 3 - (rx + ry * kDenseRightW)) : 4u)];
                         score += okp ? cnt : 0u;
                         tn += okp ? ((nll << 4) | 1u) : 0u;
                     }
@@ -1028,7 +1039,7 @@ __device__ __forceinline__ bool dense_pair(const FilterParams& p, uint32_t* smem
                     score += dpp_xor1(score);
                     tn += dpp_xor1(tn);
                 }
-                score += 255u - (best >> 11);  // centre pair (k = 4): ll = i, rr = j*, the arg-max count itself
+                score += (best >> 11) + 1u;  // centre pair (k = 4): ll = i, rr = j*, the arg-max count itself
                 tn += (ni << 4) | 1u;
                 uint32_t pass = 0;
                 if (ni != 0 && (ROT || half == 0))
@@ -1040,30 +1051,36 @@ __device__ __forceinline__ bool dense_pair(const FilterParams& p, uint32_t* smem
                     bits = (uint32_t)(bal >> (lane & 56)) & 0xFFu;
                     writer = ni != 0 && (lane & 7) == 0;
                 }
-                // every lane of the cell has read hdr[i] above (same wave, program order): it now holds cellPairs[i]
-                if (writer) hdr[i] = ((uint32_t)j << 8) | bits;
+                // every lane of the cell has read the header above (same wave, program order): it now holds cellPairs[i]
+                if (writer) smem[i * (kDenseRow / 4)] = (ej << 8) | bits;
             }
         }
         __syncthreads();
         GMS_STAMP(5);  // verify
 
-        // ---- mark inliers: cellPairs[l] == r, all rotations at once
+        // ---- mark inliers: cellPairs[l] == r, all rotations at once; and take this grid type's increments back
         {
             uint32_t cr[KPT];
-            bool valid[KPT];
 #pragma unroll
             for (int k = 0; k < KPT; ++k) {
                 const uint32_t cw = code[k];
-                const uint32_t lx = (((cw >> kDHxShift) & 63u) + (uint32_t)gx) >> 1;
-                const uint32_t ly = (((cw >> kDHyShift) & 63u) + (uint32_t)gy) >> 1;
-                valid[k] = max(lx, ly) < (uint32_t)kLeftW;
-                cr[k] = hdr[valid[k] ? __umul24(ly, (uint32_t)kLeftW) + lx : 0u];
+                const uint32_t row = __umul24(cw & q_mask, kDenseRow) + row1[k];
+                cr[k] = 0xFFFFFFFFu;
+                if ((cw & out_mask) == 0) {
+                    cr[k] = smem[row >> 2];
+                    if (g < 3) {
+                        const uint32_t at = row + ((cw >> kDEShift) & kDEMask);
+                        atomicSub(lds_at(smem, at & ~3u), 1u << ((at << 3) & 31u));
+                    }
+                }
             }
 #pragma unroll
-            for (int k = 0; k < KPT; ++k)
-                if (valid[k] && (cr[k] >> 8) == (code[k] & kRMask)) code[k] |= (cr[k] & 0xFFu) << kDAccShift;
+            for (int k = 0; k < KPT; ++k) {
+                const uint32_t x = cr[k] ^ (code[k] & (kDEMask << kDEShift));  // < 256: same right cell, x = rotation bits
+                if (x < 256u) code[k] |= x << kDAccShift;
+            }
         }
-        __syncthreads();  // hdr is cleared next; after the last grid type the matrix area is reused below
+        __syncthreads();  // headers are reset next; after the last grid type the matrix area is reused below
         GMS_STAMP(6);  // mark
     }
 
