@@ -22,6 +22,7 @@ struct FilterParams {
     int prefetch_stride;        // workgroup b touches the match array of pair b + stride (0 = off)
     int stagger_cycles;         // first-round workgroups start spread over this many shader cycles (0 = off)
     int stagger_blocks;         // how many leading workgroups count as the first round
+    int stagger_mode;           // 0: delay grows with the workgroup index; 1: scattered (diagnostics)
     const gms_dmatch* matches;
     gms_dmatch* out;
     gms_pair_result* results;
@@ -30,6 +31,7 @@ struct FilterParams {
     int region_shift;           // region slots per match = 1 + 2^-shift
     int with_rotation, with_scale;
     int dense;                  // try the byte-matrix path first (no scale hypotheses only); the general path is the fallback
+    int persist_grid;           // dense only: > 0 = that many workgroups each walk several pairs (one per CU)
     double threshold_factor;
     int right_w[5], right_h[5]; // setScale (DLL@0x180048c10): cvRound(20 * ratio[s])
 #ifdef GMS_PHASE_TIMING

@@ -45,7 +45,7 @@ constexpr uint32_t kEmpty = 0xFFFFFFFFu;
 #ifdef GMS_PHASE_TIMING
 #define GMS_STAMP_DECL unsigned long long ph_[16] = {0}; unsigned long long t_prev_ = __builtin_readcyclecounter();
 #define GMS_STAMP(k) do { unsigned long long t_ = __builtin_readcyclecounter(); ph_[k] += t_ - t_prev_; t_prev_ = t_; } while (0)
-#define GMS_STAMP_FLUSH do { if (tid == 0 && p.diag) { for (int k_ = 0; k_ < 16; ++k_) p.diag[blockIdx.x * 16 + k_] = ph_[k_]; } } while (0)
+#define GMS_STAMP_FLUSH do { if (tid == 0 && p.diag) { for (int k_ = 0; k_ < 16; ++k_) p.diag[pair_idx * 16 + k_] = ph_[k_]; } } while (0)
 #else
 #define GMS_STAMP_DECL
 #define GMS_STAMP(k)
@@ -232,8 +232,11 @@ normalize_kernel(const gms_keypoint* __restrict__ kp, const int64_t* __restrict_
 __device__ __forceinline__ void first_round_stagger(const FilterParams& p)
 {
     if (p.stagger_cycles > 0 && blockIdx.x < (unsigned)p.stagger_blocks) {
-        const unsigned slot = (blockIdx.x * 37u) & 63u;
-        const long long until = (long long)__builtin_readcyclecounter() + (long long)slot * (p.stagger_cycles >> 6);
+        // in workgroup order: workgroups are handed to the XCDs round-robin and in order, so CUs should come free in
+        // that same order or the next workgroup in line waits for "its" XCD while others sit idle
+        const unsigned slot = p.stagger_mode ? ((blockIdx.x * 37u) & 63u) * (unsigned)(p.stagger_blocks >> 6) : blockIdx.x;
+        const long long until = (long long)__builtin_readcyclecounter() +
+                                (long long)slot * (long long)p.stagger_cycles / (long long)p.stagger_blocks;
         while ((long long)__builtin_readcyclecounter() < until) __builtin_amdgcn_s_sleep(32);
     }
 }
@@ -245,18 +248,17 @@ __device__ __forceinline__ void first_round_stagger(const FilterParams& p)
 // half-cell index gives the table region (insert) and the verified cell result (mark) with one LDS read.
 // ------------------------------------------------------------------------------------------------
 template <int KPT, bool ROT, int NT>
-__device__ __forceinline__ void hash_pair(const FilterParams& p, uint32_t* smem)
+__device__ __forceinline__ void hash_pair(const FilterParams& p, uint32_t* smem, const int pair_idx, const int tid)
 {
     constexpr int kMcap = KPT * NT;
     constexpr int kNRot = ROT ? 8 : 1;
     // matches a thread keeps in flight through the LDS stages: 5 (4) with 128 registers per thread, 10 with 256
     constexpr int kChunk = (NT <= 512 && KPT % 10 == 0) ? 10 : (KPT % 5 == 0) ? 5 : 4;
     static_assert(KPT % kChunk == 0, "KPT must be a multiple of the chunk");
-    const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
 
-    const gms_pair pr = p.pairs[blockIdx.x];
+    const gms_pair pr = p.pairs[pair_idx];
     const int m = pr.m;
     const gms_dmatch* __restrict__ matches = p.matches + pr.match_off;
 
@@ -307,7 +309,7 @@ __device__ __forceinline__ void hash_pair(const FilterParams& p, uint32_t* smem)
             r.best_scale = -1;
             r.best_rot = -1;
             r.status = (bad_pair || m > 0) ? GMS_ERR_DOMAIN : GMS_OK;
-            p.results[blockIdx.x] = r;
+            p.results[pair_idx] = r;
         }
         return;
     }
@@ -381,7 +383,7 @@ __device__ __forceinline__ void hash_pair(const FilterParams& p, uint32_t* smem)
     // under round-robin placement; speed only): one dword per 128-byte line, results unused. Its HBM reads
     // then overlap this pair's LDS work instead of arriving as one burst in front of it.
     {
-        const int nxt = blockIdx.x + p.prefetch_stride;
+        const int nxt = pair_idx + p.prefetch_stride;
         if (p.prefetch_stride > 0 && nxt < p.n_pairs) {
             const gms_pair np = p.pairs[nxt];
             const volatile char* base = reinterpret_cast<const volatile char*>(p.matches + np.match_off);
@@ -778,7 +780,7 @@ __device__ __forceinline__ void hash_pair(const FilterParams& p, uint32_t* smem)
         r.best_scale = failed ? -1 : best_scale;
         r.best_rot = failed ? -1 : best_rot;
         r.status = failed ? GMS_ERR_DOMAIN : GMS_OK;
-        p.results[blockIdx.x] = r;
+        p.results[pair_idx] = r;
     }
 }
 
@@ -788,7 +790,7 @@ filter_kernel(FilterParams p)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     first_round_stagger(p);
-    hash_pair<KPT, ROT, NT>(p, smem);
+    hash_pair<KPT, ROT, NT>(p, smem, (int)blockIdx.x, (int)threadIdx.x);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -832,9 +834,11 @@ static_assert(kDenseBytes % 16 == 0 && kDenseRow % 4 == 0, "rows are dword align
 constexpr uint32_t kDNever = 1u << 5;                // bit 5       not binned under any grid type
 constexpr uint32_t kDEdgeX = 1u << 6;                // bit 6       hx == 39: x >= 20 under the x-shifted grid types
 constexpr uint32_t kDEdgeY = 1u << 7;                // bit 7       hy == 39
-constexpr int kDEShift = 8;                          // bits 8..18  E(r) = 403 - r, the byte's offset in its row
-constexpr uint32_t kDEMask = 0x7FFu;
-constexpr int kDAccShift = 20;                       // bits 20..27 inlier-under-rotation bits
+constexpr int kDEShift = 8;                          // bits 8..16  E(r) = 403 - r, the byte's offset in its row
+constexpr uint32_t kDEMask = 0x1FFu;
+constexpr int kDAccShift = 17;                       // bits 17..24 inlier-under-rotation bits (one bit without rotation)
+constexpr int kDCellShift = 18;                      // without rotation only, bits 18..26: the left cell under grid type 1
+                                                     // (with rotation it has a register of its own, as a row offset)
 
 // mNumberPointsInPerCellLeft of cell (x, y) under the grid type shifted by (gx, gy) half cells
 __device__ __forceinline__ uint32_t dense_nleft(const uint8_t* nfine8, int x, int y, int gx, int gy)
@@ -854,17 +858,16 @@ __device__ __forceinline__ uint32_t dense_nleft(const uint8_t* nfine8, int x, in
 
 // false (workgroup-uniform, nothing written to global memory): the pair has to take the general path
 template <int KPT, bool ROT, int NT>
-__device__ __forceinline__ bool dense_pair(const FilterParams& p, uint32_t* smem)
+__device__ __forceinline__ bool dense_pair(const FilterParams& p, uint32_t* smem, const int pair_idx, const int tid)
 {
     constexpr int kMcap = KPT * NT;
     constexpr int kNRot = ROT ? 8 : 1;
     constexpr int kChunk = (KPT % 5 == 0) ? 5 : 4;
     static_assert(KPT % kChunk == 0, "KPT must be a multiple of the chunk");
-    const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
 
-    const gms_pair pr = p.pairs[blockIdx.x];
+    const gms_pair pr = p.pairs[pair_idx];
     const int m = pr.m;
     if (p.with_scale || p.right_w[0] != kDenseRightW || p.right_h[0] != kDenseRightW || m <= 0 || m > kMcap ||
         pr.frame_a < 0 || pr.frame_a >= p.n_frames || pr.frame_b < 0 || pr.frame_b >= p.n_frames)
@@ -884,6 +887,9 @@ __device__ __forceinline__ bool dense_pair(const FilterParams& p, uint32_t* smem
     uint32_t* trash = smem + kDenseTrashOff / 4;
 
     GMS_STAMP_DECL
+#ifdef GMS_PHASE_TIMING
+    ph_[14] = wall_clock64();  // absolute start of this workgroup (100 MHz), for the dispatch-phase histogram
+#endif
     if (tid < 32) misc[tid] = 0;
     if (tid < 16) trash[tid] = 0;
     if (tid < kFineN / 4) nfine32[tid] = 0;
@@ -899,9 +905,17 @@ __device__ __forceinline__ bool dense_pair(const FilterParams& p, uint32_t* smem
 #ifdef GMS_PHASE_TIMING
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     GMS_STAMP(4);  // bin: records landed, frame B staged
+    ph_[15] = wall_clock64();
 #endif
 
-    uint32_t code[KPT], row1[KPT];  // row1: byte offset of the left cell's row under grid type 1
+    // With rotation: row1 = byte offset of the left cell's row under grid type 1. Without, the cell rides in the code word
+    // (two more instructions per use, ten registers fewer -- this variant sits at the 128-register limit).
+    constexpr bool kPackCell = !ROT;
+    uint32_t code[KPT], row1[kPackCell ? 1 : KPT];
+    auto row_of = [&](int k, uint32_t cw, uint32_t q_mask) -> uint32_t {
+        if (kPackCell) return __umul24(((cw >> kDCellShift) & 0x1FFu) + (cw & q_mask), kDenseRow);
+        return __umul24(cw & q_mask, kDenseRow) + row1[k];
+    };
     {
         float2 a[KPT], b[KPT];
 #pragma unroll
@@ -930,8 +944,9 @@ __device__ __forceinline__ bool dense_pair(const FilterParams& p, uint32_t* smem
             any_bad |= live && !ok;
             const uint32_t q = (hx & 1u) + 20u * (hy & 1u);
             const uint32_t edge = (hx == 39u ? kDEdgeX : 0u) | (hy == 39u ? kDEdgeY : 0u);
-            code[k] = binned ? (q | edge | ((uint32_t)(kDenseRightN + 3) - r) << kDEShift) : kDNever;
-            row1[k] = binned ? ((hy >> 1) * kLeftW + (hx >> 1)) * kDenseRow : 0u;
+            const uint32_t l1 = (hy >> 1) * kLeftW + (hx >> 1);
+            code[k] = binned ? (q | edge | ((uint32_t)(kDenseRightN + 3) - r) << kDEShift) | (kPackCell ? l1 << kDCellShift : 0u) : kDNever;
+            if (!kPackCell) row1[k] = binned ? l1 * kDenseRow : 0u;
         }
         if (any_bad) misc[8] = 1;   // benign races: every writer stores 1
         if (spill) misc[11] = 1;
@@ -973,7 +988,7 @@ __device__ __forceinline__ bool dense_pair(const FilterParams& p, uint32_t* smem
 #pragma unroll
             for (int c = 0; c < kChunk; ++c) {
                 const uint32_t cw = code[k0 + c];
-                row[c] = __umul24(cw & q_mask, kDenseRow) + row1[k0 + c];
+                row[c] = row_of(k0 + c, cw, q_mask);
                 at[c] = row[c] + ((cw >> kDEShift) & kDEMask);
                 old[c] = 0;
                 // shift counts are taken modulo 32: at << 3 selects the byte (at & 3)
@@ -1064,7 +1079,7 @@ __device__ __forceinline__ bool dense_pair(const FilterParams& p, uint32_t* smem
 #pragma unroll
             for (int k = 0; k < KPT; ++k) {
                 const uint32_t cw = code[k];
-                const uint32_t row = __umul24(cw & q_mask, kDenseRow) + row1[k];
+                const uint32_t row = row_of(k, cw, q_mask);
                 cr[k] = 0xFFFFFFFFu;
                 if ((cw & out_mask) == 0) {
                     cr[k] = smem[row >> 2];
@@ -1172,7 +1187,7 @@ __device__ __forceinline__ bool dense_pair(const FilterParams& p, uint32_t* smem
         r.best_scale = winner >= 0 ? 0 : -1;
         r.best_rot = winner >= 0 ? winner + 1 : -1;
         r.status = GMS_OK;
-        p.results[blockIdx.x] = r;
+        p.results[pair_idx] = r;
     }
     return true;
 }
@@ -1183,7 +1198,26 @@ filter_kernel_dense(FilterParams p)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     first_round_stagger(p);
-    if (!dense_pair<KPT, ROT, NT>(p, smem)) hash_pair<KPT, ROT, NT>(p, smem);
+    if (!dense_pair<KPT, ROT, NT>(p, smem, (int)blockIdx.x, (int)threadIdx.x)) hash_pair<KPT, ROT, NT>(p, smem, (int)blockIdx.x, (int)threadIdx.x);
+}
+
+// One workgroup per CU walks pairs blockIdx.x, blockIdx.x + gridDim.x, ... With one workgroup per pair the
+// dispatcher releases successors in bursts (measured: starts of ~100 workgroups within 5 us every ~17 us from the
+// second dispatch round on, whatever the first round's spread), every burst's match-array reads then share the HBM
+// at once and take twice as long. Workgroups that simply keep going stay spread the way the first round was.
+template <int KPT, bool ROT, int NT>
+__global__ void __launch_bounds__(NT)
+filter_kernel_dense_persist(FilterParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    first_round_stagger(p);
+#pragma nounroll
+    for (int pi = (int)blockIdx.x; pi < p.n_pairs; pi += (int)gridDim.x) {
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));  // opaque per iteration: nothing derived from it is hoisted out of the loop (and spilled)
+        if (!dense_pair<KPT, ROT, NT>(p, smem, pi, tid)) hash_pair<KPT, ROT, NT>(p, smem, pi, tid);
+        __syncthreads();  // nobody still reads this pair's LDS state
+    }
 }
 
 // Test hook: the threshold comparison in device fp64.
@@ -1245,11 +1279,17 @@ static hipError_t launch_filter_t(const FilterParams& p, int n_pairs, size_t lds
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(filter_kernel_dense<KPT, ROT, NT>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes);
         if (e != hipSuccess) return e;
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(filter_kernel_dense_persist<KPT, ROT, NT>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes);
+        if (e != hipSuccess) return e;
         attr_set = true;
     }
     if (p.dense) {
         const size_t lds = lds_bytes > kDenseLdsBytes ? lds_bytes : (size_t)kDenseLdsBytes;
-        hipLaunchKernelGGL((filter_kernel_dense<KPT, ROT, NT>), dim3((unsigned)n_pairs), dim3(NT), lds, stream, p);
+        if (p.persist_grid > 0 && n_pairs > p.persist_grid)
+            hipLaunchKernelGGL((filter_kernel_dense_persist<KPT, ROT, NT>), dim3((unsigned)p.persist_grid), dim3(NT), lds, stream, p);
+        else
+            hipLaunchKernelGGL((filter_kernel_dense<KPT, ROT, NT>), dim3((unsigned)n_pairs), dim3(NT), lds, stream, p);
     } else {
         hipLaunchKernelGGL((filter_kernel<KPT, ROT, NT>), dim3((unsigned)n_pairs), dim3(NT), lds_bytes, stream, p);
     }

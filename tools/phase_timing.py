@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--pairs", type=int, default=1024)
     ap.add_argument("--rot", type=int, default=0)
     ap.add_argument("--scale", type=int, default=0)
+    ap.add_argument("--starts", default="", help="save per-pair (start, records landed) wall-clock stamps to this .npy")
     a = ap.parse_args()
     capi = importlib.import_module("sfm-gms_amd.capi")
     diag_path = os.path.join(ROOT, "sfm-gms_amd", "csrc", "libgms_hip_diag.so")
@@ -44,7 +45,11 @@ def main():
         with torch.cuda.stream(stream):
             bench.launch(ctx, wl, bool(a.rot), bool(a.scale))
     torch.cuda.synchronize()
-    d = dbuf.cpu().numpy().reshape(-1, 16)[:, :16].astype(np.float64)
+    raw = dbuf.cpu().numpy().reshape(-1, 16)
+    if a.starts:
+        np.save(a.starts, raw[:, 14:16])
+    d = raw[:, :16].astype(np.float64)
+    d[:, 14:16] = 0
     mean = d.mean(axis=0)
     tot = mean.sum()
     out = {"pairs": a.pairs, "rot": a.rot, "scale": a.scale, "total_cycles": tot,
