@@ -222,13 +222,7 @@ int gms_filter_device(gms_ctx* c, const float* d_pts, const int64_t* d_frame_off
         return !e || std::atoi(e) != 0;
     }();
     p.dense = (dense_on && !with_scale) ? 1 : 0;
-    // GMS_PERSIST=0: one workgroup per pair on the byte-matrix path too (diagnostics)
-    static const bool persist_on = [] {
-        const char* e = std::getenv("GMS_PERSIST");
-        return !e || std::atoi(e) != 0;
-    }();
-    p.persist_grid = (p.dense && persist_on) ? c->n_cus : 0;
-    p.stagger_cycles = (n_pairs >= 4 * p.stagger_blocks) ? (stagger_us >= 0 ? stagger_us : (p.dense ? 36 : 72)) * 2400 : 0;
+    p.stagger_cycles = (n_pairs >= 4 * p.stagger_blocks) ? (stagger_us >= 0 ? stagger_us : (p.dense ? 30 : 72)) * 2400 : 0;
 #ifdef GMS_PHASE_TIMING
     p.diag = g_diag;
 #endif

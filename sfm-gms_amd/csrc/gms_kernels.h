@@ -31,7 +31,6 @@ struct FilterParams {
     int region_shift;           // region slots per match = 1 + 2^-shift
     int with_rotation, with_scale;
     int dense;                  // try the byte-matrix path first (no scale hypotheses only); the general path is the fallback
-    int persist_grid;           // dense only: > 0 = that many workgroups each walk several pairs (one per CU)
     double threshold_factor;
     int right_w[5], right_h[5]; // setScale (DLL@0x180048c10): cvRound(20 * ratio[s])
 #ifdef GMS_PHASE_TIMING

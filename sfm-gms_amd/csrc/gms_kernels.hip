@@ -1099,8 +1099,10 @@ __device__ __forceinline__ bool dense_pair(const FilterParams& p, uint32_t* smem
         GMS_STAMP(6);  // mark
     }
 
-    // ---- run() return value per rotation, getInlierMask's strict '>' over the rotations (one scale)
-    {
+    // ---- run() return value per rotation and getInlierMask's strict '>' over the rotations (one scale). Without
+    //      rotation there is one hypothesis: it wins iff it keeps anything, which the scan below reports anyway.
+    int winner = 0;
+    if (ROT) {
         uint32_t cnt[kNRot];
 #pragma unroll
         for (int r = 0; r < kNRot; ++r) cnt[r] = 0;
@@ -1114,67 +1116,62 @@ __device__ __forceinline__ bool dense_pair(const FilterParams& p, uint32_t* smem
             for (int r = 0; r < kNRot; ++r)
                 if (cnt[r]) atomicAdd(&misc[r], cnt[r]);
         }
-    }
-    __syncthreads();
-    uint32_t best_count = 0;
-    int winner = -1;
+        __syncthreads();
+        uint32_t best_count = 0;
+        winner = -1;
 #pragma unroll
-    for (int r = 0; r < kNRot; ++r) {
-        const uint32_t c = misc[r];
-        if (c > best_count) {
-            best_count = c;
-            winner = r;
+        for (int r = 0; r < kNRot; ++r) {
+            const uint32_t c = misc[r];
+            if (c > best_count) {
+                best_count = c;
+                winner = r;
+            }
         }
     }
-    uint32_t* bestmask = smem;                       // kMcap / 32 dwords, in the matrix area
-    uint32_t* chunk_base = bestmask + (kMcap >> 5);  // kMcap / 64
-    uint32_t* wave_tot = misc + 16;
-    const int n_chunks = (m + 63) >> 6;
-#pragma unroll
-    for (int k = 0; k < KPT; ++k) {
-        const unsigned long long bsel = winner >= 0 ? __ballot((code[k] >> (kDAccShift + max(winner, 0))) & 1u) : 0ull;
-        if (lane == 0) {
-            const int ch = k * (NT / 64) + wave;  // chunk of 64 consecutive matches
-            bestmask[2 * ch] = (uint32_t)bsel;
-            bestmask[2 * ch + 1] = (uint32_t)(bsel >> 32);
-        }
-    }
-    __syncthreads();
     GMS_STAMP(7);  // count + select
 
-    // ---- copy-out: surviving DMatch verbatim, in input order (DLL@0x180048340), from the registers
-    for (int base = 0; base < n_chunks; base += NT) {
-        const int c = base + tid;
-        const uint32_t v = c < n_chunks ? __popc(bestmask[2 * c]) + __popc(bestmask[2 * c + 1]) : 0u;
-        uint32_t incl = v;
+    // ---- copy-out: surviving DMatch verbatim, in input order (DLL@0x180048340), from the registers. A chunk is 64
+    //      consecutive matches = one wave's k-th record; chunk (k, wave) sits at position k * 16 + wave of the order.
+    //      Every wave publishes its KPT popcounts, then scans all KPT * 16 of them itself (no further exchange).
+    constexpr int kWaves = NT / 64;
+    constexpr int kScanRegs = (KPT * kWaves + 63) / 64;
+    uint32_t* cnt_tab = smem;  // [KPT * kWaves], in the matrix area
+    unsigned long long keep[KPT];
+#pragma unroll
+    for (int k = 0; k < KPT; ++k) {
+        keep[k] = winner >= 0 ? __ballot((code[k] >> (kDAccShift + max(winner, 0))) & 1u) : 0ull;
+        if (lane == 0) cnt_tab[k * kWaves + wave] = (uint32_t)__popcll(keep[k]);
+    }
+    __syncthreads();
+    uint32_t excl[kScanRegs];
+    uint32_t total = 0;
+#pragma unroll
+    for (int v = 0; v < kScanRegs; ++v) {
+        const int idx = v * 64 + lane;
+        const uint32_t c = idx < KPT * kWaves ? cnt_tab[idx] : 0u;
+        uint32_t incl = c;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
             const uint32_t t = __shfl_up(incl, d);
             if (lane >= d) incl += t;
         }
-        if (lane == 63) wave_tot[wave] = incl;
-        __syncthreads();
-        uint32_t wave_off = misc[9];
-        for (int w = 0; w < wave; ++w) wave_off += wave_tot[w];
-        if (c < n_chunks) chunk_base[c] = wave_off + incl - v;
-        __syncthreads();
-        if (tid == NT - 1) misc[9] = wave_off + incl;
-        __syncthreads();
+        excl[v] = total + incl - c;
+        total += __shfl(incl, 63);
     }
-    const uint32_t total = misc[9];
     GMS_STAMP(8);  // out scan
     gms_dmatch* __restrict__ out = p.out + pr.match_off;
     uint8_t* mask_out = p.mask ? p.mask + pr.match_off : nullptr;
 #pragma unroll
     for (int k = 0; k < KPT; ++k) {
         const int i = k * NT + tid;
-        const int ch = i >> 6;
+        const int ch = k * kWaves + wave;                      // wave-uniform
+        static_assert(64 % kWaves == 0, "a wave's chunk never straddles two scan registers");
+        const uint32_t base = __shfl(excl[(k * kWaves) >> 6], ch & 63);
         if (i < m) {
-            const unsigned long long bits = (unsigned long long)bestmask[2 * ch] | ((unsigned long long)bestmask[2 * ch + 1] << 32);
-            const bool in = (bits >> lane) & 1ull;
+            const bool in = (keep[k] >> lane) & 1ull;
             if (mask_out) mask_out[i] = in ? 1 : 0;
             if (in) {
-                const uint32_t pos = chunk_base[ch] + (uint32_t)__popcll(bits & ((1ull << lane) - 1ull));
+                const uint32_t pos = base + (uint32_t)__popcll(keep[k] & ((1ull << lane) - 1ull));
                 *reinterpret_cast<uint4*>(&out[pos]) = rec[k];
             }
         }
@@ -1184,8 +1181,8 @@ __device__ __forceinline__ bool dense_pair(const FilterParams& p, uint32_t* smem
     if (tid == 0) {
         gms_pair_result r;
         r.n_inliers = (int)total;
-        r.best_scale = winner >= 0 ? 0 : -1;
-        r.best_rot = winner >= 0 ? winner + 1 : -1;
+        r.best_scale = total ? 0 : -1;
+        r.best_rot = total ? winner + 1 : -1;
         r.status = GMS_OK;
         p.results[pair_idx] = r;
     }
@@ -1199,25 +1196,6 @@ filter_kernel_dense(FilterParams p)
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     first_round_stagger(p);
     if (!dense_pair<KPT, ROT, NT>(p, smem, (int)blockIdx.x, (int)threadIdx.x)) hash_pair<KPT, ROT, NT>(p, smem, (int)blockIdx.x, (int)threadIdx.x);
-}
-
-// One workgroup per CU walks pairs blockIdx.x, blockIdx.x + gridDim.x, ... With one workgroup per pair the
-// dispatcher releases successors in bursts (measured: starts of ~100 workgroups within 5 us every ~17 us from the
-// second dispatch round on, whatever the first round's spread), every burst's match-array reads then share the HBM
-// at once and take twice as long. Workgroups that simply keep going stay spread the way the first round was.
-template <int KPT, bool ROT, int NT>
-__global__ void __launch_bounds__(NT)
-filter_kernel_dense_persist(FilterParams p)
-{
-    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-    first_round_stagger(p);
-#pragma nounroll
-    for (int pi = (int)blockIdx.x; pi < p.n_pairs; pi += (int)gridDim.x) {
-        int tid = threadIdx.x;
-        asm volatile("" : "+v"(tid));  // opaque per iteration: nothing derived from it is hoisted out of the loop (and spilled)
-        if (!dense_pair<KPT, ROT, NT>(p, smem, pi, tid)) hash_pair<KPT, ROT, NT>(p, smem, pi, tid);
-        __syncthreads();  // nobody still reads this pair's LDS state
-    }
 }
 
 // Test hook: the threshold comparison in device fp64.
@@ -1279,17 +1257,11 @@ static hipError_t launch_filter_t(const FilterParams& p, int n_pairs, size_t lds
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(filter_kernel_dense<KPT, ROT, NT>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes);
         if (e != hipSuccess) return e;
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(filter_kernel_dense_persist<KPT, ROT, NT>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes);
-        if (e != hipSuccess) return e;
         attr_set = true;
     }
     if (p.dense) {
         const size_t lds = lds_bytes > kDenseLdsBytes ? lds_bytes : (size_t)kDenseLdsBytes;
-        if (p.persist_grid > 0 && n_pairs > p.persist_grid)
-            hipLaunchKernelGGL((filter_kernel_dense_persist<KPT, ROT, NT>), dim3((unsigned)p.persist_grid), dim3(NT), lds, stream, p);
-        else
-            hipLaunchKernelGGL((filter_kernel_dense<KPT, ROT, NT>), dim3((unsigned)n_pairs), dim3(NT), lds, stream, p);
+        hipLaunchKernelGGL((filter_kernel_dense<KPT, ROT, NT>), dim3((unsigned)n_pairs), dim3(NT), lds, stream, p);
     } else {
         hipLaunchKernelGGL((filter_kernel<KPT, ROT, NT>), dim3((unsigned)n_pairs), dim3(NT), lds_bytes, stream, p);
     }
