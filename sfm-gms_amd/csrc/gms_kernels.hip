@@ -837,6 +837,7 @@ constexpr uint32_t kDEdgeY = 1u << 7;                // bit 7       hy == 39
 constexpr int kDEShift = 8;                          // bits 8..16  E(r) = 403 - r, the byte's offset in its row
 constexpr uint32_t kDEMask = 0x1FFu;
 constexpr int kDAccShift = 17;                       // bits 17..24 inlier-under-rotation bits (one bit without rotation)
+constexpr int kDTagShift = 20;                       // arg-max key in a row header: grid type << 20 | (count - 1) << 11 | E(j)
 constexpr int kDCellShift = 18;                      // without rotation only, bits 18..26: the left cell under grid type 1
                                                      // (with rotation it has a register of its own, as a row offset)
 
@@ -901,6 +902,13 @@ __device__ __forceinline__ bool dense_pair(const FilterParams& p, uint32_t* smem
     for (int k = 0; k < KPT; ++k) rec[k] = *reinterpret_cast<const uint4*>(&matches[min(k * NT + tid, m - 1)]);
     float2* lds_b = reinterpret_cast<float2*>(smem);
     for (int j = tid; j < nB; j += NT) lds_b[j] = ptsB[j];
+    // motion.setTo(0) for the part of the matrix area that frame B does not occupy: now, while the loads are in flight
+    const uint32_t staged16 = ((uint32_t)nB * 8u + 15u) >> 4;  // uint4s holding the staged frame
+    {
+        const uint4 z4 = make_uint4(0, 0, 0, 0);
+        uint4* d4 = reinterpret_cast<uint4*>(smem);
+        for (uint32_t i = staged16 + tid; i < kDenseBytes / 16; i += NT) d4[i] = z4;
+    }
     __syncthreads();
 #ifdef GMS_PHASE_TIMING
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -935,18 +943,24 @@ __device__ __forceinline__ bool dense_pair(const FilterParams& p, uint32_t* smem
                                        max(__float_as_uint(b[k].x), __float_as_uint(b[k].y)));
             const float fx = 20.0f * a[k].x, fy = 20.0f * a[k].y;   // mulss, rounded to fp32
             const uint32_t hx = (uint32_t)(int)(fx + fx), hy = (uint32_t)(int)(fy + fy);  // floor(2f), 2f exact
-            const uint32_t r = (uint32_t)((int)(20.0f * b[k].x) + (int)(20.0f * b[k].y) * kDenseRightW);
-            const bool ok = rec[k].x < (uint32_t)nA && rec[k].y < (uint32_t)nB && worst < 0x49800000u && r < (uint32_t)kDenseRightN;
-            const bool binned = live && ok && hx < 40u && hy < 40u;
-            const uint32_t f = binned ? hy * kFineW + hx : 0u;
-            const uint32_t old = atomicAdd(binned ? &nfine32[f >> 2] : &trash[lane & 7], 1u << ((f & 3u) << 3));
-            spill |= binned && ((old >> ((f & 3u) << 3)) & 255u) == 255u;  // the byte wrapped: > 255 in one half cell
-            any_bad |= live && !ok;
-            const uint32_t q = (hx & 1u) + 20u * (hy & 1u);
-            const uint32_t edge = (hx == 39u ? kDEdgeX : 0u) | (hy == 39u ? kDEdgeY : 0u);
-            const uint32_t l1 = (hy >> 1) * kLeftW + (hx >> 1);
-            code[k] = binned ? (q | edge | ((uint32_t)(kDenseRightN + 3) - r) << kDEShift) | (kPackCell ? l1 << kDCellShift : 0u) : kDNever;
-            if (!kPackCell) row1[k] = binned ? l1 * kDenseRow : 0u;
+            // getGridIndexRight: x + y * 20, no bounds test in the reference. Both terms are below 2^25 inside the parity
+            // domain; clamped to 4096 the 24-bit multiply-add is exact whenever the true value is below 400 and stays
+            // above it otherwise (full-rate instructions instead of a 32-bit multiply)
+            const uint32_t rx = (uint32_t)(int)(20.0f * b[k].x), ry = (uint32_t)(int)(20.0f * b[k].y);
+            const uint32_t r = __umul24(min(ry, 4096u), (uint32_t)kDenseRightW) + min(rx, 4096u);
+            // '&', not '&&': no short-circuit branches
+            const bool ok = (rec[k].x < (uint32_t)nA) & (rec[k].y < (uint32_t)nB) & (worst < 0x49800000u) & (r < (uint32_t)kDenseRightN);
+            const bool binned = live & ok & (max(hx, hy) < 40u);
+            const uint32_t f = binned ? __umul24(hy, (uint32_t)kFineW) + hx : 0u;
+            const uint32_t old = atomicAdd(binned ? &nfine32[f >> 2] : &trash[lane & 7], 1u << ((f << 3) & 31u));
+            spill |= binned & (((old >> ((f << 3) & 31u)) & 255u) == 255u);  // the byte wrapped: > 255 in one half cell
+            any_bad |= live & !ok;
+            const uint32_t q = (hx & 1u) + __umul24(hy & 1u, 20u);
+            const uint32_t edge = ((hx + 25u) & kDEdgeX) | ((hy + 89u) & kDEdgeY);  // hx == 39 -> bit 6, hy == 39 -> bit 7 (hx, hy < 40)
+            const uint32_t l1 = __umul24(hy >> 1, (uint32_t)kLeftW) + (hx >> 1);
+            const uint32_t cw = q | edge | (((uint32_t)(kDenseRightN + 3) - r) << kDEShift) | (kPackCell ? l1 << kDCellShift : 0u);
+            code[k] = binned ? cw : kDNever;
+            if (!kPackCell) row1[k] = binned ? __umul24(l1, kDenseRow) : 0u;
         }
         if (any_bad) misc[8] = 1;   // benign races: every writer stores 1
         if (spill) misc[11] = 1;
@@ -955,11 +969,19 @@ __device__ __forceinline__ bool dense_pair(const FilterParams& p, uint32_t* smem
     __syncthreads();  // histogram complete; every read of the staged frame is done
     GMS_STAMP(0);     // bin: wait for the other waves
 
-    // ---- motion.setTo(0), once: from here on every grid type leaves the matrix as it found it
+    // ---- motion.setTo(0), once: from here on every grid type leaves the matrix as it found it. The row headers are
+    //      never reset either: a grid type's arg-max keys carry the type in their top bits, so they outrank
+    //      whatever the previous type left there (its cellPairs word, which is below 2^17).
     {
         const uint4 z4 = make_uint4(0, 0, 0, 0);
         uint4* d4 = reinterpret_cast<uint4*>(smem);
-        for (uint32_t i = tid; i < kDenseBytes / 16; i += NT) d4[i] = z4;
+        for (uint32_t i = tid; i < staged16; i += NT) d4[i] = z4;  // the rest was cleared while the records were loading
+    }
+    __syncthreads();
+    GMS_STAMP(2);  // clear
+    if ((misc[8] | misc[11]) != 0) {  // workgroup-uniform; nothing has been written to global memory yet
+        __syncthreads();              // everybody has read the flags before the general path reuses the LDS
+        return false;
     }
 
     const bool thr_fast = threshold_fast_ok(p.threshold_factor);
@@ -967,18 +989,13 @@ __device__ __forceinline__ bool dense_pair(const FilterParams& p, uint32_t* smem
         const int gx = g & 1, gy = g >> 1;
         const uint32_t q_mask = (uint32_t)(gx + 20 * gy);                                 // l = l1 + (q & q_mask)
         const uint32_t out_mask = kDNever | (gx ? kDEdgeX : 0u) | (gy ? kDEdgeY : 0u);    // x >= 20 || y >= 20 -> -1 (DLL@0x180047d3d)
+        const uint32_t key_tag = (uint32_t)g << kDTagShift;
         if (tid < kLeftN) {
-            if (g > 0) smem[tid * (kDenseRow / 4)] = 0;  // row header back to "no arg-max yet"
-            // nLeft of this grid type, once per cell; above 255 the byte matrix cannot hold the cell's row
+            // nLeft of this grid type, once per cell (read by verify, behind the next barrier); above 255 the byte matrix
+            // cannot hold the cell's row
             const uint32_t n = dense_nleft(nfine8, tid % kLeftW, tid / kLeftW, gx, gy);
             if (n > 255u) misc[11] = 1;
             nleft8[tid] = (uint8_t)n;
-        }
-        __syncthreads();
-        GMS_STAMP(2);  // clear / reset
-        if ((misc[8] | misc[11]) != 0) {  // workgroup-uniform; nothing has been written to global memory yet
-            __syncthreads();              // everybody has read the flags before the general path reuses the LDS
-            return false;
         }
 
         // ---- assignMatchPairs: motion[l][r]++ on the byte; the count it produced goes into the row's arg-max
@@ -999,12 +1016,16 @@ __device__ __forceinline__ bool dense_pair(const FilterParams& p, uint32_t* smem
             for (int c = 0; c < kChunk; ++c) {
                 const uint32_t cw = code[k0 + c];
                 const uint32_t before = (old[c] >> ((at[c] << 3) & 31u)) & 255u;  // <= 254
-                if ((cw & out_mask) == 0) atomicMax(lds_at(smem, row[c]), (before << 11) | ((cw >> kDEShift) & kDEMask));
+                if ((cw & out_mask) == 0) atomicMax(lds_at(smem, row[c]), key_tag | (before << 11) | ((cw >> kDEShift) & kDEMask));
             }
         }
         GMS_STAMP(3);  // insert
         __syncthreads();
         GMS_STAMP(11);  // insert: wait for the other waves
+        if (misc[11] != 0) {  // a cell above 255 matches under this grid type (workgroup-uniform; still nothing written out)
+            __syncthreads();
+            return false;
+        }
 
         // ---- verifyCellPairs. Without rotation: two lanes per left cell, four neighbours each, joined by one DPP
         //      exchange; with rotation: one lane per (cell, rotation).
@@ -1017,7 +1038,7 @@ __device__ __forceinline__ bool dense_pair(const FilterParams& p, uint32_t* smem
                 const int half = item & 1;  // !ROT only
                 const int ix = i % kLeftW, iy = i / kLeftW;
                 const uint32_t ni = live ? nleft8[i] : 0u;
-                const uint32_t best = smem[i * (kDenseRow / 4)];  // ((max count - 1) << 11) | E(j*), lowest j* among maxima
+                const uint32_t best = smem[i * (kDenseRow / 4)] & ((1u << kDTagShift) - 1u);  // ((max count - 1) << 11) | E(j*), lowest j* among maxima
                 const uint32_t ej = ni ? (best & kDEMask) : (uint32_t)(kDenseRightN + 3);
                 const int j = kDenseRightN + 3 - (int)ej;
                 const int jx = j % kDenseRightW, jy = j / kDenseRightW;
@@ -1095,7 +1116,7 @@ __device__ __forceinline__ bool dense_pair(const FilterParams& p, uint32_t* smem
                 if (x < 256u) code[k] |= x << kDAccShift;
             }
         }
-        __syncthreads();  // headers are reset next; after the last grid type the matrix area is reused below
+        __syncthreads();  // the next grid type writes the headers; after the last one the matrix area is reused below
         GMS_STAMP(6);  // mark
     }
 
