@@ -897,11 +897,16 @@ __device__ __forceinline__ bool dense_pair(const FilterParams& p, uint32_t* smem
 
     // ---- the pair's DMatch records, whole (they stay in registers until copy-out), and frame B staged in the
     //      still unused matrix area for the train-side gather
+    // Frame B's points are requested first and the records right behind them (loads return in order): the staged frame is
+    // complete -- and the barrier passed -- while the later records are still on their way, and binning starts on the
+    // first records as they land instead of behind all of them.
+    constexpr int kStageRegs = 10;  // 10 240 keypoints through registers; larger frames finish in a plain loop
+    float2 tb[kStageRegs];
+#pragma unroll
+    for (int i = 0; i < kStageRegs; ++i) tb[i] = ptsB[min(i * NT + tid, nB - 1)];
     uint4 rec[KPT];
 #pragma unroll
     for (int k = 0; k < KPT; ++k) rec[k] = *reinterpret_cast<const uint4*>(&matches[min(k * NT + tid, m - 1)]);
-    float2* lds_b = reinterpret_cast<float2*>(smem);
-    for (int j = tid; j < nB; j += NT) lds_b[j] = ptsB[j];
     // motion.setTo(0) for the part of the matrix area that frame B does not occupy: now, while the loads are in flight
     const uint32_t staged16 = ((uint32_t)nB * 8u + 15u) >> 4;  // uint4s holding the staged frame
     {
@@ -909,9 +914,16 @@ __device__ __forceinline__ bool dense_pair(const FilterParams& p, uint32_t* smem
         uint4* d4 = reinterpret_cast<uint4*>(smem);
         for (uint32_t i = staged16 + tid; i < kDenseBytes / 16; i += NT) d4[i] = z4;
     }
+    float2* lds_b = reinterpret_cast<float2*>(smem);
+#pragma unroll
+    for (int i = 0; i < kStageRegs; ++i)
+        if (i * NT + tid < nB) lds_b[i * NT + tid] = tb[i];
+    for (int j = kStageRegs * NT + tid; j < nB; j += NT) lds_b[j] = ptsB[j];
     __syncthreads();
-#ifdef GMS_PHASE_TIMING
+    // the left-side gathers below are global loads and return behind the records whatever their issue time: wait for the
+    // records once, so that the gathers go out together instead of one round trip per record
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef GMS_PHASE_TIMING
     GMS_STAMP(4);  // bin: records landed, frame B staged
     ph_[15] = wall_clock64();
 #endif
