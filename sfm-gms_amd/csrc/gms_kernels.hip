@@ -841,6 +841,23 @@ constexpr int kDTagShift = 20;                       // arg-max key in a row hea
 constexpr int kDCellShift = 18;                      // without rotation only, bits 18..26: the left cell under grid type 1
                                                      // (with rotation it has a register of its own, as a row offset)
 
+// The threshold test of the byte-matrix path: T <= 9 * 255, score <= 9 * 255, n <= 9. For an integer factor up to 1023
+// (the reference's default is 6) T * factor^2 and score^2 * n are exact 32-bit integers; when they differ, they differ by
+// at least 1 in about 2^32, far more than the reference's three fp64 roundings can move thresh, so their order is the
+// reference's answer. Exact ties (and every other factor) take the fp64 route of threshold_rejects().
+__device__ __forceinline__ uint32_t dense_factor_sq(double factor)
+{
+    return (factor >= 1.0 && factor <= 1023.0 && factor == floor(factor)) ? (uint32_t)(factor * factor) : 0u;
+}
+__device__ __forceinline__ bool dense_threshold_rejects(uint32_t T, uint32_t n, uint32_t score, double factor, bool fast_ok, uint32_t f2i)
+{
+    if (f2i) {
+        const uint32_t a = __umul24(T, f2i), b = __umul24(__umul24(score, score), n);
+        if (a != b) return a > b;
+    }
+    return threshold_rejects(T, n, score, factor, fast_ok);
+}
+
 // mNumberPointsInPerCellLeft of cell (x, y) under the grid type shifted by (gx, gy) half cells
 __device__ __forceinline__ uint32_t dense_nleft(const uint8_t* nfine8, int x, int y, int gx, int gy)
 {
@@ -997,6 +1014,7 @@ __device__ __forceinline__ bool dense_pair(const FilterParams& p, uint32_t* smem
     }
 
     const bool thr_fast = threshold_fast_ok(p.threshold_factor);
+    const uint32_t f2i = dense_factor_sq(p.threshold_factor);
     for (int g = 0; g < 4; ++g) {
         const int gx = g & 1, gy = g >> 1;
         const uint32_t q_mask = (uint32_t)(gx + 20 * gy);                                 // l = l1 + (q & q_mask)
@@ -1091,7 +1109,7 @@ __device__ __forceinline__ bool dense_pair(const FilterParams& p, uint32_t* smem
                 tn += (ni << 4) | 1u;
                 uint32_t pass = 0;
                 if (ni != 0 && (ROT || half == 0))
-                    pass = threshold_rejects(tn >> 4, tn & 15u, score, p.threshold_factor, thr_fast) ? 0u : 1u;
+                    pass = dense_threshold_rejects(tn >> 4, tn & 15u, score, p.threshold_factor, thr_fast, f2i) ? 0u : 1u;
                 uint32_t bits = pass;
                 bool writer = ni != 0 && half == 0;
                 if (ROT) {
@@ -1231,13 +1249,20 @@ filter_kernel_dense(FilterParams p)
     if (!dense_pair<KPT, ROT, NT>(p, smem, (int)blockIdx.x, (int)threadIdx.x)) hash_pair<KPT, ROT, NT>(p, smem, (int)blockIdx.x, (int)threadIdx.x);
 }
 
-// Test hook: the threshold comparison in device fp64.
+// Test hook: the threshold comparison in device fp64 -- and, where the operands are in its range, the byte-matrix
+// path's integer form of it, which must agree (a disagreement is reported as 2).
 __global__ void threshold_kernel(const int32_t* T, const int32_t* n, const int32_t* score, double factor,
                                  int count, uint8_t* out)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < count) {
-        out[i] = threshold_rejects((uint32_t)T[i], (uint32_t)n[i], (uint32_t)score[i], factor, threshold_fast_ok(factor)) ? 1 : 0;
+        const uint32_t t = (uint32_t)T[i], nn = (uint32_t)n[i], sc = (uint32_t)score[i];
+        const bool general = threshold_rejects(t, nn, sc, factor, threshold_fast_ok(factor));
+        uint8_t r = general ? 1 : 0;
+        if (t <= 9u * 255u && sc <= 9u * 255u && nn >= 1u && nn <= 9u &&
+            dense_threshold_rejects(t, nn, sc, factor, threshold_fast_ok(factor), dense_factor_sq(factor)) != general)
+            r = 2;
+        out[i] = r;
     }
 }
 

@@ -132,3 +132,35 @@ def test_eligible_and_ineligible_pairs_share_a_launch(ctx, oracle):
             assert rc == 0 and results[i]["status"] == 0 and k == wres["n_inliers"] and results[i]["best_rot"] == wres["best_rot"]
             assert out[o:o + k].tobytes() == want.tobytes()
             assert np.array_equal(mask[o:o + len(c["matches"])], np.asarray(wmask, dtype=np.uint8))
+
+
+def test_integer_threshold_form_agrees_with_fp64(ctx):
+    """The byte-matrix path decides sqrt(T / n) * factor > score on exact integers when factor is a small integer. The
+    selftest kernel evaluates both forms and reports 2 on a disagreement; the fp64 form is checked against IEEE here.
+    All of the path's operand range around the decision boundary, every exact tie included."""
+    rng = np.random.default_rng(12)
+    for f in (1.0, 2.0, 3.0, 6.0, 7.0, 13.0, 1023.0, 1024.0, 5.5, 0.0):
+        T, n = np.meshgrid(np.arange(0, 9 * 255 + 1, dtype=np.int64), np.arange(1, 10, dtype=np.int64))
+        T, n = T.ravel(), n.ravel()
+        th = np.sqrt(T.astype(np.float64) / n) * f
+        for d in (-1, 0, 1):
+            sc = np.clip(np.floor(th) + d, 0, 9 * 255).astype(np.int32)
+            got = ctx.selftest_threshold(T.astype(np.int32), n.astype(np.int32), sc, f)
+            assert got.max() <= 1, ("integer and fp64 forms disagree", f, d)
+            assert np.array_equal(got, (th > sc).astype(np.uint8)), (f, d)
+        # exact ties T * f^2 == score^2 * n are not rejections (thresh == score)
+        if f >= 1 and f == int(f):
+            k = np.arange(1, 48, dtype=np.int64)
+            for nn in range(1, 10):
+                Tt, st = nn * k * k, int(f) * k
+                ok = (Tt <= 9 * 255) & (st <= 9 * 255)
+                if ok.any():
+                    g = ctx.selftest_threshold(Tt[ok].astype(np.int32), np.full(ok.sum(), nn, dtype=np.int32), st[ok].astype(np.int32), f)
+                    assert not g.any(), (f, nn)
+    # random operands, random integer factors
+    for f in rng.integers(1, 1024, 20):
+        T = rng.integers(0, 9 * 255 + 1, 20000).astype(np.int32)
+        n = rng.integers(1, 10, 20000).astype(np.int32)
+        sc = rng.integers(0, 9 * 255 + 1, 20000).astype(np.int32)
+        th = np.sqrt(T.astype(np.float64) / n) * float(f)
+        assert np.array_equal(ctx.selftest_threshold(T, n, sc, float(f)), (th > sc).astype(np.uint8)), f
