@@ -227,7 +227,7 @@ def main():
                        "frames_per_gpu": args.frames, "inlier_frac": args.inlier_frac,
                        "mean_kept_per_pair": kept / wl["n_pairs"], "sharding": f"pairs x{world}, no collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "kernel": "gms::filter_kernel",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "kernel": "gms::filter_kernel_dense<10, false, 1024>",
                          "kernel_ms_per_launch": kern_ms, "algorithmic_bytes_per_launch": alg_bytes},
         }
         if not args.no_cpu:

@@ -2,8 +2,16 @@
 //
 // What the reference does per pair (cv::xfeatures2d::matchGMS, opencv_xfeatures2d452.dll; SURVEY.md
 // section 8a) is a dense 400 x N_right int32 "motion" matrix that is zeroed, filled and scanned 4 times
-// per hypothesis. That matrix has at most M non-zeros, so here it is never materialised: one 1024-thread
-// workgroup owns one image pair and keeps the pair's whole state in registers and in the CU's 160 KB LDS:
+// per hypothesis. One 1024-thread workgroup owns one image pair and keeps the pair's whole state in
+// registers and in the CU's 160 KB LDS, in one of two forms:
+//
+//   filter_kernel_dense / dense_pair()   no scale hypotheses (right grid 20 x 20) and no left cell above 255
+//               matches: the 400 x 400 matrix itself, one BYTE per entry, fills the LDS; binning is one
+//               returning atomic per match, verification reads neighbour counts directly, the DMatch records
+//               stay in registers from load to copy-out. Described in front of dense_pair() below. Pairs that
+//               do not qualify are handed to hash_pair() by the same workgroup before anything is written.
+//   filter_kernel / hash_pair()          everything else (scale hypotheses, crowded cells): the matrix has at
+//               most M non-zeros and is kept as a hash table --
 //
 //   code[KPT]   (registers) one dword per match: right cell of the current scale, half-cell index of the
 //               left point (it carries the left cell under all four grid types), 8 per-rotation inlier bits
@@ -18,12 +26,11 @@
 //   fres        per half-cell: (j*, rotation bits that pass the threshold) of the cell it falls in
 //
 // Rotation only changes which neighbour counts are summed, so one table build serves all 8 rotations;
-// the right cell only depends on the scale, the left cell only on the grid type. HBM sees each match
-// once on the way in (16 B, coalesced) plus the two 8-B keypoint gathers, and 16 B per survivor on the
-// way out (today the 16-B records are read a second time at copy-out). No MFMA: integer histogramming.
-// Measured on MI355X the kernel is bound by chains of dependent LDS operations and by instruction issue
-// (one 16-wave workgroup per CU), not by HBM: the hot loops are written branch-free and staged (all of a
-// thread's independent LDS operations are issued before the first result is consumed).
+// the right cell only depends on the scale, the left cell only on the grid type. No MFMA: integer
+// histogramming. Measured on MI355X both forms are bound by VALU issue (16 cycles of a SIMD per instruction
+// of the 16-wave workgroup) and by the wait for the pair's records, not by HBM bandwidth: the hot loops are
+// written branch-free and staged (all of a thread's independent LDS operations are issued before the first
+// result is consumed).
 //
 // Bit-exactness notes (vs the DLL): fp32 multiply then floor for unshifted axes; widen the fp32
 // product to fp64, add 0.5, floor for shifted axes (DLL@0x180047bc0) -- both read off floor(2 * fl32(20 n));

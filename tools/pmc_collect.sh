@@ -22,6 +22,7 @@ for f in glob.glob(out + "/p*/**/*counter_collection.csv", recursive=True):
     for row in csv.DictReader(open(f)):
         if "filter_kernel" in row.get("Kernel_Name", ""):
             agg[row["Counter_Name"]].append(float(row["Counter_Value"]))
+open(out + "/../pmc_summary.csv", "w").write("counter,mean_per_dispatch,n\n" + "".join(f"{k},{sum(agg[k])/len(agg[k]):.0f},{len(agg[k])}\n" for k in sorted(agg)))
 print("counter,mean_per_dispatch,n")
 for k in sorted(agg):
     v = agg[k]
