@@ -928,9 +928,19 @@ __device__ __forceinline__ bool dense_pair(const FilterParams& p, uint32_t* smem
     float2 tb[kStageRegs];
 #pragma unroll
     for (int i = 0; i < kStageRegs; ++i) tb[i] = ptsB[min(i * NT + tid, nB - 1)];
-    uint4 rec[KPT];
+    // Up to 10 matches per thread the whole 16-byte records stay in registers until copy-out (the match array is read
+    // once); at 16 per thread that would be 64 registers of a 128-register budget, so there only (queryIdx, trainIdx)
+    // are loaded here and the survivors' records are read again at copy-out.
+    constexpr bool kKeepRec = KPT <= 10;
+    uint4 rec[kKeepRec ? KPT : 1];
+    uint2 qt[kKeepRec ? 1 : KPT];
 #pragma unroll
-    for (int k = 0; k < KPT; ++k) rec[k] = *reinterpret_cast<const uint4*>(&matches[min(k * NT + tid, m - 1)]);
+    for (int k = 0; k < KPT; ++k) {
+        if (kKeepRec) rec[k] = *reinterpret_cast<const uint4*>(&matches[min(k * NT + tid, m - 1)]);
+        else qt[k] = *reinterpret_cast<const uint2*>(&matches[min(k * NT + tid, m - 1)]);
+    }
+    auto query_of = [&](int k) -> uint32_t { return kKeepRec ? rec[k].x : qt[k].x; };
+    auto train_of = [&](int k) -> uint32_t { return kKeepRec ? rec[k].y : qt[k].y; };
     // motion.setTo(0) for the part of the matrix area that frame B does not occupy: now, while the loads are in flight
     const uint32_t staged16 = ((uint32_t)nB * 8u + 15u) >> 4;  // uint4s holding the staged frame
     {
@@ -963,9 +973,9 @@ __device__ __forceinline__ bool dense_pair(const FilterParams& p, uint32_t* smem
     {
         float2 a[KPT], b[KPT];
 #pragma unroll
-        for (int k = 0; k < KPT; ++k) a[k] = ptsA[min(rec[k].x, (uint32_t)(nA - 1))];
+        for (int k = 0; k < KPT; ++k) a[k] = ptsA[min(query_of(k), (uint32_t)(nA - 1))];
 #pragma unroll
-        for (int k = 0; k < KPT; ++k) b[k] = lds_b[min(rec[k].y, (uint32_t)(nB - 1))];
+        for (int k = 0; k < KPT; ++k) b[k] = lds_b[min(train_of(k), (uint32_t)(nB - 1))];
 #ifdef GMS_PHASE_TIMING
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         GMS_STAMP(12);  // bin: gathers landed
@@ -985,7 +995,7 @@ __device__ __forceinline__ bool dense_pair(const FilterParams& p, uint32_t* smem
             const uint32_t rx = (uint32_t)(int)(20.0f * b[k].x), ry = (uint32_t)(int)(20.0f * b[k].y);
             const uint32_t r = __umul24(min(ry, 4096u), (uint32_t)kDenseRightW) + min(rx, 4096u);
             // '&', not '&&': no short-circuit branches
-            const bool ok = (rec[k].x < (uint32_t)nA) & (rec[k].y < (uint32_t)nB) & (worst < 0x49800000u) & (r < (uint32_t)kDenseRightN);
+            const bool ok = ((int)(query_of(k) < (uint32_t)nA) & (int)(train_of(k) < (uint32_t)nB) & (int)(worst < 0x49800000u) & (int)(r < (uint32_t)kDenseRightN)) != 0;
             const bool binned = live & ok & (max(hx, hy) < 40u);
             const uint32_t f = binned ? __umul24(hy, (uint32_t)kFineW) + hx : 0u;
             const uint32_t old = atomicAdd(binned ? &nfine32[f >> 2] : &trash[lane & 7], 1u << ((f << 3) & 31u));
@@ -1230,7 +1240,7 @@ __device__ __forceinline__ bool dense_pair(const FilterParams& p, uint32_t* smem
             if (mask_out) mask_out[i] = in ? 1 : 0;
             if (in) {
                 const uint32_t pos = base + (uint32_t)__popcll(keep[k] & ((1ull << lane) - 1ull));
-                *reinterpret_cast<uint4*>(&out[pos]) = rec[k];
+                *reinterpret_cast<uint4*>(&out[pos]) = kKeepRec ? rec[k] : *reinterpret_cast<const uint4*>(&matches[i]);
             }
         }
     }
