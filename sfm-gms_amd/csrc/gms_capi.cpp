@@ -77,7 +77,7 @@ struct gms_ctx {
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     std::mutex mu;  // serialises the one-shot path's scratch buffers
-    DevBuf kp, foff, wh, pts, pair, matches, out, result, aux, big_ws;
+    DevBuf kp, foff, wh, pts, pair, matches, out, result, aux, big_ws, band_ws;
     int n_cus = 256;  // multiProcessorCount of the device
 };
 
@@ -135,7 +135,7 @@ int gms_ctx_destroy(gms_ctx* c)
     if (!c) return GMS_OK;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    DevBuf* bufs[] = {&c->kp, &c->foff, &c->wh, &c->pts, &c->pair, &c->matches, &c->out, &c->result, &c->aux, &c->big_ws};
+    DevBuf* bufs[] = {&c->kp, &c->foff, &c->wh, &c->pts, &c->pair, &c->matches, &c->out, &c->result, &c->aux, &c->big_ws, &c->band_ws};
     for (DevBuf* b : bufs) b->release();
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
@@ -214,6 +214,7 @@ int gms_filter_device(gms_ctx* c, const float* d_pts, const int64_t* d_frame_off
     p.with_rotation = with_rotation ? 1 : 0;
     p.with_scale = with_scale ? 1 : 0;
     p.threshold_factor = threshold_factor;
+    p.pair_flags = nullptr;
     right_grids(p.right_w, p.right_h);
     // GMS_DENSE=0 keeps every pair on the hashed path (diagnostics); by default the byte-matrix path is tried first
     // whenever there are no scale hypotheses (the reference's default flags, DisparityUtil.cpp:149,299)
@@ -248,7 +249,38 @@ int gms_filter_device(gms_ctx* c, const float* d_pts, const int64_t* d_frame_off
             GMS_HIP(c->big_ws.reserve(need));
         }
         p.stagger_cycles = 0;
-        GMS_HIP(gms::launch_filter_big(p, mcap, n_wg, (uint32_t*)c->big_ws.p, c->stream));
+        // GMS_BAND=0 keeps large pairs on the HBM-slab kernel alone (diagnostics)
+        static const bool band_on = [] {
+            const char* e = std::getenv("GMS_BAND");
+            return !e || std::atoi(e) != 0;
+        }();
+        if (band_on && !with_rotation && !with_scale) {
+            // Default flags: the three-band LDS kernels, a slice of the batch at a time so that the per-pair workspace
+            // (code words, histogram, mask) stays bounded; pairs they flag (a cell above 65 535 matches) fall through to
+            // the HBM-slab kernel, which looks at flagged pairs only.
+            const size_t per_pair = gms::band_ws_bytes_per_pair(mcap, d_mask == nullptr);
+            const size_t budget = (size_t)4 << 30;
+            size_t slice = budget / per_pair;
+            if (slice < 1) slice = 1;
+            if (slice > (size_t)n_pairs) slice = (size_t)n_pairs;
+            if (slice * per_pair > c->band_ws.cap) {
+                GMS_HIP(hipStreamSynchronize(c->stream));
+                GMS_HIP(c->band_ws.reserve(slice * per_pair));
+            }
+            for (int s0 = 0; s0 < n_pairs; s0 += (int)slice) {
+                gms::FilterParams ps = p;
+                ps.pairs = d_pairs + s0;
+                ps.results = d_results + s0;
+                ps.n_pairs = (n_pairs - s0 < (int)slice) ? n_pairs - s0 : (int)slice;
+                const uint32_t* flags = nullptr;
+                GMS_HIP(gms::launch_filter_band(ps, mcap, c->band_ws.p, &flags, c->stream));
+                ps.pair_flags = flags;
+                const int wg = ps.n_pairs < c->n_cus ? ps.n_pairs : c->n_cus;
+                GMS_HIP(gms::launch_filter_big(ps, mcap, wg, (uint32_t*)c->big_ws.p, c->stream));
+            }
+        } else {
+            GMS_HIP(gms::launch_filter_big(p, mcap, n_wg, (uint32_t*)c->big_ws.p, c->stream));
+        }
     }
     return GMS_OK;
 }

@@ -1,0 +1,413 @@
+// gms_kernel_band.hip -- large pairs (16 385 ... 262 144 matches) under the reference's default flags (no rotation,
+// no scale hypotheses): BASELINE config 4 and the reference's dense one-keypoint-per-pixel disparity call
+// (DisparityUtil.cpp:123-149, W*H matches).
+//
+// The byte-matrix idea of gms_kernels.hip (dense_pair) with 16-bit counters: the 400 x 400 motion matrix is
+// 320 KB then, so the 20 left-grid rows are cut into three bands (7 + 7 + 6 rows). One workgroup owns one band of one
+// pair and keeps the band's rows plus one halo row on either side in LDS -- [header dword | 400 x u16] per left cell,
+// 145 KB for 9 rows -- so that every neighbour count verifyCellPairs needs for the band's own cells is local. A left
+// cell (of whatever grid type) belongs to exactly one band, so the bands of a pair never exchange anything: each
+// marks the matches its own cells accept in the pair's byte mask (all writers store 1), and the mask is the OR over
+// the four grid types by construction. Three stream-ordered launches per batch:
+//   band_codes_kernel    one thread per match: (queryIdx, trainIdx) + the two keypoint gathers -> a 4-byte code word
+//                        (right cell, half-cell coordinates of the left point) in a workspace slab, and the pair's
+//                        40 x 40 half-cell histogram (LDS-privatised per block, then global atomics);
+//   band_filter_kernel   grid (3 bands, pairs): per grid type clear, stream the code words (coalesced, 4 B per
+//                        match) for assignMatchPairs, verify the band's cells, stream again to mark;
+//   band_compact_kernel  grid (16k-match tiles, pairs): order-preserving compaction of the DMatch records by the mask.
+// A pair with a left cell above 65 535 matches (a 16-bit entry could wrap) is flagged instead and left to the
+// HBM-slab kernel of gms_kernel_big.hip, which runs afterwards on flagged pairs only. Bit-exactness rules are the ones
+// of gms_kernels.hip (same float -> cell arithmetic, same threshold, same arg-max and tie rules).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "gms_kernels.h"
+
+namespace gms {
+namespace {
+
+constexpr int kRightW = 20, kRightN = 400;                 // right grid of scale 0
+constexpr uint32_t kRowBytes = 4u + 2u * kRightN;          // header dword + 400 x u16
+constexpr int kBandRowsMax = 9;                            // 7 own rows + 2 halo rows
+constexpr uint32_t kMatrixBytes = kBandRowsMax * kLeftW * kRowBytes;  // 144 720
+constexpr uint32_t kNleftOff = kMatrixBytes;               // [400] u32: nLeft of every cell under the current grid type
+constexpr uint32_t kMiscOff = kNleftOff + 4u * kLeftN;     // [16] u32
+constexpr uint32_t kBandLdsBytes = kMiscOff + 64u;
+static_assert(kMatrixBytes % 16 == 0, "the band matrix is cleared in uint4s");
+
+// code word: E' = 400 - r (1..400; higher = lower right cell) : 9 | hx : 6 | hy : 6 | binned : 1
+constexpr int kHxShift = 9, kHyShift = 15;
+constexpr uint32_t kBinned = 1u << 21;
+
+constexpr uint32_t kFlagDomain = 1u;    // an input outside the parity domain: the pair fails as a whole
+constexpr uint32_t kFlagGeneral = 2u;   // a left cell above 65 535 matches: gms_kernel_big.hip takes the pair
+
+__device__ __forceinline__ void band_rows(int band, int& lo, int& hi)  // own rows [lo, hi)
+{
+    lo = band * 7;
+    hi = band == 2 ? kLeftH : lo + 7;
+}
+
+__device__ __forceinline__ uint32_t* lds_at(uint32_t* base, uint32_t byte_off)
+{
+    return reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(base) + byte_off);
+}
+
+// the general fp64 form of verifyCellPairs' test (see threshold_rejects in gms_kernels.hip)
+__device__ __forceinline__ bool band_threshold_rejects(uint32_t T, uint32_t n, uint32_t score, double factor)
+{
+    const double dT = (double)T, dN = (double)n, dS = (double)score;
+    if (factor > 1e-100 && factor < 1e100) {
+        const double a = dT * factor * factor, b = dS * dS * dN;
+        if (fabs(a - b) > fmax(a, b) * 0x1p-40) return a > b;
+    }
+    return sqrt(dT / dN) * factor > dS;
+}
+
+__device__ __forceinline__ uint32_t dpp_xor1(uint32_t x)
+{
+    return (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0xB1, 0xF, 0xF, true);  // quad_perm [1,0,3,2]
+}
+
+}  // namespace
+
+// ---- code words + half-cell histogram -----------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024)
+band_codes_kernel(FilterParams p, uint32_t* codes, uint32_t* nfine_g, uint32_t* flags, uint8_t* mask_ws, int mcap)
+{
+    __shared__ uint32_t hist[kFineN];
+    const int pi = blockIdx.y, tid = threadIdx.x;
+    const gms_pair pr = p.pairs[pi];
+    const int m = pr.m;
+    const bool bad_pair = m < 0 || m > mcap || pr.frame_a < 0 || pr.frame_a >= p.n_frames || pr.frame_b < 0 ||
+                          pr.frame_b >= p.n_frames;
+    if (bad_pair) {
+        if (blockIdx.x == 0 && tid == 0) atomicOr(&flags[pi], kFlagDomain);
+        return;
+    }
+    const int base = blockIdx.x * 4096;
+    if (base >= m) return;  // workgroup-uniform
+    const int64_t offA = p.frame_off[pr.frame_a], offB = p.frame_off[pr.frame_b];
+    const int nA = (int)(p.frame_off[pr.frame_a + 1] - offA), nB = (int)(p.frame_off[pr.frame_b + 1] - offB);
+    if (nA <= 0 || nB <= 0) {  // matches, but nothing valid to index
+        if (blockIdx.x == 0 && tid == 0) atomicOr(&flags[pi], kFlagDomain);
+        return;
+    }
+    const float2* __restrict__ ptsA = p.pts + offA;
+    const float2* __restrict__ ptsB = p.pts + offB;
+    const gms_dmatch* __restrict__ matches = p.matches + pr.match_off;
+    uint32_t* code = codes + (size_t)pi * mcap;
+    uint8_t* mask = p.mask ? p.mask + pr.match_off : mask_ws + (size_t)pi * mcap;
+
+    for (int j = tid; j < kFineN; j += 1024) hist[j] = 0;
+    __syncthreads();
+    uint2 qt[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) qt[k] = *reinterpret_cast<const uint2*>(&matches[min(base + k * 1024 + tid, m - 1)]);
+    float2 a[4], b[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        a[k] = ptsA[min(qt[k].x, (uint32_t)(nA - 1))];
+        b[k] = ptsB[min(qt[k].y, (uint32_t)(nB - 1))];
+    }
+    bool any_bad = false;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int i = base + k * 1024 + tid;
+        const bool live = i < m;
+        // parity domain: coordinates finite, non-negative, < 2^20 (one unsigned compare on the bit patterns)
+        const uint32_t worst = max(max(__float_as_uint(a[k].x), __float_as_uint(a[k].y)),
+                                   max(__float_as_uint(b[k].x), __float_as_uint(b[k].y)));
+        const float fx = 20.0f * a[k].x, fy = 20.0f * a[k].y;   // mulss, rounded to fp32
+        const uint32_t hx = (uint32_t)(int)(fx + fx), hy = (uint32_t)(int)(fy + fy);  // floor(2f), 2f exact
+        // getGridIndexRight: x + y * 20 with no bounds test; clamped operands keep the 24-bit form exact below 400
+        const uint32_t rx = (uint32_t)(int)(20.0f * b[k].x), ry = (uint32_t)(int)(20.0f * b[k].y);
+        const uint32_t r = __umul24(min(ry, 4096u), (uint32_t)kRightW) + min(rx, 4096u);
+        const bool ok = qt[k].x < (uint32_t)nA && qt[k].y < (uint32_t)nB && worst < 0x49800000u && r < (uint32_t)kRightN;
+        const bool binned = live && ok && hx < 40u && hy < 40u;
+        if (binned) atomicAdd(&hist[hy * kFineW + hx], 1u);
+        any_bad |= live && !ok;
+        if (live) {
+            code[i] = binned ? (((uint32_t)kRightN - r) | (hx << kHxShift) | (hy << kHyShift) | kBinned) : 0u;
+            mask[i] = 0;
+        }
+    }
+    if (any_bad) atomicOr(&flags[pi], kFlagDomain);
+    __syncthreads();
+    uint32_t* nf = nfine_g + (size_t)pi * kFineN;
+    for (int j = tid; j < kFineN; j += 1024)
+        if (hist[j]) atomicAdd(&nf[j], hist[j]);
+}
+
+// ---- one band of one pair -------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024)
+band_filter_kernel(FilterParams p, const uint32_t* codes, const uint32_t* nfine_g, uint32_t* flags, uint8_t* mask_ws, int mcap)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    const int band = blockIdx.x, pi = blockIdx.y, tid = threadIdx.x;
+    const gms_pair pr = p.pairs[pi];
+    const int m = pr.m;
+    if (m <= 0 || m > mcap) return;
+    if (flags[pi] & kFlagDomain) return;  // written by the previous launch
+    const uint32_t* __restrict__ code = codes + (size_t)pi * mcap;
+    const uint32_t* __restrict__ nf = nfine_g + (size_t)pi * kFineN;
+    uint8_t* mask = p.mask ? p.mask + pr.match_off : mask_ws + (size_t)pi * mcap;
+
+    const uint8_t* bytes = reinterpret_cast<const uint8_t*>(smem);
+    uint32_t* nleft = smem + kNleftOff / 4;
+    uint32_t* misc = smem + kMiscOff / 4;
+    int lo, hi;
+    band_rows(band, lo, hi);
+    const int row0 = max(lo - 1, 0), row1 = min(hi + 1, kLeftH);  // rows held in LDS: [row0, row1)
+    const uint32_t clear16 = (uint32_t)((row1 - row0) * kLeftW) * kRowBytes / 16u;
+
+    auto nleft_of = [&](int cell, int gx, int gy) -> uint32_t {
+        const int hx0 = 2 * (cell % kLeftW) - gx, hy0 = 2 * (cell / kLeftW) - gy;  // hx0 + 1, hy0 + 1 <= 39
+        uint32_t n = 0;
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) {
+                const int hx = hx0 + dx, hy = hy0 + dy;
+                if (hx >= 0 && hy >= 0) n += nf[hy * kFineW + hx];
+            }
+        return n;
+    };
+
+    // a 16-bit entry never exceeds its left cell's population: every cell of every grid type has to stay below 2^16
+    if (tid == 0) misc[0] = 0;
+    __syncthreads();
+    for (int item = tid; item < 4 * kLeftN; item += 1024) {
+        const int g = item / kLeftN;
+        if (nleft_of(item - g * kLeftN, g & 1, g >> 1) > 65535u) misc[0] = 1;
+    }
+    __syncthreads();
+    if (misc[0]) {  // the same decision in all three bands of the pair
+        if (band == 0 && tid == 0) atomicOr(&flags[pi], kFlagGeneral);
+        return;
+    }
+
+    for (int g = 0; g < 4; ++g) {
+        const int gx = g & 1, gy = g >> 1;
+        if (tid < kLeftN) nleft[tid] = nleft_of(tid, gx, gy);
+        {
+            const uint4 z4 = make_uint4(0, 0, 0, 0);
+            uint4* d4 = reinterpret_cast<uint4*>(smem);
+            for (uint32_t i = tid; i < clear16; i += 1024) d4[i] = z4;  // motion.setTo(0), headers included
+        }
+        __syncthreads();
+
+        // ---- assignMatchPairs for the rows this band holds (own + halo): +1 on the 16-bit entry, the count it produced
+        //      into the row's running arg-max ((count - 1) << 9 | E', atomicMax: highest count, then lowest right cell)
+        for (int i0 = 0; i0 < m; i0 += 8 * 1024) {
+            uint32_t cw[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int i = i0 + k * 1024 + tid;
+                cw[k] = i < m ? code[i] : 0u;
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const uint32_t lx = (((cw[k] >> kHxShift) & 63u) + (uint32_t)gx) >> 1;
+                const uint32_t ly = (((cw[k] >> kHyShift) & 63u) + (uint32_t)gy) >> 1;
+                // x >= 20 || y >= 20 -> -1 (DLL@0x180047d3d); rows outside [row0, row1) belong to another band
+                if ((cw[k] & kBinned) && lx < (uint32_t)kLeftW && ly >= (uint32_t)row0 && ly < (uint32_t)row1) {
+                    const uint32_t e = cw[k] & 0x1FFu;  // E' = 400 - r
+                    const uint32_t row = (__umul24(ly - (uint32_t)row0, (uint32_t)kLeftW) + lx) * kRowBytes;
+                    const uint32_t at = row + 4u + 2u * (e - 1u);
+                    const uint32_t sh = (at & 2u) << 3;
+                    const uint32_t old = atomicAdd(lds_at(smem, at & ~3u), 1u << sh);
+                    atomicMax(lds_at(smem, row), (((old >> sh) & 0xFFFFu) << 9) | e);
+                }
+            }
+        }
+        __syncthreads();
+
+        // ---- verifyCellPairs for the band's own cells: two lanes per cell, four neighbours each, joined by one DPP exchange
+        {
+            const int n_items = (hi - lo) * kLeftW * 2;
+            for (int item = tid; item < ((n_items + 63) & ~63); item += 1024) {
+                const bool live = item < n_items;
+                const int c = live ? item >> 1 : 0, half = item & 1;
+                const int ix = c % kLeftW, iy = lo + c / kLeftW;
+                const int i = iy * kLeftW + ix;
+                const uint32_t hdr_off = (uint32_t)((iy - row0) * kLeftW + ix) * kRowBytes;
+                const uint32_t ni = live ? nleft[i] : 0u;
+                const uint32_t best = smem[hdr_off >> 2];  // ((max count - 1) << 9) | E'(j*), lowest j* among maxima
+                const uint32_t ej = ni ? (best & 0x1FFu) : (uint32_t)kRightN;
+                const int j = kRightN - (int)ej;
+                const int jx = j % kRightW, jy = j / kRightW;
+                uint32_t score = 0, T = 0, np = 0;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int k = half ? q + 5 : q;  // lane 0: neighbours 0..3, lane 1: neighbours 5..8 (4 is the centre)
+                    const int dx = (k % 3) - 1, dy = (k / 3) - 1;
+                    const int lx = ix + dx, ly = iy + dy, rx = jx + dx, ry = jy + dy;
+                    const bool okl = ni != 0 && (uint32_t)lx < (uint32_t)kLeftW && (uint32_t)ly < (uint32_t)kLeftH;   // ll != -1
+                    const bool okp = okl && (uint32_t)rx < (uint32_t)kRightW && (uint32_t)ry < (uint32_t)kRightW;    // rr != -1
+                    if (okp) {  // ly is within one row of an own row, so the band holds it
+                        // entries are stored by E' - 1 = 399 - r
+                        const uint32_t at = (uint32_t)((ly - row0) * kLeftW + lx) * kRowBytes + 4u +
+                                            2u * (uint32_t)(kRightN - 1 - (rx + ry * kRightW));
+                        score += *reinterpret_cast<const uint16_t*>(bytes + at);
+                        T += nleft[ly * kLeftW + lx];
+                        np += 1;
+                    }
+                }
+                score += dpp_xor1(score);
+                T += dpp_xor1(T);
+                np += dpp_xor1(np);
+                score += (best >> 9) + 1u;  // centre pair (k = 4): ll = i, rr = j*, the arg-max count itself
+                T += ni;
+                np += 1;
+                if (live && half == 0 && ni != 0) {
+                    const uint32_t pass = band_threshold_rejects(T, np, score, p.threshold_factor) ? 0u : 1u;
+                    smem[hdr_off >> 2] = (ej << 1) | pass;  // cellPairs[i] (both lanes of the cell have read the header above)
+                }
+            }
+        }
+        __syncthreads();
+
+        // ---- mark: cellPairs[l] == r for the matches whose left cell is one of the band's own
+        for (int i0 = 0; i0 < m; i0 += 8 * 1024) {
+            uint32_t cw[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int i = i0 + k * 1024 + tid;
+                cw[k] = i < m ? code[i] : 0u;
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const uint32_t lx = (((cw[k] >> kHxShift) & 63u) + (uint32_t)gx) >> 1;
+                const uint32_t ly = (((cw[k] >> kHyShift) & 63u) + (uint32_t)gy) >> 1;
+                if ((cw[k] & kBinned) && lx < (uint32_t)kLeftW && ly >= (uint32_t)lo && ly < (uint32_t)hi) {
+                    const uint32_t cp = smem[((__umul24(ly - (uint32_t)row0, (uint32_t)kLeftW) + lx) * kRowBytes) >> 2];
+                    if (cp == (((cw[k] & 0x1FFu) << 1) | 1u)) mask[i0 + k * 1024 + tid] = 1;
+                }
+            }
+        }
+        __syncthreads();  // the next grid type clears the matrix
+    }
+}
+
+// ---- order-preserving compaction: workgroup (tile, pair) writes the survivors among matches [tile * 16384, +16384) ----
+// Its output offset is the number of survivors in front of the tile, which it counts from the mask itself (at most
+// 256 KB of bytes to sum) instead of waiting for other workgroups; the pair's last tile also knows the total.
+__device__ __forceinline__ uint32_t mask_bits16(const uint8_t* mask, int first, int m)
+{
+    uint32_t bits = 0;
+    if (first + 16 <= m && ((reinterpret_cast<uintptr_t>(mask) + (uintptr_t)first) & 15u) == 0) {
+        const uint4 v = *reinterpret_cast<const uint4*>(mask + first);  // 16 mask bytes, each 0 or 1
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+        // bytes b0..b3 (bit 0 of each) -> bits 24..27: b_k * 2^(8k) * 2^(24 - 7k); the cross terms stay below bit 20
+#pragma unroll
+        for (int q = 0; q < 4; ++q) bits |= ((((w[q] & 0x01010101u) * 0x01020408u) >> 24) & 15u) << (4 * q);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 16; ++k)
+            if (first + k < m && mask[first + k]) bits |= 1u << k;
+    }
+    return bits;
+}
+
+__global__ void __launch_bounds__(1024)
+band_compact_kernel(FilterParams p, const uint32_t* flags, uint8_t* mask_ws, int mcap)
+{
+    __shared__ uint32_t wave_tile[16], wave_before[16];
+    const int tile = blockIdx.x, pi = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const gms_pair pr = p.pairs[pi];
+    const int m = pr.m;
+    const uint32_t fl = flags[pi];
+    if (fl & kFlagGeneral) return;  // gms_kernel_big.hip produces this pair
+    const bool failed = (fl & kFlagDomain) != 0 || m < 0 || m > mcap;
+    const int n_tiles = (failed || m <= 0) ? 1 : (m + 16383) >> 14;
+    if (tile >= n_tiles) return;
+    uint32_t total = 0;
+    if (!failed && m > 0) {
+        const gms_dmatch* __restrict__ matches = p.matches + pr.match_off;
+        gms_dmatch* __restrict__ out = p.out + pr.match_off;
+        const uint8_t* mask = p.mask ? p.mask + pr.match_off : mask_ws + (size_t)pi * mcap;
+        // survivors in front of this tile (this thread's share of them)
+        uint32_t before = 0;
+        for (int f = tid * 16; f < tile * 16384; f += 16 * 1024) before += (uint32_t)__popc(mask_bits16(mask, f, m));
+        // thread t owns 16 consecutive matches of the tile
+        const int first = tile * 16384 + tid * 16;
+        const uint32_t bits = first < m ? mask_bits16(mask, first, m) : 0u;
+        const uint32_t v = (uint32_t)__popc(bits);
+        uint32_t incl = v, sum_b = before;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t t = __shfl_up(incl, d), tb = __shfl_up(sum_b, d);
+            if (lane >= d) {
+                incl += t;
+                sum_b += tb;
+            }
+        }
+        if (lane == 63) {
+            wave_tile[wave] = incl;
+            wave_before[wave] = sum_b;
+        }
+        __syncthreads();
+        uint32_t pos = incl - v, tile_total = 0, before_total = 0;
+        for (int w = 0; w < 16; ++w) {
+            if (w < wave) pos += wave_tile[w];
+            tile_total += wave_tile[w];
+            before_total += wave_before[w];
+        }
+        pos += before_total;
+#pragma unroll
+        for (int k = 0; k < 16; ++k)
+            if ((bits >> k) & 1u) {
+                *reinterpret_cast<uint4*>(&out[pos]) = *reinterpret_cast<const uint4*>(&matches[first + k]);
+                ++pos;
+            }
+        total = before_total + tile_total;
+    } else if (failed && m > 0 && m <= mcap && p.mask) {
+        uint8_t* mask = p.mask + pr.match_off;  // a failed pair keeps nothing
+        for (int i = tid; i < m; i += 1024) mask[i] = 0;
+    }
+    if (tid == 0 && tile == n_tiles - 1) {
+        gms_pair_result r;
+        r.n_inliers = failed ? 0 : (int)total;
+        r.best_scale = (failed || total == 0) ? -1 : 0;
+        r.best_rot = (failed || total == 0) ? -1 : 1;
+        r.status = failed ? GMS_ERR_DOMAIN : GMS_OK;
+        p.results[pi] = r;
+    }
+}
+
+// ---- launch helpers ----------------------------------------------------------------------------------------------------
+size_t band_ws_bytes_per_pair(int mcap, bool need_mask)
+{
+    return (size_t)mcap * 4 + (size_t)kFineN * 4 + 4 + (need_mask ? (size_t)mcap : 0);
+}
+
+// ws layout for n pairs: codes [n][mcap] u32 | nfine [n][1600] u32 | flags [n] u32 | mask [n][mcap] u8 (if p.mask is null)
+hipError_t launch_filter_band(const FilterParams& p, int mcap, void* ws, const uint32_t** flags_out, hipStream_t stream)
+{
+    const int n = p.n_pairs;
+    if (n <= 0) return hipSuccess;
+    uint32_t* codes = reinterpret_cast<uint32_t*>(ws);
+    uint32_t* nfine = codes + (size_t)n * mcap;
+    uint32_t* flags = nfine + (size_t)n * kFineN;
+    uint8_t* mask_ws = reinterpret_cast<uint8_t*>(flags + n);
+    hipError_t e = hipMemsetAsync(nfine, 0, ((size_t)n * kFineN + n) * 4, stream);
+    if (e != hipSuccess) return e;
+    static bool attr_set = false;
+    if (!attr_set) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(band_filter_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)kLdsBytes);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(band_codes_kernel, dim3((unsigned)((mcap + 4095) / 4096), (unsigned)n), dim3(1024), 0, stream, p, codes,
+                       nfine, flags, mask_ws, mcap);
+    hipLaunchKernelGGL(band_filter_kernel, dim3(3, (unsigned)n), dim3(1024), kBandLdsBytes, stream, p, codes, nfine, flags,
+                       mask_ws, mcap);
+    hipLaunchKernelGGL(band_compact_kernel, dim3((unsigned)((mcap + 16383) / 16384), (unsigned)n), dim3(1024), 0, stream, p, flags,
+                       mask_ws, mcap);
+    *flags_out = flags;
+    return hipGetLastError();
+}
+
+}  // namespace gms

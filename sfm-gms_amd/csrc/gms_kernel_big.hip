@@ -118,6 +118,7 @@ filter_kernel_big(FilterParams p, uint32_t* ws, size_t ws_stride, int mcap, uint
     uint32_t* misc = chunk_base + (mcap >> 6) + 1; // [0..7] counts, [8] error, [9] carry, [12..15] allocators, [16..31] scan
 
     for (int pi = blockIdx.x; pi < p.n_pairs; pi += gridDim.x) {
+        if (p.pair_flags && !(p.pair_flags[pi] & 2u)) continue;  // the band kernels (gms_kernel_band.hip) did this pair
         const gms_pair pr = p.pairs[pi];
         const int m = pr.m;
         const gms_dmatch* __restrict__ matches = p.matches + pr.match_off;

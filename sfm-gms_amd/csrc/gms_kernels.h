@@ -30,6 +30,7 @@ struct FilterParams {
     uint32_t table_slots;       // multiple of 4: data + header buckets of all 400 regions
     int region_shift;           // region slots per match = 1 + 2^-shift
     int with_rotation, with_scale;
+    const uint32_t* pair_flags; // large-pair kernel only: when set, it filters just the pairs whose flag word has bit 1 set
     int dense;                  // try the byte-matrix path first (no scale hypotheses only); the general path is the fallback
     double threshold_factor;
     int right_w[5], right_h[5]; // setScale (DLL@0x180048c10): cvRound(20 * ratio[s])
@@ -54,6 +55,10 @@ constexpr int kBigMaxMatches = 262144;
 int        big_mcap(int max_m);
 size_t     big_ws_stride_dwords(int mcap);
 hipError_t launch_filter_big(const FilterParams& p, int mcap, int n_workgroups, uint32_t* ws, hipStream_t stream);
+// large pairs under the default flags (gms_kernel_band.hip): three-band 16-bit matrix in LDS; *flags_out marks the pairs
+// left to launch_filter_big (bit 1)
+size_t     band_ws_bytes_per_pair(int mcap, bool need_mask);
+hipError_t launch_filter_band(const FilterParams& p, int mcap, void* ws, const uint32_t** flags_out, hipStream_t stream);
 hipError_t launch_threshold(const int32_t* d_T, const int32_t* d_n, const int32_t* d_score, double factor,
                             int count, uint8_t* d_out, hipStream_t stream);
 

@@ -1,0 +1,135 @@
+"""-m gpu: large pairs (above 16 384 matches) under the reference's default flags go through the three-band LDS kernels
+(gms_kernel_band.hip); against the CPU oracle, bit-exact. Covered here: sizes across the 16k-match compaction tiles, matches
+concentrated on the band borders (rows 6/7, 13/14 and their half-cell neighbours), a left cell above 65 535 matches (the pair
+is flagged and finished by the HBM-slab kernel), mixed batches with ragged and unaligned pairs, the optional mask, and
+out-of-domain inputs."""
+import importlib
+
+import numpy as np
+import pytest
+
+import cases
+
+pytestmark = pytest.mark.gpu
+
+
+def _check(ctx, oracle, c, rot=False, scale=False, thr=6.0):
+    got, res = ctx.match(c["size1"], c["size2"], c["kp1"], c["kp2"], c["matches"], rot, scale, thr, return_result=True)
+    rc, want, _, wres = oracle.match(c["size1"], c["size2"], c["kp1"], c["kp2"], c["matches"], rot, scale, thr)
+    assert rc == 0
+    assert got.tobytes() == want.tobytes(), (len(got), len(want), res, wres)
+    assert (res["n_inliers"], res["best_scale"], res["best_rot"]) == (wres["n_inliers"], wres["best_scale"], wres["best_rot"])
+    return len(got)
+
+
+@pytest.mark.parametrize("n", [16385, 16400, 32768, 32769, 50000, 100000, 262144])
+def test_sizes_across_compaction_tiles(ctx, oracle, n):
+    kept = _check(ctx, oracle, cases.random_pair(80 + n % 11, n=n, size1=(3840, 2160), inlier_frac=0.5))
+    assert kept > n // 10
+
+
+@pytest.mark.parametrize("thr", [0.0, 2.5, 6.0, 40.0])
+def test_threshold_factors(ctx, oracle, thr):
+    _check(ctx, oracle, cases.random_pair(91, n=40000, inlier_frac=0.4), thr=thr)
+
+
+def _border_case(seed, n_total, rows, size=(2000, 1000)):
+    """Matches whose left points crowd the given left-grid rows (in cell units, fractional), coherent displacement."""
+    rng = np.random.default_rng(seed)
+    w, h = size
+    n_band = n_total * 2 // 3
+    ys = rng.choice(rows, n_band) + rng.uniform(-0.3, 0.3, n_band)
+    xs = rng.uniform(0, 20, n_band)
+    xy1 = np.stack([xs * w / 20.0, ys * h / 20.0], axis=1)
+    xy1 = np.concatenate([xy1, np.stack([rng.uniform(0, w, n_total - n_band), rng.uniform(0, h, n_total - n_band)], axis=1)])
+    xy1 = np.clip(xy1, 0, [w - 0.01, h - 0.01]).astype(np.float32)
+    xy2 = np.clip(xy1 + rng.normal(0, 2.0, xy1.shape) + [7.0, -5.0], 0, [w - 0.01, h - 0.01]).astype(np.float32)
+    bad = rng.uniform(size=n_total) < 0.4
+    xy2[bad] = np.stack([rng.uniform(0, w, bad.sum()), rng.uniform(0, h, bad.sum())], axis=1).astype(np.float32)
+    idx = rng.permutation(n_total)
+    c = cases._pair(xy1, xy2, np.arange(n_total), np.arange(n_total), size, size)
+    c["matches"] = c["matches"][idx]
+    return c
+
+
+@pytest.mark.parametrize("rows", [(6.5, 7.0, 7.5), (13.5, 14.0, 14.5), (6.75, 7.25, 13.75, 14.25), (0.25, 19.75)])
+def test_matches_on_the_band_borders(ctx, oracle, rows):
+    """Left points on and around rows 7 and 14, where one band ends and the next begins -- also for the half-cell-shifted grid
+    types, whose row of a point differs from the unshifted one."""
+    assert _check(ctx, oracle, _border_case(5, 60000, np.array(rows))) > 5000
+
+
+def test_cell_above_65535_matches_falls_through_to_the_slab_kernel(ctx, oracle):
+    """70 000 of 120 000 matches in one left cell: a 16-bit entry could wrap, the pair is flagged and the HBM-slab kernel
+    produces it."""
+    rng = np.random.default_rng(8)
+    w, h = 2000, 1000
+    n_hot, n_rest = 70000, 50000
+    hot1 = np.stack([rng.uniform(1000, 1099, n_hot), rng.uniform(500, 549, n_hot)], axis=1)
+    rest1 = np.stack([rng.uniform(0, w - 1, n_rest), rng.uniform(0, h - 1, n_rest)], axis=1)
+    xy1 = np.concatenate([hot1, rest1]).astype(np.float32)
+    xy2 = np.clip(xy1 + rng.normal(0, 1.5, xy1.shape), 0, [w - 0.01, h - 0.01]).astype(np.float32)
+    n = n_hot + n_rest
+    c = cases._pair(xy1, xy2, np.arange(n), np.arange(n), (w, h), (w, h))
+    c["matches"] = c["matches"][rng.permutation(n)]
+    assert _check(ctx, oracle, c) > n_hot
+
+
+def test_mixed_batch_with_mask(ctx, oracle, pkg, synth):
+    """Ragged pairs (some below 16k, some above, one empty) in one launch; odd match offsets make the mask unaligned."""
+    batch = importlib.import_module("sfm-gms_amd.batch")
+    size = (1920, 1080)
+    n_frames, n_kp = 4, 40000
+    frames = synth.make_sequence(44, n_frames, size=size, n_kp=n_kp)
+    lengths = [40000, 17001, 0, 333, 25000, 39999, 16385]
+    pairs = np.zeros(len(lengths), dtype=pkg.PAIR_DTYPE)
+    matches, off = [], 0
+    total = pkg.all_pairs_count(n_frames)
+    for i, ln in enumerate(lengths):
+        a, b = pkg.pair_from_index((i * 5) % total, n_frames)
+        mt = synth.sequence_matches(4400 + i, n_kp, n_kp, 0.5)[:ln]
+        pairs[i] = (a, b, len(mt), 0, off)
+        matches.append(mt)
+        off += len(mt)
+    matches = np.concatenate(matches)
+    table = batch.FrameTable(ctx, frames, [size] * n_frames)
+    kp_all = np.concatenate(frames)
+    wh = np.array([size] * n_frames, dtype=np.int32).reshape(-1)
+    failed, wout, wres, wmask = oracle.batch(kp_all, table.frame_off_host, wh, pairs, matches, False, False, 6.0, 4)
+    assert failed == 0
+    for want_mask in (True, False):
+        out, res, mask = batch.filter_pairs(ctx, table, pairs, matches, False, False, 6.0, want_mask=want_mask)
+        assert res.tobytes() == wres.tobytes()
+        if want_mask:
+            assert np.array_equal(mask, wmask)
+        for i in range(len(pairs)):
+            o, k = int(pairs["match_off"][i]), int(res["n_inliers"][i])
+            assert out[o:o + k].tobytes() == wout[o:o + k].tobytes()
+
+
+def test_out_of_domain_input_fails_the_pair_only(ctx, oracle, pkg, synth):
+    """One large pair with an out-of-range index: that pair reports GMS_ERR_DOMAIN with nothing kept, its neighbours are intact."""
+    batch = importlib.import_module("sfm-gms_amd.batch")
+    size = (1920, 1080)
+    n_frames, n_kp = 3, 20000
+    frames = synth.make_sequence(45, n_frames, size=size, n_kp=n_kp)
+    pairs = np.zeros(3, dtype=pkg.PAIR_DTYPE)
+    matches, off = [], 0
+    for i in range(3):
+        mt = synth.sequence_matches(4500 + i, n_kp, n_kp, 0.5).copy()
+        if i == 1:
+            mt["trainIdx"][12345] = n_kp  # one past the frame
+        pairs[i] = (i % n_frames, (i + 1) % n_frames, len(mt), 0, off)
+        matches.append(mt)
+        off += len(mt)
+    matches = np.concatenate(matches)
+    table = batch.FrameTable(ctx, frames, [size] * n_frames)
+    out, res, mask = batch.filter_pairs(ctx, table, pairs, matches, False, False, 6.0)
+    kp_all = np.concatenate(frames)
+    wh = np.array([size] * n_frames, dtype=np.int32).reshape(-1)
+    failed, wout, wres, wmask = oracle.batch(kp_all, table.frame_off_host, wh, pairs, matches, False, False, 6.0, 2)
+    assert failed == 1 and res["status"][1] == -2 and res["n_inliers"][1] == 0
+    assert res.tobytes() == wres.tobytes() and np.array_equal(mask, wmask)
+    for i in (0, 2):
+        o, k = int(pairs["match_off"][i]), int(res["n_inliers"][i])
+        assert k > 1000 and out[o:o + k].tobytes() == wout[o:o + k].tobytes()
