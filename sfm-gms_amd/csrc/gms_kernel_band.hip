@@ -12,7 +12,7 @@
 //   band_codes_kernel    one thread per match: (queryIdx, trainIdx) + the two keypoint gathers -> a 4-byte code word
 //                        (right cell, half-cell coordinates of the left point) in a workspace slab, and the pair's
 //                        40 x 40 half-cell histogram (LDS-privatised per block, then global atomics);
-//   band_filter_kernel   grid (3 bands, pairs): per grid type clear, stream the code words (coalesced, 4 B per
+//   band_filter_kernel   grid (3 bands [x 4 grid types when the batch is small], pairs): per grid type clear, stream the code words (coalesced, 4 B per
 //                        match) for assignMatchPairs, verify the band's cells, stream again to mark;
 //   band_compact_kernel  grid (16k-match tiles, pairs): order-preserving compaction of the DMatch records by the mask.
 // A pair with a left cell above 65 535 matches (a 16-bit entry could wrap) is flagged instead and left to the
@@ -144,7 +144,8 @@ __global__ void __launch_bounds__(1024)
 band_filter_kernel(FilterParams p, const uint32_t* codes, const uint32_t* nfine_g, uint32_t* flags, uint8_t* mask_ws, int mcap)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-    const int band = blockIdx.x, pi = blockIdx.y, tid = threadIdx.x;
+    const int band = blockIdx.x % 3, pi = blockIdx.y, tid = threadIdx.x;
+    const int g_only = (gridDim.x == 12) ? (int)(blockIdx.x / 3) : -1;  // one (band, grid type) per workgroup, or all four types
     const gms_pair pr = p.pairs[pi];
     const int m = pr.m;
     if (m <= 0 || m > mcap) return;
@@ -183,11 +184,11 @@ band_filter_kernel(FilterParams p, const uint32_t* codes, const uint32_t* nfine_
     }
     __syncthreads();
     if (misc[0]) {  // the same decision in all three bands of the pair
-        if (band == 0 && tid == 0) atomicOr(&flags[pi], kFlagGeneral);
+        if (blockIdx.x == 0 && tid == 0) atomicOr(&flags[pi], kFlagGeneral);
         return;
     }
 
-    for (int g = 0; g < 4; ++g) {
+    for (int g = (g_only < 0 ? 0 : g_only); g < (g_only < 0 ? 4 : g_only + 1); ++g) {
         const int gx = g & 1, gy = g >> 1;
         if (tid < kLeftN) nleft[tid] = nleft_of(tid, gx, gy);
         {
@@ -330,37 +331,42 @@ band_compact_kernel(FilterParams p, const uint32_t* flags, uint8_t* mask_ws, int
         // survivors in front of this tile (this thread's share of them)
         uint32_t before = 0;
         for (int f = tid * 16; f < tile * 16384; f += 16 * 1024) before += (uint32_t)__popc(mask_bits16(mask, f, m));
-        // thread t owns 16 consecutive matches of the tile
-        const int first = tile * 16384 + tid * 16;
-        const uint32_t bits = first < m ? mask_bits16(mask, first, m) : 0u;
-        const uint32_t v = (uint32_t)__popc(bits);
-        uint32_t incl = v, sum_b = before;
 #pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t t = __shfl_up(incl, d), tb = __shfl_up(sum_b, d);
-            if (lane >= d) {
-                incl += t;
-                sum_b += tb;
-            }
+        for (int d = 32; d >= 1; d >>= 1) before += __shfl_xor(before, d);
+        // a wave owns 1024 consecutive matches of the tile, 64 at a time: loads and stores are coalesced
+        const int wbase = tile * 16384 + wave * 1024;
+        uint8_t mb[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int i = wbase + j * 64 + lane;
+            mb[j] = i < m ? mask[i] : (uint8_t)0;
         }
-        if (lane == 63) {
-            wave_tile[wave] = incl;
-            wave_before[wave] = sum_b;
+        unsigned long long bal[16];
+        uint32_t wave_count = 0;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            bal[j] = __ballot(mb[j] != 0);
+            wave_count += (uint32_t)__popcll(bal[j]);
+        }
+        if (lane == 0) {
+            wave_tile[wave] = wave_count;
+            wave_before[wave] = before;
         }
         __syncthreads();
-        uint32_t pos = incl - v, tile_total = 0, before_total = 0;
+        uint32_t pos = 0, tile_total = 0, before_total = 0;
         for (int w = 0; w < 16; ++w) {
             if (w < wave) pos += wave_tile[w];
             tile_total += wave_tile[w];
             before_total += wave_before[w];
         }
         pos += before_total;
+        const unsigned long long lt = (1ull << lane) - 1ull;
 #pragma unroll
-        for (int k = 0; k < 16; ++k)
-            if ((bits >> k) & 1u) {
-                *reinterpret_cast<uint4*>(&out[pos]) = *reinterpret_cast<const uint4*>(&matches[first + k]);
-                ++pos;
-            }
+        for (int j = 0; j < 16; ++j) {
+            const int i = wbase + j * 64 + lane;
+            if (mb[j]) *reinterpret_cast<uint4*>(&out[pos + (uint32_t)__popcll(bal[j] & lt)]) = *reinterpret_cast<const uint4*>(&matches[i]);
+            pos += (uint32_t)__popcll(bal[j]);
+        }
         total = before_total + tile_total;
     } else if (failed && m > 0 && m <= mcap && p.mask) {
         uint8_t* mask = p.mask + pr.match_off;  // a failed pair keeps nothing
@@ -402,7 +408,10 @@ hipError_t launch_filter_band(const FilterParams& p, int mcap, void* ws, const u
     }
     hipLaunchKernelGGL(band_codes_kernel, dim3((unsigned)((mcap + 4095) / 4096), (unsigned)n), dim3(1024), 0, stream, p, codes,
                        nfine, flags, mask_ws, mcap);
-    hipLaunchKernelGGL(band_filter_kernel, dim3(3, (unsigned)n), dim3(1024), kBandLdsBytes, stream, p, codes, nfine, flags,
+    // few pairs: one workgroup per (band, grid type) -- 12 per pair -- so that a single large pair spreads over more CUs (the
+    // grid types of a band are independent: each only ORs into the mask); many pairs: one per band, which streams less
+    const unsigned per_pair = n < 64 ? 12u : 3u;
+    hipLaunchKernelGGL(band_filter_kernel, dim3(per_pair, (unsigned)n), dim3(1024), kBandLdsBytes, stream, p, codes, nfine, flags,
                        mask_ws, mcap);
     hipLaunchKernelGGL(band_compact_kernel, dim3((unsigned)((mcap + 16383) / 16384), (unsigned)n), dim3(1024), 0, stream, p, flags,
                        mask_ws, mcap);
