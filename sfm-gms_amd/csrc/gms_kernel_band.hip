@@ -69,6 +69,30 @@ __device__ __forceinline__ uint32_t dpp_xor1(uint32_t x)
     return (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0xB1, 0xF, 0xF, true);  // quad_perm [1,0,3,2]
 }
 
+// Streams a pair's code words through the workgroup, 8 per thread per step, the next step's loads issued before the
+// current step is worked on (the loop is latency-bound otherwise). body(code word, match index) for every match.
+template <typename F>
+__device__ __forceinline__ void stream_codes(const uint32_t* __restrict__ code, int m, int tid, F&& body)
+{
+    uint32_t cur[8], nxt[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int i = k * 1024 + tid;
+        cur[k] = i < m ? code[i] : 0u;
+    }
+    for (int i0 = 0; i0 < m; i0 += 8 * 1024) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int i = i0 + 8 * 1024 + k * 1024 + tid;
+            nxt[k] = i < m ? code[i] : 0u;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) body(cur[k], i0 + k * 1024 + tid);  // code word 0 (not binned) beyond m
+#pragma unroll
+        for (int k = 0; k < 8; ++k) cur[k] = nxt[k];
+    }
+}
+
 }  // namespace
 
 // ---- code words + half-cell histogram -----------------------------------------------------------------------------
@@ -200,28 +224,19 @@ band_filter_kernel(FilterParams p, const uint32_t* codes, const uint32_t* nfine_
 
         // ---- assignMatchPairs for the rows this band holds (own + halo): +1 on the 16-bit entry, the count it produced
         //      into the row's running arg-max ((count - 1) << 9 | E', atomicMax: highest count, then lowest right cell)
-        for (int i0 = 0; i0 < m; i0 += 8 * 1024) {
-            uint32_t cw[8];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const int i = i0 + k * 1024 + tid;
-                cw[k] = i < m ? code[i] : 0u;
+        stream_codes(code, m, tid, [&](uint32_t cw, int) {
+            const uint32_t lx = (((cw >> kHxShift) & 63u) + (uint32_t)gx) >> 1;
+            const uint32_t ly = (((cw >> kHyShift) & 63u) + (uint32_t)gy) >> 1;
+            // x >= 20 || y >= 20 -> -1 (DLL@0x180047d3d); rows outside [row0, row1) belong to another band
+            if ((cw & kBinned) && lx < (uint32_t)kLeftW && ly >= (uint32_t)row0 && ly < (uint32_t)row1) {
+                const uint32_t e = cw & 0x1FFu;  // E' = 400 - r
+                const uint32_t row = (__umul24(ly - (uint32_t)row0, (uint32_t)kLeftW) + lx) * kRowBytes;
+                const uint32_t at = row + 4u + 2u * (e - 1u);
+                const uint32_t sh = (at & 2u) << 3;
+                const uint32_t old = atomicAdd(lds_at(smem, at & ~3u), 1u << sh);
+                atomicMax(lds_at(smem, row), (((old >> sh) & 0xFFFFu) << 9) | e);
             }
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const uint32_t lx = (((cw[k] >> kHxShift) & 63u) + (uint32_t)gx) >> 1;
-                const uint32_t ly = (((cw[k] >> kHyShift) & 63u) + (uint32_t)gy) >> 1;
-                // x >= 20 || y >= 20 -> -1 (DLL@0x180047d3d); rows outside [row0, row1) belong to another band
-                if ((cw[k] & kBinned) && lx < (uint32_t)kLeftW && ly >= (uint32_t)row0 && ly < (uint32_t)row1) {
-                    const uint32_t e = cw[k] & 0x1FFu;  // E' = 400 - r
-                    const uint32_t row = (__umul24(ly - (uint32_t)row0, (uint32_t)kLeftW) + lx) * kRowBytes;
-                    const uint32_t at = row + 4u + 2u * (e - 1u);
-                    const uint32_t sh = (at & 2u) << 3;
-                    const uint32_t old = atomicAdd(lds_at(smem, at & ~3u), 1u << sh);
-                    atomicMax(lds_at(smem, row), (((old >> sh) & 0xFFFFu) << 9) | e);
-                }
-            }
-        }
+        });
         __syncthreads();
 
         // ---- verifyCellPairs for the band's own cells: two lanes per cell, four neighbours each, joined by one DPP exchange
@@ -270,23 +285,14 @@ band_filter_kernel(FilterParams p, const uint32_t* codes, const uint32_t* nfine_
         __syncthreads();
 
         // ---- mark: cellPairs[l] == r for the matches whose left cell is one of the band's own
-        for (int i0 = 0; i0 < m; i0 += 8 * 1024) {
-            uint32_t cw[8];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const int i = i0 + k * 1024 + tid;
-                cw[k] = i < m ? code[i] : 0u;
+        stream_codes(code, m, tid, [&](uint32_t cw, int i) {
+            const uint32_t lx = (((cw >> kHxShift) & 63u) + (uint32_t)gx) >> 1;
+            const uint32_t ly = (((cw >> kHyShift) & 63u) + (uint32_t)gy) >> 1;
+            if ((cw & kBinned) && lx < (uint32_t)kLeftW && ly >= (uint32_t)lo && ly < (uint32_t)hi) {
+                const uint32_t cp = smem[((__umul24(ly - (uint32_t)row0, (uint32_t)kLeftW) + lx) * kRowBytes) >> 2];
+                if (cp == (((cw & 0x1FFu) << 1) | 1u)) mask[i] = 1;
             }
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const uint32_t lx = (((cw[k] >> kHxShift) & 63u) + (uint32_t)gx) >> 1;
-                const uint32_t ly = (((cw[k] >> kHyShift) & 63u) + (uint32_t)gy) >> 1;
-                if ((cw[k] & kBinned) && lx < (uint32_t)kLeftW && ly >= (uint32_t)lo && ly < (uint32_t)hi) {
-                    const uint32_t cp = smem[((__umul24(ly - (uint32_t)row0, (uint32_t)kLeftW) + lx) * kRowBytes) >> 2];
-                    if (cp == (((cw[k] & 0x1FFu) << 1) | 1u)) mask[i0 + k * 1024 + tid] = 1;
-                }
-            }
-        }
+        });
         __syncthreads();  // the next grid type clears the matrix
     }
 }
