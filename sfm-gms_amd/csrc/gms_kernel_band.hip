@@ -9,11 +9,12 @@
 // cell (of whatever grid type) belongs to exactly one band, so the bands of a pair never exchange anything: each
 // marks the matches its own cells accept in the pair's byte mask (all writers store 1), and the mask is the OR over
 // the four grid types by construction. Three stream-ordered launches per batch:
-//   band_codes_kernel    one thread per match: (queryIdx, trainIdx) + the two keypoint gathers -> a 4-byte code word
-//                        (right cell, half-cell coordinates of the left point) in a workspace slab, and the pair's
-//                        40 x 40 half-cell histogram (LDS-privatised per block, then global atomics);
-//   band_filter_kernel   grid (3 bands [x 4 grid types when the batch is small], pairs): per grid type clear, stream the code words (coalesced, 4 B per
-//                        match) for assignMatchPairs, verify the band's cells, stream again to mark;
+//   band_codes_kernel    one thread per match: (queryIdx, trainIdx) + the two keypoint gathers -> a code word (right
+//                        cell, half-cell coordinates of the left point) appended, with the match index, to the list of
+//                        every band that keeps the match's left row (1.2 lists per match on average), and the pair's
+//                        40 x 40 half-cell histogram (both LDS-privatised per block, then global atomics);
+//   band_filter_kernel   grid (3 bands [x 4 grid types when the batch is small], pairs): per grid type clear, stream the band's list (coalesced, 8 B per
+//                        entry) for assignMatchPairs, verify the band's cells, stream again to mark;
 //   band_compact_kernel  grid (16k-match tiles, pairs): order-preserving compaction of the DMatch records by the mask.
 // A pair with a left cell above 65 535 matches (a 16-bit entry could wrap) is flagged instead and left to the
 // HBM-slab kernel of gms_kernel_big.hip, which runs afterwards on flagged pairs only. Bit-exactness rules are the ones
@@ -69,37 +70,46 @@ __device__ __forceinline__ uint32_t dpp_xor1(uint32_t x)
     return (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0xB1, 0xF, 0xF, true);  // quad_perm [1,0,3,2]
 }
 
-// Streams a pair's code words through the workgroup, 8 per thread per step, the next step's loads issued before the
-// current step is worked on (the loop is latency-bound otherwise). body(code word, match index) for every match.
+// Streams a band's list of (code word, match index) entries through the workgroup, 8 per thread per step, the next step's
+// loads issued before the current step is worked on. body(code word, match index) for every entry.
 template <typename F>
-__device__ __forceinline__ void stream_codes(const uint32_t* __restrict__ code, int m, int tid, F&& body)
+__device__ __forceinline__ void stream_list(const uint2* __restrict__ list, int len, int tid, F&& body)
 {
-    uint32_t cur[8], nxt[8];
+    uint2 cur[8], nxt[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         const int i = k * 1024 + tid;
-        cur[k] = i < m ? code[i] : 0u;
+        cur[k] = i < len ? list[i] : make_uint2(0u, 0u);
     }
-    for (int i0 = 0; i0 < m; i0 += 8 * 1024) {
+    for (int i0 = 0; i0 < len; i0 += 8 * 1024) {
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const int i = i0 + 8 * 1024 + k * 1024 + tid;
-            nxt[k] = i < m ? code[i] : 0u;
+            nxt[k] = i < len ? list[i] : make_uint2(0u, 0u);
         }
 #pragma unroll
-        for (int k = 0; k < 8; ++k) body(cur[k], i0 + k * 1024 + tid);  // code word 0 (not binned) beyond m
+        for (int k = 0; k < 8; ++k) body(cur[k].x, (int)cur[k].y);  // code word 0 (not binned) beyond the list
 #pragma unroll
         for (int k = 0; k < 8; ++k) cur[k] = nxt[k];
     }
+}
+
+// rows a band keeps in LDS: its own [lo, hi) plus one halo row on either side
+__device__ __forceinline__ bool band_holds(int band, uint32_t row)
+{
+    int lo, hi;
+    band_rows(band, lo, hi);
+    return (int)row >= lo - 1 && (int)row < hi + 1;
 }
 
 }  // namespace
 
 // ---- code words + half-cell histogram -----------------------------------------------------------------------------
 __global__ void __launch_bounds__(1024)
-band_codes_kernel(FilterParams p, uint32_t* codes, uint32_t* nfine_g, uint32_t* flags, uint8_t* mask_ws, int mcap)
+band_codes_kernel(FilterParams p, uint2* lists, uint32_t* list_len, uint32_t* nfine_g, uint32_t* flags, uint8_t* mask_ws, int mcap)
 {
     __shared__ uint32_t hist[kFineN];
+    __shared__ uint32_t cnt_l[3], base_g[3];
     const int pi = blockIdx.y, tid = threadIdx.x;
     const gms_pair pr = p.pairs[pi];
     const int m = pr.m;
@@ -120,10 +130,10 @@ band_codes_kernel(FilterParams p, uint32_t* codes, uint32_t* nfine_g, uint32_t* 
     const float2* __restrict__ ptsA = p.pts + offA;
     const float2* __restrict__ ptsB = p.pts + offB;
     const gms_dmatch* __restrict__ matches = p.matches + pr.match_off;
-    uint32_t* code = codes + (size_t)pi * mcap;
     uint8_t* mask = p.mask ? p.mask + pr.match_off : mask_ws + (size_t)pi * mcap;
 
     for (int j = tid; j < kFineN; j += 1024) hist[j] = 0;
+    if (tid < 3) cnt_l[tid] = 0;
     __syncthreads();
     uint2 qt[4];
 #pragma unroll
@@ -135,6 +145,7 @@ band_codes_kernel(FilterParams p, uint32_t* codes, uint32_t* nfine_g, uint32_t* 
         b[k] = ptsB[min(qt[k].y, (uint32_t)(nB - 1))];
     }
     bool any_bad = false;
+    uint32_t cw[4], rank[4][3];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int i = base + k * 1024 + tid;
@@ -151,9 +162,13 @@ band_codes_kernel(FilterParams p, uint32_t* codes, uint32_t* nfine_g, uint32_t* 
         const bool binned = live && ok && hx < 40u && hy < 40u;
         if (binned) atomicAdd(&hist[hy * kFineW + hx], 1u);
         any_bad |= live && !ok;
-        if (live) {
-            code[i] = binned ? (((uint32_t)kRightN - r) | (hx << kHxShift) | (hy << kHyShift) | kBinned) : 0u;
-            mask[i] = 0;
+        if (live) mask[i] = 0;
+        cw[k] = binned ? (((uint32_t)kRightN - r) | (hx << kHxShift) | (hy << kHyShift) | kBinned) : 0u;
+        // the bands that keep this match's left row under the unshifted (hy >> 1) or the y-shifted ((hy + 1) >> 1) grid types
+#pragma unroll
+        for (int bnd = 0; bnd < 3; ++bnd) {
+            const bool need = binned && (band_holds(bnd, hy >> 1) || (hy < 39u && band_holds(bnd, (hy + 1u) >> 1)));
+            rank[k][bnd] = need ? atomicAdd(&cnt_l[bnd], 1u) : 0xFFFFFFFFu;
         }
     }
     if (any_bad) atomicOr(&flags[pi], kFlagDomain);
@@ -161,11 +176,22 @@ band_codes_kernel(FilterParams p, uint32_t* codes, uint32_t* nfine_g, uint32_t* 
     uint32_t* nf = nfine_g + (size_t)pi * kFineN;
     for (int j = tid; j < kFineN; j += 1024)
         if (hist[j]) atomicAdd(&nf[j], hist[j]);
+    // this block's entries go to the end of the pair's three band lists (list order does not matter: every consumer is
+    // either a commutative atomic or a store of 1 to the match's own mask byte)
+    if (tid < 3) base_g[tid] = cnt_l[tid] ? atomicAdd(&list_len[pi * 3 + tid], cnt_l[tid]) : 0u;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int bnd = 0; bnd < 3; ++bnd)
+            if (rank[k][bnd] != 0xFFFFFFFFu)
+                lists[((size_t)pi * 3 + bnd) * mcap + base_g[bnd] + rank[k][bnd]] = make_uint2(cw[k], (uint32_t)(base + k * 1024 + tid));
 }
 
 // ---- one band of one pair -------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(1024)
-band_filter_kernel(FilterParams p, const uint32_t* codes, const uint32_t* nfine_g, uint32_t* flags, uint8_t* mask_ws, int mcap)
+band_filter_kernel(FilterParams p, const uint2* lists, const uint32_t* list_len, const uint32_t* nfine_g, uint32_t* flags,
+                   uint8_t* mask_ws, int mcap)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     const int band = blockIdx.x % 3, pi = blockIdx.y, tid = threadIdx.x;
@@ -174,7 +200,8 @@ band_filter_kernel(FilterParams p, const uint32_t* codes, const uint32_t* nfine_
     const int m = pr.m;
     if (m <= 0 || m > mcap) return;
     if (flags[pi] & kFlagDomain) return;  // written by the previous launch
-    const uint32_t* __restrict__ code = codes + (size_t)pi * mcap;
+    const uint2* __restrict__ list = lists + ((size_t)pi * 3 + band) * mcap;
+    const int len = (int)list_len[pi * 3 + band];
     const uint32_t* __restrict__ nf = nfine_g + (size_t)pi * kFineN;
     uint8_t* mask = p.mask ? p.mask + pr.match_off : mask_ws + (size_t)pi * mcap;
 
@@ -224,7 +251,7 @@ band_filter_kernel(FilterParams p, const uint32_t* codes, const uint32_t* nfine_
 
         // ---- assignMatchPairs for the rows this band holds (own + halo): +1 on the 16-bit entry, the count it produced
         //      into the row's running arg-max ((count - 1) << 9 | E', atomicMax: highest count, then lowest right cell)
-        stream_codes(code, m, tid, [&](uint32_t cw, int) {
+        stream_list(list, len, tid, [&](uint32_t cw, int) {
             const uint32_t lx = (((cw >> kHxShift) & 63u) + (uint32_t)gx) >> 1;
             const uint32_t ly = (((cw >> kHyShift) & 63u) + (uint32_t)gy) >> 1;
             // x >= 20 || y >= 20 -> -1 (DLL@0x180047d3d); rows outside [row0, row1) belong to another band
@@ -285,7 +312,7 @@ band_filter_kernel(FilterParams p, const uint32_t* codes, const uint32_t* nfine_
         __syncthreads();
 
         // ---- mark: cellPairs[l] == r for the matches whose left cell is one of the band's own
-        stream_codes(code, m, tid, [&](uint32_t cw, int i) {
+        stream_list(list, len, tid, [&](uint32_t cw, int i) {
             const uint32_t lx = (((cw >> kHxShift) & 63u) + (uint32_t)gx) >> 1;
             const uint32_t ly = (((cw >> kHyShift) & 63u) + (uint32_t)gy) >> 1;
             if ((cw & kBinned) && lx < (uint32_t)kLeftW && ly >= (uint32_t)lo && ly < (uint32_t)hi) {
@@ -391,19 +418,21 @@ band_compact_kernel(FilterParams p, const uint32_t* flags, uint8_t* mask_ws, int
 // ---- launch helpers ----------------------------------------------------------------------------------------------------
 size_t band_ws_bytes_per_pair(int mcap, bool need_mask)
 {
-    return (size_t)mcap * 4 + (size_t)kFineN * 4 + 4 + (need_mask ? (size_t)mcap : 0);
+    return (size_t)mcap * 24 + (size_t)kFineN * 4 + 16 + (need_mask ? (size_t)mcap : 0);
 }
 
-// ws layout for n pairs: codes [n][mcap] u32 | nfine [n][1600] u32 | flags [n] u32 | mask [n][mcap] u8 (if p.mask is null)
+// ws layout for n pairs: lists [n][3][mcap] uint2 | nfine [n][1600] u32 | list_len [n][3] u32 | flags [n] u32 |
+//                        mask [n][mcap] u8 (if p.mask is null)
 hipError_t launch_filter_band(const FilterParams& p, int mcap, void* ws, const uint32_t** flags_out, hipStream_t stream)
 {
     const int n = p.n_pairs;
     if (n <= 0) return hipSuccess;
-    uint32_t* codes = reinterpret_cast<uint32_t*>(ws);
-    uint32_t* nfine = codes + (size_t)n * mcap;
-    uint32_t* flags = nfine + (size_t)n * kFineN;
+    uint2* lists = reinterpret_cast<uint2*>(ws);
+    uint32_t* nfine = reinterpret_cast<uint32_t*>(lists + (size_t)n * 3 * mcap);
+    uint32_t* list_len = nfine + (size_t)n * kFineN;
+    uint32_t* flags = list_len + (size_t)n * 3;
     uint8_t* mask_ws = reinterpret_cast<uint8_t*>(flags + n);
-    hipError_t e = hipMemsetAsync(nfine, 0, ((size_t)n * kFineN + n) * 4, stream);
+    hipError_t e = hipMemsetAsync(nfine, 0, ((size_t)n * kFineN + (size_t)n * 4) * 4, stream);
     if (e != hipSuccess) return e;
     static bool attr_set = false;
     if (!attr_set) {
@@ -412,13 +441,13 @@ hipError_t launch_filter_band(const FilterParams& p, int mcap, void* ws, const u
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL(band_codes_kernel, dim3((unsigned)((mcap + 4095) / 4096), (unsigned)n), dim3(1024), 0, stream, p, codes,
-                       nfine, flags, mask_ws, mcap);
+    hipLaunchKernelGGL(band_codes_kernel, dim3((unsigned)((mcap + 4095) / 4096), (unsigned)n), dim3(1024), 0, stream, p, lists,
+                       list_len, nfine, flags, mask_ws, mcap);
     // few pairs: one workgroup per (band, grid type) -- 12 per pair -- so that a single large pair spreads over more CUs (the
     // grid types of a band are independent: each only ORs into the mask); many pairs: one per band, which streams less
     const unsigned per_pair = n < 64 ? 12u : 3u;
-    hipLaunchKernelGGL(band_filter_kernel, dim3(per_pair, (unsigned)n), dim3(1024), kBandLdsBytes, stream, p, codes, nfine, flags,
-                       mask_ws, mcap);
+    hipLaunchKernelGGL(band_filter_kernel, dim3(per_pair, (unsigned)n), dim3(1024), kBandLdsBytes, stream, p, lists, list_len,
+                       nfine, flags, mask_ws, mcap);
     hipLaunchKernelGGL(band_compact_kernel, dim3((unsigned)((mcap + 16383) / 16384), (unsigned)n), dim3(1024), 0, stream, p, flags,
                        mask_ws, mcap);
     *flags_out = flags;
