@@ -32,8 +32,10 @@ constexpr uint32_t kRowBytes = 4u + 2u * kRightN;          // header dword + 400
 constexpr int kBandRowsMax = 9;                            // 7 own rows + 2 halo rows
 constexpr uint32_t kMatrixBytes = kBandRowsMax * kLeftW * kRowBytes;  // 144 720
 constexpr uint32_t kNleftOff = kMatrixBytes;               // [400] u32: nLeft of every cell under the current grid type
-constexpr uint32_t kMiscOff = kNleftOff + 4u * kLeftN;     // [16] u32
+constexpr uint32_t kFineOff = kNleftOff + 4u * kLeftN;     // [1600] u32: the pair's half-cell histogram
+constexpr uint32_t kMiscOff = kFineOff + 4u * kFineN;      // [16] u32
 constexpr uint32_t kBandLdsBytes = kMiscOff + 64u;
+static_assert(kBandLdsBytes <= kLdsBytes, "band layout exceeds the LDS");
 static_assert(kMatrixBytes % 16 == 0, "the band matrix is cleared in uint4s");
 
 // code word: E' = 400 - r (1..400; higher = lower right cell) : 9 | hx : 6 | hy : 6 | binned : 1
@@ -70,27 +72,28 @@ __device__ __forceinline__ uint32_t dpp_xor1(uint32_t x)
     return (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0xB1, 0xF, 0xF, true);  // quad_perm [1,0,3,2]
 }
 
-// Streams a band's list of (code word, match index) entries through the workgroup, 8 per thread per step, the next step's
+// Streams a band's list of (code word, match index) entries through the workgroup, 4 per thread per step, the next step's
 // loads issued before the current step is worked on. body(code word, match index) for every entry.
 template <typename F>
 __device__ __forceinline__ void stream_list(const uint2* __restrict__ list, int len, int tid, F&& body)
 {
-    uint2 cur[8], nxt[8];
+    constexpr int kDepth = 4;
+    uint2 cur[kDepth], nxt[kDepth];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
+    for (int k = 0; k < kDepth; ++k) {
         const int i = k * 1024 + tid;
         cur[k] = i < len ? list[i] : make_uint2(0u, 0u);
     }
-    for (int i0 = 0; i0 < len; i0 += 8 * 1024) {
+    for (int i0 = 0; i0 < len; i0 += kDepth * 1024) {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int i = i0 + 8 * 1024 + k * 1024 + tid;
+        for (int k = 0; k < kDepth; ++k) {
+            const int i = i0 + kDepth * 1024 + k * 1024 + tid;
             nxt[k] = i < len ? list[i] : make_uint2(0u, 0u);
         }
 #pragma unroll
-        for (int k = 0; k < 8; ++k) body(cur[k].x, (int)cur[k].y);  // code word 0 (not binned) beyond the list
+        for (int k = 0; k < kDepth; ++k) body(cur[k].x, (int)cur[k].y);  // code word 0 (not binned) beyond the list
 #pragma unroll
-        for (int k = 0; k < 8; ++k) cur[k] = nxt[k];
+        for (int k = 0; k < kDepth; ++k) cur[k] = nxt[k];
     }
 }
 
@@ -213,6 +216,8 @@ band_filter_kernel(FilterParams p, const uint2* lists, const uint32_t* list_len,
     const int row0 = max(lo - 1, 0), row1 = min(hi + 1, kLeftH);  // rows held in LDS: [row0, row1)
     const uint32_t clear16 = (uint32_t)((row1 - row0) * kLeftW) * kRowBytes / 16u;
 
+    uint32_t* nfine = smem + kFineOff / 4;
+    for (int j = tid; j < kFineN; j += 1024) nfine[j] = nf[j];  // one coalesced read instead of four scattered ones per cell
     auto nleft_of = [&](int cell, int gx, int gy) -> uint32_t {
         const int hx0 = 2 * (cell % kLeftW) - gx, hy0 = 2 * (cell / kLeftW) - gy;  // hx0 + 1, hy0 + 1 <= 39
         uint32_t n = 0;
@@ -221,7 +226,7 @@ band_filter_kernel(FilterParams p, const uint2* lists, const uint32_t* list_len,
 #pragma unroll
             for (int dx = 0; dx < 2; ++dx) {
                 const int hx = hx0 + dx, hy = hy0 + dy;
-                if (hx >= 0 && hy >= 0) n += nf[hy * kFineW + hx];
+                if (hx >= 0 && hy >= 0) n += nfine[hy * kFineW + hx];
             }
         return n;
     };
@@ -239,8 +244,23 @@ band_filter_kernel(FilterParams p, const uint2* lists, const uint32_t* list_len,
         return;
     }
 
+    // The band's list is walked eight times (binning and marking under each grid type) and a batch's lists together do not
+    // stay in L2: the first kResident entries per thread are read once and kept in registers, only what is beyond them
+    // is streamed again every time.
+    constexpr int kResident = 24;
+    uint2 res[kResident];
+#pragma unroll
+    for (int k = 0; k < kResident; ++k) {
+        const int i = k * 1024 + tid;
+        res[k] = i < len ? list[i] : make_uint2(0u, 0u);
+    }
+
     for (int g = (g_only < 0 ? 0 : g_only); g < (g_only < 0 ? 4 : g_only + 1); ++g) {
         const int gx = g & 1, gy = g >> 1;
+        // opaque per grid type: otherwise every resident entry's field extraction is hoisted out of this loop and the
+        // extracted fields (several registers per entry) spill
+#pragma unroll
+        for (int k = 0; k < kResident; ++k) asm volatile("" : "+v"(res[k].x));
         if (tid < kLeftN) nleft[tid] = nleft_of(tid, gx, gy);
         {
             const uint4 z4 = make_uint4(0, 0, 0, 0);
@@ -251,7 +271,7 @@ band_filter_kernel(FilterParams p, const uint2* lists, const uint32_t* list_len,
 
         // ---- assignMatchPairs for the rows this band holds (own + halo): +1 on the 16-bit entry, the count it produced
         //      into the row's running arg-max ((count - 1) << 9 | E', atomicMax: highest count, then lowest right cell)
-        stream_list(list, len, tid, [&](uint32_t cw, int) {
+        auto bin_one = [&](uint32_t cw, int) {
             const uint32_t lx = (((cw >> kHxShift) & 63u) + (uint32_t)gx) >> 1;
             const uint32_t ly = (((cw >> kHyShift) & 63u) + (uint32_t)gy) >> 1;
             // x >= 20 || y >= 20 -> -1 (DLL@0x180047d3d); rows outside [row0, row1) belong to another band
@@ -263,7 +283,10 @@ band_filter_kernel(FilterParams p, const uint2* lists, const uint32_t* list_len,
                 const uint32_t old = atomicAdd(lds_at(smem, at & ~3u), 1u << sh);
                 atomicMax(lds_at(smem, row), (((old >> sh) & 0xFFFFu) << 9) | e);
             }
-        });
+        };
+#pragma unroll
+        for (int k = 0; k < kResident; ++k) bin_one(res[k].x, 0);  // code word 0 (not binned) beyond the list
+        if (len > kResident * 1024) stream_list(list + kResident * 1024, len - kResident * 1024, tid, bin_one);
         __syncthreads();
 
         // ---- verifyCellPairs for the band's own cells: two lanes per cell, four neighbours each, joined by one DPP exchange
@@ -312,14 +335,19 @@ band_filter_kernel(FilterParams p, const uint2* lists, const uint32_t* list_len,
         __syncthreads();
 
         // ---- mark: cellPairs[l] == r for the matches whose left cell is one of the band's own
-        stream_list(list, len, tid, [&](uint32_t cw, int i) {
+        auto mark_one = [&](uint32_t cw, int i) {
             const uint32_t lx = (((cw >> kHxShift) & 63u) + (uint32_t)gx) >> 1;
             const uint32_t ly = (((cw >> kHyShift) & 63u) + (uint32_t)gy) >> 1;
             if ((cw & kBinned) && lx < (uint32_t)kLeftW && ly >= (uint32_t)lo && ly < (uint32_t)hi) {
                 const uint32_t cp = smem[((__umul24(ly - (uint32_t)row0, (uint32_t)kLeftW) + lx) * kRowBytes) >> 2];
                 if (cp == (((cw & 0x1FFu) << 1) | 1u)) mask[i] = 1;
             }
-        });
+        };
+#pragma unroll
+        for (int k = 0; k < kResident; ++k) asm volatile("" : "+v"(res[k].x));  // (as above: no fields kept across verify)
+#pragma unroll
+        for (int k = 0; k < kResident; ++k) mark_one(res[k].x, (int)res[k].y);
+        if (len > kResident * 1024) stream_list(list + kResident * 1024, len - kResident * 1024, tid, mark_one);
         __syncthreads();  // the next grid type clears the matrix
     }
 }
