@@ -43,4 +43,14 @@ for flags in ((False, False), (True, True)):
     cpu = timeit(lambda: gms_oracle.match(c["size1"], c["size2"], c["kp1"], c["kp2"], c["matches"], *flags), 2)
     out[f"config4_50k_rot{int(flags[0])}_scale{int(flags[1])}"] = {
         "gpu_call_ms_incl_pcie": gpu * 1e3, "cpu_oracle_ms_1thread": cpu * 1e3}
+# device-resident batches of large pairs (256 pairs per launch, default flags): the band kernels, and the slab kernel alone
+import subprocess
+for feats in (50000, 168750):
+    for band in ("1", "0"):
+        env = dict(os.environ, GMS_BAND=band)
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu", "--no-extra", "--features", str(feats),
+                            "--pairs", "256", "--frames", "16", "--steps", "3", "--warmup", "1"], capture_output=True, text=True, env=env)
+        d = json.loads(r.stdout.strip().splitlines()[-1])
+        out[f"batch256_{feats}_default_flags_band{band}"] = {"pairs_per_s": d["value"], "gmatches_per_s": d["value"] * feats / 1e9,
+                                                              "ms_per_256_pairs": d["ms_per_step"]}
 print(json.dumps(out, indent=1))
