@@ -821,8 +821,7 @@ filter_kernel(FilterParams p)
 // Everything else has to live in the remaining 2.2 KB: the half-cell histogram and the current grid type's nLeft as
 // bytes, the rotation counters and a few sink dwords. The DMatch records stay in registers from the first load to
 // copy-out, so the match array is read exactly once.
-// A pair that does not qualify (a cell above 255 matches, a frame too large to stage, any input outside the parity
-// domain, scale hypotheses) is handed to hash_pair() by the same workgroup; results are identical.
+// A pair that does not qualify (a cell above 255 matches, any input outside the parity domain, scale hypotheses) is handed to hash_pair() by the same workgroup; results are identical.
 // ------------------------------------------------------------------------------------------------
 constexpr int kDenseRightW = 20, kDenseRightN = 400;            // right grid of scale 0: cvRound(20 * 1.0)
 constexpr uint32_t kDenseRow = 4u + kDenseRightN;               // header dword + one byte per right cell
@@ -899,7 +898,8 @@ __device__ __forceinline__ bool dense_pair(const FilterParams& p, uint32_t* smem
         return false;
     const int64_t offA = p.frame_off[pr.frame_a], offB = p.frame_off[pr.frame_b];
     const int nA = (int)(p.frame_off[pr.frame_a + 1] - offA), nB = (int)(p.frame_off[pr.frame_b + 1] - offB);
-    if (nA <= 0 || nB <= 0 || (uint32_t)nB * 8u > kDenseBytes) return false;
+    if (nA <= 0 || nB <= 0) return false;
+    const bool stage_b = (uint32_t)nB * 8u <= kDenseBytes;  // workgroup-uniform: frame B fits the (still unused) matrix area
     const float2* __restrict__ ptsA = p.pts + offA;
     const float2* __restrict__ ptsB = p.pts + offB;
     const gms_dmatch* __restrict__ matches = p.matches + pr.match_off;
@@ -926,8 +926,10 @@ __device__ __forceinline__ bool dense_pair(const FilterParams& p, uint32_t* smem
     // first records as they land instead of behind all of them.
     constexpr int kStageRegs = 10;  // 10 240 keypoints through registers; larger frames finish in a plain loop
     float2 tb[kStageRegs];
+    if (stage_b) {
 #pragma unroll
-    for (int i = 0; i < kStageRegs; ++i) tb[i] = ptsB[min(i * NT + tid, nB - 1)];
+        for (int i = 0; i < kStageRegs; ++i) tb[i] = ptsB[min(i * NT + tid, nB - 1)];
+    }
     // Up to 10 matches per thread the whole 16-byte records stay in registers until copy-out (the match array is read
     // once); at 16 per thread that would be 64 registers of a 128-register budget, so there only (queryIdx, trainIdx)
     // are loaded here and the survivors' records are read again at copy-out.
@@ -942,17 +944,19 @@ __device__ __forceinline__ bool dense_pair(const FilterParams& p, uint32_t* smem
     auto query_of = [&](int k) -> uint32_t { return kKeepRec ? rec[k].x : qt[k].x; };
     auto train_of = [&](int k) -> uint32_t { return kKeepRec ? rec[k].y : qt[k].y; };
     // motion.setTo(0) for the part of the matrix area that frame B does not occupy: now, while the loads are in flight
-    const uint32_t staged16 = ((uint32_t)nB * 8u + 15u) >> 4;  // uint4s holding the staged frame
+    const uint32_t staged16 = stage_b ? ((uint32_t)nB * 8u + 15u) >> 4 : 0u;  // uint4s holding the staged frame
     {
         const uint4 z4 = make_uint4(0, 0, 0, 0);
         uint4* d4 = reinterpret_cast<uint4*>(smem);
         for (uint32_t i = staged16 + tid; i < kDenseBytes / 16; i += NT) d4[i] = z4;
     }
     float2* lds_b = reinterpret_cast<float2*>(smem);
+    if (stage_b) {
 #pragma unroll
-    for (int i = 0; i < kStageRegs; ++i)
-        if (i * NT + tid < nB) lds_b[i * NT + tid] = tb[i];
-    for (int j = kStageRegs * NT + tid; j < nB; j += NT) lds_b[j] = ptsB[j];
+        for (int i = 0; i < kStageRegs; ++i)
+            if (i * NT + tid < nB) lds_b[i * NT + tid] = tb[i];
+        for (int j = kStageRegs * NT + tid; j < nB; j += NT) lds_b[j] = ptsB[j];
+    }
     __syncthreads();
     // the left-side gathers below are global loads and return behind the records whatever their issue time: wait for the
     // records once, so that the gathers go out together instead of one round trip per record
@@ -974,8 +978,13 @@ __device__ __forceinline__ bool dense_pair(const FilterParams& p, uint32_t* smem
         float2 a[KPT], b[KPT];
 #pragma unroll
         for (int k = 0; k < KPT; ++k) a[k] = ptsA[min(query_of(k), (uint32_t)(nA - 1))];
+        if (stage_b) {
 #pragma unroll
-        for (int k = 0; k < KPT; ++k) b[k] = lds_b[min(train_of(k), (uint32_t)(nB - 1))];
+            for (int k = 0; k < KPT; ++k) b[k] = lds_b[min(train_of(k), (uint32_t)(nB - 1))];
+        } else {  // a frame above 20 200 keypoints: the train-side gather goes to global memory like the query side
+#pragma unroll
+            for (int k = 0; k < KPT; ++k) b[k] = ptsB[min(train_of(k), (uint32_t)(nB - 1))];
+        }
 #ifdef GMS_PHASE_TIMING
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         GMS_STAMP(12);  // bin: gathers landed

@@ -2,7 +2,7 @@
 hand-over to the hashed path on the other side of each of its limits, against the CPU oracle, bit-exact. The cases
 sit right at the limits: 255 / 256 matches in a cell of the unshifted grid, in a cell that only exists under a shifted
 grid type, in one half cell (the byte histogram wraps at 256), one matrix entry reaching 255, a frame too large to
-stage, and eligible and ineligible pairs side by side in one launch."""
+stage in LDS, and eligible and ineligible pairs side by side in one launch."""
 import importlib
 
 import numpy as np
@@ -98,7 +98,7 @@ def test_all_matches_in_the_last_half_cell(ctx, oracle):
 
 
 def test_frame_too_large_to_stage(ctx, oracle):
-    """Frame B with more keypoints than the matrix area can stage (20 000): handed to the general path."""
+    """Frame B with more keypoints than the matrix area can stage (20 200): the train-side gather reads global memory."""
     rng = np.random.default_rng(9)
     n2, m = 20500, 6000
     xy2 = np.stack([rng.uniform(0, W - 1, n2), rng.uniform(0, H - 1, n2)], axis=1).astype(np.float32)
