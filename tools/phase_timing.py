@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--pairs", type=int, default=1024)
     ap.add_argument("--rot", type=int, default=0)
     ap.add_argument("--scale", type=int, default=0)
+    ap.add_argument("--features", type=int, default=10000)
     ap.add_argument("--starts", default="", help="save per-pair (start, records landed) wall-clock stamps to this .npy")
     a = ap.parse_args()
     capi = importlib.import_module("sfm-gms_amd.capi")
@@ -36,7 +37,7 @@ def main():
     ctx = pkg.GmsContext(0)
     stream = torch.cuda.Stream(device=dev)
     ctx.set_stream(stream.cuda_stream)
-    args = argparse.Namespace(pairs=a.pairs, frames=64, features=10000, inlier_frac=0.5)
+    args = argparse.Namespace(pairs=a.pairs, frames=64, features=a.features, inlier_frac=0.5)
     wl = bench.build_workload(args, 0, 1, dev, pkg, synth, ctx)
     dbuf = torch.zeros(a.pairs * 16, dtype=torch.int64, device=dev)
     lib.gms_diag_set_buffer.argtypes = [C.c_void_p]
