@@ -77,7 +77,7 @@ struct gms_ctx {
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     std::mutex mu;  // serialises the one-shot path's scratch buffers
-    DevBuf kp, foff, wh, pts, pair, matches, out, result, aux, big_ws, band_ws;
+    DevBuf kp, foff, wh, pts, pair, matches, out, result, aux, big_ws, band_ws, partial_ws;
     int n_cus = 256;  // multiProcessorCount of the device
 };
 
@@ -135,7 +135,7 @@ int gms_ctx_destroy(gms_ctx* c)
     if (!c) return GMS_OK;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    DevBuf* bufs[] = {&c->kp, &c->foff, &c->wh, &c->pts, &c->pair, &c->matches, &c->out, &c->result, &c->aux, &c->big_ws, &c->band_ws};
+    DevBuf* bufs[] = {&c->kp, &c->foff, &c->wh, &c->pts, &c->pair, &c->matches, &c->out, &c->result, &c->aux, &c->big_ws, &c->band_ws, &c->partial_ws};
     for (DevBuf* b : bufs) b->release();
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
@@ -215,6 +215,7 @@ int gms_filter_device(gms_ctx* c, const float* d_pts, const int64_t* d_frame_off
     p.with_scale = with_scale ? 1 : 0;
     p.threshold_factor = threshold_factor;
     p.pair_flags = nullptr;
+    p.partial = nullptr;
     right_grids(p.right_w, p.right_h);
     // GMS_DENSE=0 keeps every pair on the hashed path (diagnostics); by default the byte-matrix path is tried first
     // whenever there are no scale hypotheses (the reference's default flags, DisparityUtil.cpp:149,299)
@@ -236,6 +237,15 @@ int gms_filter_device(gms_ctx* c, const float* d_pts, const int64_t* d_frame_off
     if (kpt2) {
         p.table_slots = gms::occ2_table_slots(kpt2);
         GMS_HIP(gms::launch_filter_occ2(p, kpt2, n_pairs, c->stream));
+    } else if (kpt && with_scale && dense_on) {
+        // scale hypotheses: scales 0..2 on the byte matrix, the rest on the hashed path (two launches, one record per pair)
+        const size_t need = (size_t)n_pairs * gms::kPartialStrideDw * 4;
+        if (need > c->partial_ws.cap) {
+            GMS_HIP(hipStreamSynchronize(c->stream));
+            GMS_HIP(c->partial_ws.reserve(need));
+        }
+        p.partial = (uint32_t*)c->partial_ws.p;
+        GMS_HIP(gms::launch_filter_scales(p, kpt, n_pairs, c->stream));
     } else if (kpt) {
         GMS_HIP(gms::launch_filter(p, kpt, n_pairs, c->stream));
     } else {

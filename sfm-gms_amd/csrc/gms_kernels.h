@@ -12,6 +12,10 @@ constexpr int kLeftW = 20, kLeftH = 20, kLeftN = 400;  // DLL@0x180046ac6: fixed
 constexpr int kFineW = 40, kFineN = 1600;                  // half-cell grid: carries all four grid types
 constexpr int kThreads = 1024;                         // one 16-wave workgroup per image pair
 constexpr size_t kLdsBytes = 160 * 1024;               // gfx950 LDS per CU (and per workgroup)
+// record handed from filter_kernel_dense_scales to filter_kernel: state, best count, best scale, best rotation, then one
+// inlier bit per match of the best hypothesis so far (16 x 1024 matches at most)
+constexpr uint32_t kPartialHeaderDw = 4;
+constexpr uint32_t kPartialStrideDw = kPartialHeaderDw + 16 * 1024 / 32;
 
 struct FilterParams {
     const float2* pts;          // normalised keypoints of all frames
@@ -30,6 +34,7 @@ struct FilterParams {
     uint32_t table_slots;       // multiple of 4: data + header buckets of all 400 regions
     int region_shift;           // region slots per match = 1 + 2^-shift
     int with_rotation, with_scale;
+    uint32_t* partial;          // scale hypotheses: per-pair records of the byte-matrix kernel (scales 0..2), or null
     const uint32_t* pair_flags; // large-pair kernel only: when set, it filters just the pairs whose flag word has bit 1 set
     int dense;                  // try the byte-matrix path first (no scale hypotheses only); the general path is the fallback
     double threshold_factor;
@@ -46,6 +51,7 @@ size_t     filter_lds_bytes(int kpt, uint32_t table_slots);
 hipError_t launch_normalize(const gms_keypoint* d_kp, const int64_t* d_frame_off, const int32_t* d_wh,
                             int n_frames, int64_t total_kp, float* d_pts, hipStream_t stream);
 hipError_t launch_filter(const FilterParams& p, int kpt, int n_pairs, hipStream_t stream);
+hipError_t launch_filter_scales(const FilterParams& p, int kpt, int n_pairs, hipStream_t stream);
 // two-workgroups-per-CU variant (gms_kernel_occ2.hip), m <= 10 240
 int        occ2_pick_kpt(int max_m);
 uint32_t   occ2_table_slots(int kpt);

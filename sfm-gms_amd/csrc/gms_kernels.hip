@@ -287,7 +287,11 @@ __device__ __forceinline__ void hash_pair(const FilterParams& p, uint32_t* smem,
     if (tid < 48) misc[tid] = 0;
     if (tid < 128) trash[tid] = 0;
     if (tid >= 128 && tid < 132) trash[tid] = kEmpty;
-    for (int i = tid; i < (kMcap >> 5); i += NT) bestmask[i] = 0;
+    // with scale hypotheses the byte-matrix kernel may have evaluated scales 0..2 already (see dense_scales_pair): its
+    // record holds the best hypothesis so far, and this kernel continues with scale 3
+    const uint32_t* __restrict__ part = p.partial ? p.partial + (size_t)pair_idx * kPartialStrideDw : nullptr;
+    const bool resumed = part != nullptr && part[0] == 1u;  // workgroup-uniform
+    for (int i = tid; i < (kMcap >> 5); i += NT) bestmask[i] = resumed ? part[kPartialHeaderDw + i] : 0u;
     for (int i = tid; i < kFineStride; i += NT) nfine[i] = 0;
     for (int i = tid; i < 4 * kFineStride; i += NT) fdesc4[i] = 0;
 
@@ -306,8 +310,8 @@ __device__ __forceinline__ void hash_pair(const FilterParams& p, uint32_t* smem,
     const int mm = bad_pair ? 0 : m;
     const int n_scales = p.with_scale ? 5 : 1;
     const bool thr_fast = threshold_fast_ok(p.threshold_factor);
-    uint32_t best_count = 0;
-    int best_scale = -1, best_rot = -1;
+    uint32_t best_count = resumed ? part[1] : 0u;
+    int best_scale = resumed ? (int)part[2] : -1, best_rot = resumed ? (int)part[3] : -1;
     GMS_STAMP_DECL
     if (mm == 0 || nA <= 0 || nB <= 0) {  // workgroup-uniform: nothing to filter (or nothing valid to index)
         if (tid == 0) {
@@ -434,7 +438,7 @@ __device__ __forceinline__ void hash_pair(const FilterParams& p, uint32_t* smem,
     __syncthreads();
     GMS_STAMP(1);  // region tables
 
-    for (int s = 0; s < n_scales; ++s) {
+    for (int s = resumed ? 3 : 0; s < n_scales; ++s) {
         const int wr = p.right_w[s], hr = p.right_h[s];
 
         if (s > 0) {
@@ -1275,6 +1279,352 @@ filter_kernel_dense(FilterParams p)
     if (!dense_pair<KPT, ROT, NT>(p, smem, (int)blockIdx.x, (int)threadIdx.x)) hash_pair<KPT, ROT, NT>(p, smem, (int)blockIdx.x, (int)threadIdx.x);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Scale hypotheses on the byte matrix (dense_scales_pair): the right grids of scales 0, 1 and 2 are 20 x 20,
+// 10 x 10 and 14 x 14, so their motion matrices (400 x 400, 400 x 100, 400 x 196 bytes) fit the LDS like the default
+// case; 28 x 28 and 40 x 40 (scales 3 and 4) do not. With scale hypotheses a launch therefore runs two kernels: this
+// one evaluates scales 0..2 (all rotations) and leaves the best hypothesis so far -- count, (scale, rotation), the
+// inlier bit of every match -- in a per-pair workspace record; filter_kernel then picks the record up, evaluates
+// scales 3 and 4 on the hashed path, and selects and copies out as always (getInlierMask's order is scale-outer,
+// rotation-inner with strict '>', so "best of 0..2, then 3, 4" is the same comparison sequence). A pair this kernel
+// cannot take (a cell above 255 matches, inputs outside the parity domain) gets an empty record and the hashed path
+// evaluates all five scales.
+// Everything is dense_pair() with a runtime row stride; the records are not kept (nothing is copied out here).
+// ------------------------------------------------------------------------------------------------
+constexpr uint32_t kDenseBestMaskOff = 120u * 1024u;                      // best mask so far: above every scale >= 1 matrix
+
+template <int KPT, bool ROT, int NT>
+__device__ __forceinline__ bool dense_scales_pair(const FilterParams& p, uint32_t* smem, const int pair_idx, const int tid,
+                                                  uint32_t* __restrict__ part)
+{
+    constexpr int kMcap = KPT * NT;
+    constexpr int kNRot = ROT ? 8 : 1;
+    constexpr int kChunk = (KPT % 5 == 0) ? 5 : 4;
+    static_assert(KPT % kChunk == 0, "KPT must be a multiple of the chunk");
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+
+    const gms_pair pr = p.pairs[pair_idx];
+    const int m = pr.m;
+    if (!p.with_scale || m <= 0 || m > kMcap || pr.frame_a < 0 || pr.frame_a >= p.n_frames || pr.frame_b < 0 ||
+        pr.frame_b >= p.n_frames)
+        return false;
+    if (p.right_w[0] != 20 || p.right_h[0] != 20 || p.right_w[1] != 10 || p.right_h[1] != 10 || p.right_w[2] != 14 ||
+        p.right_h[2] != 14)
+        return false;
+    const int64_t offA = p.frame_off[pr.frame_a], offB = p.frame_off[pr.frame_b];
+    const int nA = (int)(p.frame_off[pr.frame_a + 1] - offA), nB = (int)(p.frame_off[pr.frame_b + 1] - offB);
+    if (nA <= 0 || nB <= 0) return false;
+    const bool stage_b = (uint32_t)nB * 8u <= kDenseBytes;  // workgroup-uniform
+    const float2* __restrict__ ptsA = p.pts + offA;
+    const float2* __restrict__ ptsB = p.pts + offB;
+    const gms_dmatch* __restrict__ matches = p.matches + pr.match_off;
+
+    const uint8_t* dense8 = reinterpret_cast<const uint8_t*>(smem);
+    uint32_t* nfine32 = smem + kDenseFineOff / 4;
+    const uint8_t* nfine8 = reinterpret_cast<const uint8_t*>(nfine32);
+    uint8_t* nleft8 = reinterpret_cast<uint8_t*>(smem) + kDenseNleftOff;
+    uint32_t* misc = smem + kDenseMiscOff / 4;
+    uint32_t* trash = smem + kDenseTrashOff / 4;
+    uint32_t* bestmask = smem + kDenseBestMaskOff / 4;
+
+    if (tid < 32) misc[tid] = 0;
+    if (tid < 16) trash[tid] = 0;
+    if (tid < kFineN / 4) nfine32[tid] = 0;
+
+    constexpr int kStageRegs = 10;
+    float2 tb[kStageRegs];
+    if (stage_b) {
+#pragma unroll
+        for (int i = 0; i < kStageRegs; ++i) tb[i] = ptsB[min(i * NT + tid, nB - 1)];
+    }
+    uint2 qt[KPT];
+#pragma unroll
+    for (int k = 0; k < KPT; ++k) qt[k] = *reinterpret_cast<const uint2*>(&matches[min(k * NT + tid, m - 1)]);
+    const uint32_t staged16 = stage_b ? ((uint32_t)nB * 8u + 15u) >> 4 : 0u;
+    {
+        const uint4 z4 = make_uint4(0, 0, 0, 0);
+        uint4* d4 = reinterpret_cast<uint4*>(smem);
+        for (uint32_t i = staged16 + tid; i < kDenseBytes / 16; i += NT) d4[i] = z4;
+    }
+    float2* lds_b = reinterpret_cast<float2*>(smem);
+    if (stage_b) {
+#pragma unroll
+        for (int i = 0; i < kStageRegs; ++i)
+            if (i * NT + tid < nB) lds_b[i * NT + tid] = tb[i];
+        for (int j = kStageRegs * NT + tid; j < nB; j += NT) lds_b[j] = ptsB[j];
+    }
+    __syncthreads();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (see dense_pair: the left-side gathers go out together)
+
+    // code word as in dense_pair (E = E(r) of the current scale); cell1 = left cell under grid type 1; rs = the right
+    // cells of scales 1 and 2 (bits 0..7 and 8..15)
+    uint32_t code[KPT], cell1[KPT], rs[KPT];
+    {
+        float2 a[KPT], b[KPT];
+#pragma unroll
+        for (int k = 0; k < KPT; ++k) a[k] = ptsA[min(qt[k].x, (uint32_t)(nA - 1))];
+        if (stage_b) {
+#pragma unroll
+            for (int k = 0; k < KPT; ++k) b[k] = lds_b[min(qt[k].y, (uint32_t)(nB - 1))];
+        } else {
+#pragma unroll
+            for (int k = 0; k < KPT; ++k) b[k] = ptsB[min(qt[k].y, (uint32_t)(nB - 1))];
+        }
+        bool any_bad = false, spill = false;
+#pragma unroll
+        for (int k = 0; k < KPT; ++k) {
+            const bool live = k * NT + tid < m;
+            const uint32_t worst = max(max(__float_as_uint(a[k].x), __float_as_uint(a[k].y)),
+                                       max(__float_as_uint(b[k].x), __float_as_uint(b[k].y)));
+            const float fx = 20.0f * a[k].x, fy = 20.0f * a[k].y;   // mulss, rounded to fp32
+            const uint32_t hx = (uint32_t)(int)(fx + fx), hy = (uint32_t)(int)(fy + fy);  // floor(2f), 2f exact
+            // getGridIndexRight per scale: (int)(wr * x) + (int)(wr * y) * wr, no bounds test (clamped 24-bit form: see dense_pair)
+            uint32_t r[3];
+            bool in_grid = true;
+#pragma unroll
+            for (int s = 0; s < 3; ++s) {
+                const uint32_t wr = s == 0 ? 20u : s == 1 ? 10u : 14u;
+                const float fw = (float)wr;
+                const uint32_t rx = (uint32_t)(int)(fw * b[k].x), ry = (uint32_t)(int)(fw * b[k].y);
+                r[s] = __umul24(min(ry, 4096u), wr) + min(rx, 4096u);
+                in_grid = in_grid && r[s] < wr * wr;
+            }
+            const bool ok = ((int)(qt[k].x < (uint32_t)nA) & (int)(qt[k].y < (uint32_t)nB) & (int)(worst < 0x49800000u) & (int)in_grid) != 0;
+            const bool binned = live & ok & (max(hx, hy) < 40u);
+            const uint32_t f = binned ? __umul24(hy, (uint32_t)kFineW) + hx : 0u;
+            const uint32_t old = atomicAdd(binned ? &nfine32[f >> 2] : &trash[lane & 7], 1u << ((f << 3) & 31u));
+            spill |= binned & (((old >> ((f << 3) & 31u)) & 255u) == 255u);
+            any_bad |= live & !ok;
+            const uint32_t q = (hx & 1u) + __umul24(hy & 1u, 20u);
+            const uint32_t edge = ((hx + 25u) & kDEdgeX) | ((hy + 89u) & kDEdgeY);
+            code[k] = binned ? (q | edge | ((403u - r[0]) << kDEShift)) : kDNever;
+            cell1[k] = binned ? __umul24(hy >> 1, (uint32_t)kLeftW) + (hx >> 1) : 0u;
+            rs[k] = binned ? (r[1] | (r[2] << 8)) : 0u;
+        }
+        if (any_bad) misc[8] = 1;
+        if (spill) misc[11] = 1;
+    }
+    __syncthreads();
+    {
+        const uint4 z4 = make_uint4(0, 0, 0, 0);
+        uint4* d4 = reinterpret_cast<uint4*>(smem);
+        for (uint32_t i = tid; i < staged16; i += NT) d4[i] = z4;
+    }
+    __syncthreads();
+    if ((misc[8] | misc[11]) != 0) {  // workgroup-uniform
+        __syncthreads();
+        return false;
+    }
+
+    const bool thr_fast = threshold_fast_ok(p.threshold_factor);
+    const uint32_t f2i = dense_factor_sq(p.threshold_factor);
+    uint32_t best_count = 0;
+    int best_scale = -1, best_rot = -1;
+    for (int s = 0; s < 3; ++s) {
+        const uint32_t wr = (uint32_t)p.right_w[s], nr = wr * wr;
+        const uint32_t stride = 4u + nr;                 // header dword + one byte per right cell
+        const uint32_t wr_magic = 65535u / wr + 1u;      // j / wr == (j * magic) >> 16 for j * wr < 65536
+        if (s > 0) {
+#pragma unroll
+            for (int k = 0; k < KPT; ++k) {
+                const uint32_t r = s == 1 ? (rs[k] & 0xFFu) : (rs[k] >> 8);
+                if (!(code[k] & kDNever)) code[k] = (code[k] & ~(kDEMask << kDEShift)) | ((nr + 3u - r) << kDEShift);
+            }
+        }
+        for (int g = 0; g < 4; ++g) {
+            const int gx = g & 1, gy = g >> 1;
+            const uint32_t q_mask = (uint32_t)(gx + 20 * gy);
+            const uint32_t out_mask = kDNever | (gx ? kDEdgeX : 0u) | (gy ? kDEdgeY : 0u);
+            const uint32_t key_tag = (uint32_t)g << kDTagShift;
+            if (tid < kLeftN) {
+                const uint32_t n = dense_nleft(nfine8, tid % kLeftW, tid / kLeftW, gx, gy);
+                if (n > 255u) misc[11] = 1;
+                nleft8[tid] = (uint8_t)n;
+            }
+            // ---- assignMatchPairs
+#pragma unroll
+            for (int k0 = 0; k0 < KPT; k0 += kChunk) {
+                uint32_t old[kChunk], at[kChunk], row[kChunk];
+#pragma unroll
+                for (int c = 0; c < kChunk; ++c) {
+                    const uint32_t cw = code[k0 + c];
+                    row[c] = __umul24(cell1[k0 + c] + (cw & q_mask), stride);
+                    at[c] = row[c] + ((cw >> kDEShift) & kDEMask);
+                    old[c] = 0;
+                    if ((cw & out_mask) == 0) old[c] = atomicAdd(lds_at(smem, at[c] & ~3u), 1u << ((at[c] << 3) & 31u));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int c = 0; c < kChunk; ++c) {
+                    const uint32_t cw = code[k0 + c];
+                    const uint32_t before = (old[c] >> ((at[c] << 3) & 31u)) & 255u;
+                    if ((cw & out_mask) == 0) atomicMax(lds_at(smem, row[c]), key_tag | (before << 11) | ((cw >> kDEShift) & kDEMask));
+                }
+            }
+            __syncthreads();
+            if (misc[11] != 0) {  // a cell above 255 matches (workgroup-uniform; nothing has been written out)
+                __syncthreads();
+                return false;
+            }
+
+            // ---- verifyCellPairs: two lanes per cell without rotation, one lane per (cell, rotation) with
+            {
+                constexpr int kItems = ROT ? kLeftN * 8 : kLeftN * 2;
+                for (int item = tid; item < ((kItems + 63) & ~63); item += NT) {
+                    const bool live = item < kItems;
+                    const int i = live ? (ROT ? (item >> 3) : (item >> 1)) : 0;
+                    const int rot = ROT ? (item & 7) : 0;
+                    const int half = item & 1;  // !ROT only
+                    const int ix = i % kLeftW, iy = i / kLeftW;
+                    const uint32_t ni = live ? nleft8[i] : 0u;
+                    const uint32_t best = smem[(uint32_t)i * (stride >> 2)] & ((1u << kDTagShift) - 1u);
+                    const uint32_t ej = ni ? (best & kDEMask) : nr + 3u;
+                    const uint32_t j = nr + 3u - ej;
+                    const int jy = (int)((j * wr_magic) >> 16), jx = (int)j - jy * (int)wr;
+                    uint32_t score = 0, tn = 0;  // tn = (sum of nLeft << 4) | numpair
+#pragma unroll
+                    for (int h = 0; h < (ROT ? 8 : 4); h += 4) {
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            int ldx, ldy, rdx, rdy;
+                            if (ROT) {
+                                const int k8 = h + c;
+                                const int k = k8 < 4 ? k8 : k8 + 1;
+                                constexpr int kRingIndex[9] = {0, 1, 2, 7, -1, 3, 6, 5, 4};
+                                const int q = rotated_position(rot, kRingIndex[k]);
+                                ldx = (k % 3) - 1; ldy = (k / 3) - 1;
+                                rdx = position_dx(q); rdy = position_dy(q);
+                            } else {
+                                ldx = half ? ((c + 5) % 3) - 1 : (c % 3) - 1;
+                                ldy = half ? ((c + 5) / 3) - 1 : (c / 3) - 1;
+                                rdx = ldx; rdy = ldy;
+                            }
+                            const int lx = ix + ldx, ly = iy + ldy;
+                            const int rx = jx + rdx, ry = jy + rdy;
+                            const bool okl = ni != 0 && (uint32_t)lx < (uint32_t)kLeftW && (uint32_t)ly < (uint32_t)kLeftH;
+                            const bool okp = okl && (uint32_t)rx < wr && (uint32_t)ry < wr;
+                            const uint32_t ll = okl ? (uint32_t)(lx + ly * kLeftW) : 0u;
+                            const uint32_t nll = nleft8[ll];
+                            const uint32_t cnt = dense8[ll * stride + (okp ? nr + 3u - (uint32_t)(rx + ry * (int)wr) : 4u)];
+                            score += okp ? cnt : 0u;
+                            tn += okp ? ((nll << 4) | 1u) : 0u;
+                        }
+                    }
+                    if (!ROT) {
+                        score += dpp_xor1(score);
+                        tn += dpp_xor1(tn);
+                    }
+                    score += (best >> 11) + 1u;
+                    tn += (ni << 4) | 1u;
+                    uint32_t pass = 0;
+                    if (ni != 0 && (ROT || half == 0))
+                        pass = dense_threshold_rejects(tn >> 4, tn & 15u, score, p.threshold_factor, thr_fast, f2i) ? 0u : 1u;
+                    uint32_t bits = pass;
+                    bool writer = ni != 0 && half == 0;
+                    if (ROT) {
+                        const unsigned long long bal = __ballot(pass);
+                        bits = (uint32_t)(bal >> (lane & 56)) & 0xFFu;
+                        writer = ni != 0 && (lane & 7) == 0;
+                    }
+                    if (writer) smem[(uint32_t)i * (stride >> 2)] = (ej << 8) | bits;
+                }
+            }
+            __syncthreads();
+
+            // ---- mark, and every increment taken back (the matrix is all zero again after each grid type)
+            {
+                uint32_t cr[KPT];
+#pragma unroll
+                for (int k = 0; k < KPT; ++k) {
+                    const uint32_t cw = code[k];
+                    const uint32_t row = __umul24(cell1[k] + (cw & q_mask), stride);
+                    cr[k] = 0xFFFFFFFFu;
+                    if ((cw & out_mask) == 0) {
+                        cr[k] = smem[row >> 2];
+                        const uint32_t at = row + ((cw >> kDEShift) & kDEMask);
+                        atomicSub(lds_at(smem, at & ~3u), 1u << ((at << 3) & 31u));
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < KPT; ++k) {
+                    const uint32_t x = cr[k] ^ (code[k] & (kDEMask << kDEShift));
+                    if (x < 256u) code[k] |= x << kDAccShift;
+                }
+            }
+            __syncthreads();
+        }
+        // the next scale lays its rows out differently: no header of this one may survive as a count byte
+        if (tid < kLeftN) smem[(uint32_t)tid * (stride >> 2)] = 0;
+
+        // ---- run() return value per rotation of this scale, getInlierMask's strict '>'
+        {
+            uint32_t cnt[kNRot];
+#pragma unroll
+            for (int r = 0; r < kNRot; ++r) cnt[r] = 0;
+#pragma unroll
+            for (int k = 0; k < KPT; ++k)
+#pragma unroll
+                for (int r = 0; r < kNRot; ++r)
+                    cnt[r] += (uint32_t)__popcll(__ballot((code[k] >> (kDAccShift + r)) & 1u));
+            if (lane == 0) {
+#pragma unroll
+                for (int r = 0; r < kNRot; ++r)
+                    if (cnt[r]) atomicAdd(&misc[r], cnt[r]);
+            }
+        }
+        __syncthreads();  // counts complete; headers zeroed
+        int winner = -1;
+#pragma unroll
+        for (int r = 0; r < kNRot; ++r) {
+            const uint32_t c = misc[r];
+            if (c > best_count) {
+                best_count = c;
+                best_scale = s;
+                best_rot = r + 1;
+                winner = r;
+            }
+        }
+        if (winner >= 0) {
+#pragma unroll
+            for (int k = 0; k < KPT; ++k) {
+                const unsigned long long bsel = __ballot((code[k] >> (kDAccShift + winner)) & 1u);
+                if (lane == 0) {
+                    const int ch = k * (NT / 64) + wave;  // chunk of 64 consecutive matches
+                    bestmask[2 * ch] = (uint32_t)bsel;
+                    bestmask[2 * ch + 1] = (uint32_t)(bsel >> 32);
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < KPT; ++k) code[k] &= ~(0xFFu << kDAccShift);
+        __syncthreads();
+        if (tid < 8) misc[tid] = 0;
+    }
+    __syncthreads();
+    // the record the hashed kernel continues from
+    if (tid == 0) {
+        part[0] = 1u;
+        part[1] = best_count;
+        part[2] = (uint32_t)best_scale;
+        part[3] = (uint32_t)best_rot;
+    }
+    for (int i = tid; i < (kMcap >> 5); i += NT) part[kPartialHeaderDw + i] = best_count ? bestmask[i] : 0u;
+    return true;
+}
+
+template <int KPT, bool ROT, int NT>
+__global__ void __launch_bounds__(NT)
+filter_kernel_dense_scales(FilterParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    first_round_stagger(p);
+    uint32_t* part = p.partial + (size_t)blockIdx.x * kPartialStrideDw;
+    if (!dense_scales_pair<KPT, ROT, NT>(p, smem, (int)blockIdx.x, (int)threadIdx.x, part)) {
+        if (threadIdx.x == 0) part[0] = 0u;  // the hashed kernel evaluates all five scales
+    }
+}
+
 // Test hook: the threshold comparison in device fp64 -- and, where the operands are in its range, the byte-matrix
 // path's integer form of it, which must agree (a disagreement is reported as 2).
 __global__ void threshold_kernel(const int32_t* T, const int32_t* n, const int32_t* score, double factor,
@@ -1366,6 +1716,39 @@ hipError_t launch_filter(const FilterParams& p, int kpt, int n_pairs, hipStream_
     case 16: return rot ? launch_filter_t<16, true, 1024>(p, n_pairs, lds, stream) : launch_filter_t<16, false, 1024>(p, n_pairs, lds, stream);
     default: return hipErrorInvalidValue;
     }
+}
+
+template <int KPT, bool ROT, int NT>
+static hipError_t launch_dense_scales_t(const FilterParams& p, int n_pairs, hipStream_t stream)
+{
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(filter_kernel_dense_scales<KPT, ROT, NT>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((filter_kernel_dense_scales<KPT, ROT, NT>), dim3((unsigned)n_pairs), dim3(NT), kDenseLdsBytes, stream, p);
+    return hipGetLastError();
+}
+
+// Scale hypotheses: scales 0..2 on the byte matrix (records in p.partial), then the hashed kernel for scales 3 and 4 and
+// for everything the first kernel could not take. p.partial: n_pairs * kPartialStrideDw dwords.
+hipError_t launch_filter_scales(const FilterParams& p, int kpt, int n_pairs, hipStream_t stream)
+{
+    if (n_pairs <= 0) return hipSuccess;
+    const bool rot = p.with_rotation != 0;
+    hipError_t e = hipErrorInvalidValue;
+    switch (kpt) {
+    case 4: e = rot ? launch_dense_scales_t<4, true, 1024>(p, n_pairs, stream) : launch_dense_scales_t<4, false, 1024>(p, n_pairs, stream); break;
+    case 10: e = rot ? launch_dense_scales_t<10, true, 1024>(p, n_pairs, stream) : launch_dense_scales_t<10, false, 1024>(p, n_pairs, stream); break;
+    case 16: e = rot ? launch_dense_scales_t<16, true, 1024>(p, n_pairs, stream) : launch_dense_scales_t<16, false, 1024>(p, n_pairs, stream); break;
+    default: break;
+    }
+    if (e != hipSuccess) return e;
+    FilterParams q = p;
+    q.dense = 0;
+    return launch_filter(q, kpt, n_pairs, stream);
 }
 
 hipError_t launch_threshold(const int32_t* d_T, const int32_t* d_n, const int32_t* d_score, double factor,
