@@ -164,3 +164,36 @@ def test_integer_threshold_form_agrees_with_fp64(ctx):
         sc = rng.integers(0, 9 * 255 + 1, 20000).astype(np.int32)
         th = np.sqrt(T.astype(np.float64) / n) * float(f)
         assert np.array_equal(ctx.selftest_threshold(T, n, sc, float(f)), (th > sc).astype(np.uint8)), f
+
+
+# ---- scale hypotheses: scales 0..2 run on the byte matrix (filter_kernel_dense_scales), 3 and 4 on the hashed path ----------
+@pytest.mark.parametrize("rot", [False, True])
+@pytest.mark.parametrize("n", [255, 256, 400])
+def test_scales_cell_population_at_the_byte_limit(ctx, oracle, n, rot):
+    """With 256 or more matches in a cell the first kernel leaves an empty record and the hashed kernel does all five scales."""
+    _check(ctx, oracle, _case([((0.5, 0.5), (3.5, 7.5), n, CELL)], background=True), rot, scale=True)
+
+
+@pytest.mark.parametrize("scale_factor,theta", [(1.0, 0.0), (0.5, 0.0), (0.7071, 90.0), (1.4142, 45.0), (2.0, 180.0)])
+def test_scales_winner_on_either_side_of_the_hand_over(ctx, oracle, scale_factor, theta):
+    """True scale ratios that make each of the five scale hypotheses the winner in turn: 0..2 are decided by the byte-matrix
+    kernel, 3 and 4 by the hashed kernel that resumes from its record."""
+    c = cases.random_pair(300 + int(scale_factor * 10), n=8000, inlier_frac=0.6, theta_deg=theta, scale=scale_factor)
+    for rot in (False, True):
+        got, res = ctx.match(c["size1"], c["size2"], c["kp1"], c["kp2"], c["matches"], rot, True, 6.0, return_result=True)
+        rc, want, _, wres = oracle.match(c["size1"], c["size2"], c["kp1"], c["kp2"], c["matches"], rot, True, 6.0)
+        assert rc == 0 and got.tobytes() == want.tobytes()
+        assert (res["n_inliers"], res["best_scale"], res["best_rot"]) == (wres["n_inliers"], wres["best_scale"], wres["best_rot"])
+
+
+def test_scales_shifted_grid_overfill_and_half_cell_wrap(ctx, oracle):
+    groups = [((0.75, 0.5), (5.75, 9.5), 200, (0.2, 0.4)), ((1.25, 0.5), (6.25, 9.5), 200, (0.2, 0.4))]
+    _check(ctx, oracle, _case(groups), True, scale=True)
+    _check(ctx, oracle, _case([((0.25, 0.25), (10.25, 10.25), 300, TIGHT)]), False, scale=True)
+
+
+def test_scales_no_inliers_in_the_first_three_scales(ctx, oracle):
+    """Random matches only: every count is small; whatever the winner, record and resumption must agree with the oracle."""
+    c = cases.random_pair(77, n=6000, inlier_frac=0.0)
+    for rot in (False, True):
+        _check(ctx, oracle, c, rot, scale=True)
