@@ -41,6 +41,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "gms_kernels.h"
 
 namespace gms {
@@ -290,7 +292,8 @@ __device__ __forceinline__ void hash_pair(const FilterParams& p, uint32_t* smem,
     // with scale hypotheses the byte-matrix kernel may have evaluated scales 0..2 already (see dense_scales_pair): its
     // record holds the best hypothesis so far, and this kernel continues with scale 3
     const uint32_t* __restrict__ part = p.partial ? p.partial + (size_t)pair_idx * kPartialStrideDw : nullptr;
-    const bool resumed = part != nullptr && part[0] == 1u;  // workgroup-uniform
+    const int scales_done = part != nullptr ? (int)part[0] : 0;  // workgroup-uniform: 0, or the 4 scales of the first kernel
+    const bool resumed = scales_done != 0;
     for (int i = tid; i < (kMcap >> 5); i += NT) bestmask[i] = resumed ? part[kPartialHeaderDw + i] : 0u;
     for (int i = tid; i < kFineStride; i += NT) nfine[i] = 0;
     for (int i = tid; i < 4 * kFineStride; i += NT) fdesc4[i] = 0;
@@ -438,7 +441,7 @@ __device__ __forceinline__ void hash_pair(const FilterParams& p, uint32_t* smem,
     __syncthreads();
     GMS_STAMP(1);  // region tables
 
-    for (int s = resumed ? 3 : 0; s < n_scales; ++s) {
+    for (int s = scales_done; s < n_scales; ++s) {
         const int wr = p.right_w[s], hr = p.right_h[s];
 
         if (s > 0) {
@@ -1291,7 +1294,7 @@ filter_kernel_dense(FilterParams p)
 // evaluates all five scales.
 // Everything is dense_pair() with a runtime row stride; the records are not kept (nothing is copied out here).
 // ------------------------------------------------------------------------------------------------
-constexpr uint32_t kDenseBestMaskOff = 120u * 1024u;                      // best mask so far: above every scale >= 1 matrix
+constexpr uint32_t kDenseBestMaskOff = 157696u;  // best mask so far (2 KB): above every scale >= 1 matrix and every scale-3 band
 
 template <int KPT, bool ROT, int NT>
 __device__ __forceinline__ bool dense_scales_pair(const FilterParams& p, uint32_t* smem, const int pair_idx, const int tid,
@@ -1310,8 +1313,10 @@ __device__ __forceinline__ bool dense_scales_pair(const FilterParams& p, uint32_
         pr.frame_b >= p.n_frames)
         return false;
     if (p.right_w[0] != 20 || p.right_h[0] != 20 || p.right_w[1] != 10 || p.right_h[1] != 10 || p.right_w[2] != 14 ||
-        p.right_h[2] != 14)
+        p.right_h[2] != 14 || p.right_w[3] != 28 || p.right_h[3] != 28)
         return false;
+    constexpr uint32_t kSEMask = 0x3FFu;   // E(r) = nr + 3 - r needs 10 bits at 28 x 28 right cells (bits 8..17 of the code word)
+    constexpr int kSAccShift = 18;         // rotation bits 18..25
     const int64_t offA = p.frame_off[pr.frame_a], offB = p.frame_off[pr.frame_b];
     const int nA = (int)(p.frame_off[pr.frame_a + 1] - offA), nB = (int)(p.frame_off[pr.frame_b + 1] - offB);
     if (nA <= 0 || nB <= 0) return false;
@@ -1357,8 +1362,8 @@ __device__ __forceinline__ bool dense_scales_pair(const FilterParams& p, uint32_
     __syncthreads();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (see dense_pair: the left-side gathers go out together)
 
-    // code word as in dense_pair (E = E(r) of the current scale); cell1 = left cell under grid type 1; rs = the right
-    // cells of scales 1 and 2 (bits 0..7 and 8..15)
+    // code word as in dense_pair (E = E(r) of the current scale, 10 bits); cell1 = left cell under grid type 1; rs = the
+    // right cells of scales 1, 2 and 3 (bits 0..7, 8..15, 16..25)
     uint32_t code[KPT], cell1[KPT], rs[KPT];
     {
         float2 a[KPT], b[KPT];
@@ -1380,11 +1385,11 @@ __device__ __forceinline__ bool dense_scales_pair(const FilterParams& p, uint32_
             const float fx = 20.0f * a[k].x, fy = 20.0f * a[k].y;   // mulss, rounded to fp32
             const uint32_t hx = (uint32_t)(int)(fx + fx), hy = (uint32_t)(int)(fy + fy);  // floor(2f), 2f exact
             // getGridIndexRight per scale: (int)(wr * x) + (int)(wr * y) * wr, no bounds test (clamped 24-bit form: see dense_pair)
-            uint32_t r[3];
+            uint32_t r[4];
             bool in_grid = true;
 #pragma unroll
-            for (int s = 0; s < 3; ++s) {
-                const uint32_t wr = s == 0 ? 20u : s == 1 ? 10u : 14u;
+            for (int s = 0; s < 4; ++s) {
+                const uint32_t wr = s == 0 ? 20u : s == 1 ? 10u : s == 2 ? 14u : 28u;
                 const float fw = (float)wr;
                 const uint32_t rx = (uint32_t)(int)(fw * b[k].x), ry = (uint32_t)(int)(fw * b[k].y);
                 r[s] = __umul24(min(ry, 4096u), wr) + min(rx, 4096u);
@@ -1400,7 +1405,7 @@ __device__ __forceinline__ bool dense_scales_pair(const FilterParams& p, uint32_
             const uint32_t edge = ((hx + 25u) & kDEdgeX) | ((hy + 89u) & kDEdgeY);
             code[k] = binned ? (q | edge | ((403u - r[0]) << kDEShift)) : kDNever;
             cell1[k] = binned ? __umul24(hy >> 1, (uint32_t)kLeftW) + (hx >> 1) : 0u;
-            rs[k] = binned ? (r[1] | (r[2] << 8)) : 0u;
+            rs[k] = binned ? (r[1] | (r[2] << 8) | (r[3] << 16)) : 0u;
         }
         if (any_bad) misc[8] = 1;
         if (spill) misc[11] = 1;
@@ -1421,141 +1426,165 @@ __device__ __forceinline__ bool dense_scales_pair(const FilterParams& p, uint32_
     const uint32_t f2i = dense_factor_sq(p.threshold_factor);
     uint32_t best_count = 0;
     int best_scale = -1, best_rot = -1;
-    for (int s = 0; s < 3; ++s) {
+
+    // One scale hypothesis. BANDED (scale 3, 28 x 28 right cells: 400 rows of 788 bytes do not fit): the left grid's rows
+    // are taken 8 at a time, each band with one halo row on either side in LDS (at most 10 rows = 157 600 bytes); per
+    // grid type a band bins the matches of the rows it holds, verifies and marks its own rows' cells and takes every
+    // increment back before the next band.
+    auto run_scale = [&](auto banded_c, const int s) {
+        constexpr bool BANDED = decltype(banded_c)::value;
         const uint32_t wr = (uint32_t)p.right_w[s], nr = wr * wr;
         const uint32_t stride = 4u + nr;                 // header dword + one byte per right cell
         const uint32_t wr_magic = 65535u / wr + 1u;      // j / wr == (j * magic) >> 16 for j * wr < 65536
         if (s > 0) {
 #pragma unroll
             for (int k = 0; k < KPT; ++k) {
-                const uint32_t r = s == 1 ? (rs[k] & 0xFFu) : (rs[k] >> 8);
-                if (!(code[k] & kDNever)) code[k] = (code[k] & ~(kDEMask << kDEShift)) | ((nr + 3u - r) << kDEShift);
+                const uint32_t r = s == 1 ? (rs[k] & 0xFFu) : s == 2 ? ((rs[k] >> 8) & 0xFFu) : (rs[k] >> 16);
+                if (!(code[k] & kDNever)) code[k] = (code[k] & ~(kSEMask << kDEShift)) | ((nr + 3u - r) << kDEShift);
             }
         }
+        bool ok_all = true;
         for (int g = 0; g < 4; ++g) {
             const int gx = g & 1, gy = g >> 1;
             const uint32_t q_mask = (uint32_t)(gx + 20 * gy);
             const uint32_t out_mask = kDNever | (gx ? kDEdgeX : 0u) | (gy ? kDEdgeY : 0u);
-            const uint32_t key_tag = (uint32_t)g << kDTagShift;
             if (tid < kLeftN) {
                 const uint32_t n = dense_nleft(nfine8, tid % kLeftW, tid / kLeftW, gx, gy);
                 if (n > 255u) misc[11] = 1;
                 nleft8[tid] = (uint8_t)n;
             }
-            // ---- assignMatchPairs
-#pragma unroll
-            for (int k0 = 0; k0 < KPT; k0 += kChunk) {
-                uint32_t old[kChunk], at[kChunk], row[kChunk];
-#pragma unroll
-                for (int c = 0; c < kChunk; ++c) {
-                    const uint32_t cw = code[k0 + c];
-                    row[c] = __umul24(cell1[k0 + c] + (cw & q_mask), stride);
-                    at[c] = row[c] + ((cw >> kDEShift) & kDEMask);
-                    old[c] = 0;
-                    if ((cw & out_mask) == 0) old[c] = atomicAdd(lds_at(smem, at[c] & ~3u), 1u << ((at[c] << 3) & 31u));
-                }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int c = 0; c < kChunk; ++c) {
-                    const uint32_t cw = code[k0 + c];
-                    const uint32_t before = (old[c] >> ((at[c] << 3) & 31u)) & 255u;
-                    if ((cw & out_mask) == 0) atomicMax(lds_at(smem, row[c]), key_tag | (before << 11) | ((cw >> kDEShift) & kDEMask));
-                }
-            }
-            __syncthreads();
-            if (misc[11] != 0) {  // a cell above 255 matches (workgroup-uniform; nothing has been written out)
-                __syncthreads();
-                return false;
-            }
+            constexpr int kBandRows = 8;
+            for (int band = 0; band < (BANDED ? (kLeftH + kBandRows - 1) / kBandRows : 1); ++band) {
+                const int lo = BANDED ? band * kBandRows : 0, hi = BANDED ? min(lo + kBandRows, kLeftH) : kLeftH;  // own rows
+                const int blo = BANDED ? max(lo - 1, 0) : 0, bhi = BANDED ? min(hi + 1, kLeftH) : kLeftH;          // rows held
+                const uint32_t cell0 = (uint32_t)(blo * kLeftW), n_held = (uint32_t)((bhi - blo) * kLeftW);
+                const uint32_t own0 = (uint32_t)(lo * kLeftW), n_own = (uint32_t)((hi - lo) * kLeftW);
+                // arg-max keys carry (grid type, band) in their top bits: every binning pass outranks what the previous one
+                // left in the headers (a cellPairs word, below 2^19), so headers are never reset inside a scale
+                const uint32_t key_tag = (uint32_t)(BANDED ? g * 3 + band : g) << kDTagShift;
 
-            // ---- verifyCellPairs: two lanes per cell without rotation, one lane per (cell, rotation) with
-            {
-                constexpr int kItems = ROT ? kLeftN * 8 : kLeftN * 2;
-                for (int item = tid; item < ((kItems + 63) & ~63); item += NT) {
-                    const bool live = item < kItems;
-                    const int i = live ? (ROT ? (item >> 3) : (item >> 1)) : 0;
-                    const int rot = ROT ? (item & 7) : 0;
-                    const int half = item & 1;  // !ROT only
-                    const int ix = i % kLeftW, iy = i / kLeftW;
-                    const uint32_t ni = live ? nleft8[i] : 0u;
-                    const uint32_t best = smem[(uint32_t)i * (stride >> 2)] & ((1u << kDTagShift) - 1u);
-                    const uint32_t ej = ni ? (best & kDEMask) : nr + 3u;
-                    const uint32_t j = nr + 3u - ej;
-                    const int jy = (int)((j * wr_magic) >> 16), jx = (int)j - jy * (int)wr;
-                    uint32_t score = 0, tn = 0;  // tn = (sum of nLeft << 4) | numpair
+                // ---- assignMatchPairs
 #pragma unroll
-                    for (int h = 0; h < (ROT ? 8 : 4); h += 4) {
+                for (int k0 = 0; k0 < KPT; k0 += kChunk) {
+                    uint32_t old[kChunk], at[kChunk], row[kChunk];
+                    bool in[kChunk];
 #pragma unroll
-                        for (int c = 0; c < 4; ++c) {
-                            int ldx, ldy, rdx, rdy;
-                            if (ROT) {
-                                const int k8 = h + c;
-                                const int k = k8 < 4 ? k8 : k8 + 1;
-                                constexpr int kRingIndex[9] = {0, 1, 2, 7, -1, 3, 6, 5, 4};
-                                const int q = rotated_position(rot, kRingIndex[k]);
-                                ldx = (k % 3) - 1; ldy = (k / 3) - 1;
-                                rdx = position_dx(q); rdy = position_dy(q);
-                            } else {
-                                ldx = half ? ((c + 5) % 3) - 1 : (c % 3) - 1;
-                                ldy = half ? ((c + 5) / 3) - 1 : (c / 3) - 1;
-                                rdx = ldx; rdy = ldy;
+                    for (int c = 0; c < kChunk; ++c) {
+                        const uint32_t cw = code[k0 + c];
+                        const uint32_t l = cell1[k0 + c] + (cw & q_mask) - cell0;
+                        in[c] = (cw & out_mask) == 0 && (!BANDED || l < n_held);
+                        row[c] = __umul24(l, stride);
+                        at[c] = row[c] + ((cw >> kDEShift) & kSEMask);
+                        old[c] = 0;
+                        if (in[c]) old[c] = atomicAdd(lds_at(smem, at[c] & ~3u), 1u << ((at[c] << 3) & 31u));
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int c = 0; c < kChunk; ++c) {
+                        const uint32_t before = (old[c] >> ((at[c] << 3) & 31u)) & 255u;
+                        if (in[c]) atomicMax(lds_at(smem, row[c]), key_tag | (before << 11) | ((code[k0 + c] >> kDEShift) & kSEMask));
+                    }
+                }
+                __syncthreads();
+                if (misc[11] != 0) {  // a cell above 255 matches (workgroup-uniform; nothing has been written out)
+                    ok_all = false;
+                    break;
+                }
+
+                // ---- verifyCellPairs for the cells of the own rows
+                {
+                    const int n_items = (int)n_own * (ROT ? 8 : 2);
+                    for (int item = tid; item < ((n_items + 63) & ~63); item += NT) {
+                        const bool live = item < n_items;
+                        const int i = (int)own0 + (live ? (ROT ? (item >> 3) : (item >> 1)) : 0);
+                        const int rot = ROT ? (item & 7) : 0;
+                        const int half = item & 1;  // !ROT only
+                        const int ix = i % kLeftW, iy = i / kLeftW;
+                        const uint32_t ni = live ? nleft8[i] : 0u;
+                        const uint32_t hdr = ((uint32_t)i - cell0) * (stride >> 2);
+                        const uint32_t best = smem[hdr] & ((1u << kDTagShift) - 1u);
+                        const uint32_t ej = ni ? (best & 0x7FFu) : nr + 3u;
+                        const uint32_t j = nr + 3u - ej;
+                        const int jy = (int)((j * wr_magic) >> 16), jx = (int)j - jy * (int)wr;
+                        uint32_t score = 0, tn = 0;  // tn = (sum of nLeft << 4) | numpair
+#pragma unroll
+                        for (int h = 0; h < (ROT ? 8 : 4); h += 4) {
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) {
+                                int ldx, ldy, rdx, rdy;
+                                if (ROT) {
+                                    const int k8 = h + c;
+                                    const int k = k8 < 4 ? k8 : k8 + 1;
+                                    constexpr int kRingIndex[9] = {0, 1, 2, 7, -1, 3, 6, 5, 4};
+                                    const int q = rotated_position(rot, kRingIndex[k]);
+                                    ldx = (k % 3) - 1; ldy = (k / 3) - 1;
+                                    rdx = position_dx(q); rdy = position_dy(q);
+                                } else {
+                                    ldx = half ? ((c + 5) % 3) - 1 : (c % 3) - 1;
+                                    ldy = half ? ((c + 5) / 3) - 1 : (c / 3) - 1;
+                                    rdx = ldx; rdy = ldy;
+                                }
+                                const int lx = ix + ldx, ly = iy + ldy;
+                                const int rx = jx + rdx, ry = jy + rdy;
+                                const bool okl = ni != 0 && (uint32_t)lx < (uint32_t)kLeftW && (uint32_t)ly < (uint32_t)kLeftH;
+                                const bool okp = okl && (uint32_t)rx < wr && (uint32_t)ry < wr;
+                                const uint32_t ll = okl ? (uint32_t)(lx + ly * kLeftW) : (uint32_t)i;  // within one row of an own row: held
+                                const uint32_t nll = nleft8[ll];
+                                const uint32_t cnt = dense8[(ll - cell0) * stride + (okp ? nr + 3u - (uint32_t)(rx + ry * (int)wr) : 4u)];
+                                score += okp ? cnt : 0u;
+                                tn += okp ? ((nll << 4) | 1u) : 0u;
                             }
-                            const int lx = ix + ldx, ly = iy + ldy;
-                            const int rx = jx + rdx, ry = jy + rdy;
-                            const bool okl = ni != 0 && (uint32_t)lx < (uint32_t)kLeftW && (uint32_t)ly < (uint32_t)kLeftH;
-                            const bool okp = okl && (uint32_t)rx < wr && (uint32_t)ry < wr;
-                            const uint32_t ll = okl ? (uint32_t)(lx + ly * kLeftW) : 0u;
-                            const uint32_t nll = nleft8[ll];
-                            const uint32_t cnt = dense8[ll * stride + (okp ? nr + 3u - (uint32_t)(rx + ry * (int)wr) : 4u)];
-                            score += okp ? cnt : 0u;
-                            tn += okp ? ((nll << 4) | 1u) : 0u;
+                        }
+                        if (!ROT) {
+                            score += dpp_xor1(score);
+                            tn += dpp_xor1(tn);
+                        }
+                        score += (best >> 11) + 1u;
+                        tn += (ni << 4) | 1u;
+                        uint32_t pass = 0;
+                        if (ni != 0 && (ROT || half == 0))
+                            pass = dense_threshold_rejects(tn >> 4, tn & 15u, score, p.threshold_factor, thr_fast, f2i) ? 0u : 1u;
+                        uint32_t bits = pass;
+                        bool writer = ni != 0 && half == 0;
+                        if (ROT) {
+                            const unsigned long long bal = __ballot(pass);
+                            bits = (uint32_t)(bal >> (lane & 56)) & 0xFFu;
+                            writer = ni != 0 && (lane & 7) == 0;
+                        }
+                        if (writer) smem[hdr] = (ej << 8) | bits;
+                    }
+                }
+                __syncthreads();
+
+                // ---- mark the matches of the own rows; every increment of the rows held is taken back
+                {
+                    uint32_t cr[KPT];
+#pragma unroll
+                    for (int k = 0; k < KPT; ++k) {
+                        const uint32_t cw = code[k];
+                        const uint32_t l = cell1[k] + (cw & q_mask);
+                        const uint32_t row = __umul24(l - cell0, stride);
+                        cr[k] = 0xFFFFFFFFu;
+                        if ((cw & out_mask) == 0 && (!BANDED || l - cell0 < n_held)) {
+                            if (!BANDED || l - own0 < n_own) cr[k] = smem[row >> 2];
+                            const uint32_t at = row + ((cw >> kDEShift) & kSEMask);
+                            atomicSub(lds_at(smem, at & ~3u), 1u << ((at << 3) & 31u));
                         }
                     }
-                    if (!ROT) {
-                        score += dpp_xor1(score);
-                        tn += dpp_xor1(tn);
-                    }
-                    score += (best >> 11) + 1u;
-                    tn += (ni << 4) | 1u;
-                    uint32_t pass = 0;
-                    if (ni != 0 && (ROT || half == 0))
-                        pass = dense_threshold_rejects(tn >> 4, tn & 15u, score, p.threshold_factor, thr_fast, f2i) ? 0u : 1u;
-                    uint32_t bits = pass;
-                    bool writer = ni != 0 && half == 0;
-                    if (ROT) {
-                        const unsigned long long bal = __ballot(pass);
-                        bits = (uint32_t)(bal >> (lane & 56)) & 0xFFu;
-                        writer = ni != 0 && (lane & 7) == 0;
-                    }
-                    if (writer) smem[(uint32_t)i * (stride >> 2)] = (ej << 8) | bits;
-                }
-            }
-            __syncthreads();
-
-            // ---- mark, and every increment taken back (the matrix is all zero again after each grid type)
-            {
-                uint32_t cr[KPT];
 #pragma unroll
-                for (int k = 0; k < KPT; ++k) {
-                    const uint32_t cw = code[k];
-                    const uint32_t row = __umul24(cell1[k] + (cw & q_mask), stride);
-                    cr[k] = 0xFFFFFFFFu;
-                    if ((cw & out_mask) == 0) {
-                        cr[k] = smem[row >> 2];
-                        const uint32_t at = row + ((cw >> kDEShift) & kDEMask);
-                        atomicSub(lds_at(smem, at & ~3u), 1u << ((at << 3) & 31u));
+                    for (int k = 0; k < KPT; ++k) {
+                        const uint32_t x = cr[k] ^ (code[k] & (kSEMask << kDEShift));
+                        if (x < 256u) code[k] |= x << kSAccShift;
                     }
                 }
-#pragma unroll
-                for (int k = 0; k < KPT; ++k) {
-                    const uint32_t x = cr[k] ^ (code[k] & (kDEMask << kDEShift));
-                    if (x < 256u) code[k] |= x << kDAccShift;
-                }
+                __syncthreads();
             }
-            __syncthreads();
+            if (!ok_all) break;
         }
+        if (!ok_all) return false;
         // the next scale lays its rows out differently: no header of this one may survive as a count byte
-        if (tid < kLeftN) smem[(uint32_t)tid * (stride >> 2)] = 0;
+        for (uint32_t c = tid; c < (uint32_t)kLeftN; c += NT)
+            if (!BANDED || c < 10u * kLeftW) smem[c * (stride >> 2)] = 0;
 
         // ---- run() return value per rotation of this scale, getInlierMask's strict '>'
         {
@@ -1566,7 +1595,7 @@ __device__ __forceinline__ bool dense_scales_pair(const FilterParams& p, uint32_
             for (int k = 0; k < KPT; ++k)
 #pragma unroll
                 for (int r = 0; r < kNRot; ++r)
-                    cnt[r] += (uint32_t)__popcll(__ballot((code[k] >> (kDAccShift + r)) & 1u));
+                    cnt[r] += (uint32_t)__popcll(__ballot((code[k] >> (kSAccShift + r)) & 1u));
             if (lane == 0) {
 #pragma unroll
                 for (int r = 0; r < kNRot; ++r)
@@ -1588,7 +1617,7 @@ __device__ __forceinline__ bool dense_scales_pair(const FilterParams& p, uint32_
         if (winner >= 0) {
 #pragma unroll
             for (int k = 0; k < KPT; ++k) {
-                const unsigned long long bsel = __ballot((code[k] >> (kDAccShift + winner)) & 1u);
+                const unsigned long long bsel = __ballot((code[k] >> (kSAccShift + winner)) & 1u);
                 if (lane == 0) {
                     const int ch = k * (NT / 64) + wave;  // chunk of 64 consecutive matches
                     bestmask[2 * ch] = (uint32_t)bsel;
@@ -1597,14 +1626,25 @@ __device__ __forceinline__ bool dense_scales_pair(const FilterParams& p, uint32_
             }
         }
 #pragma unroll
-        for (int k = 0; k < KPT; ++k) code[k] &= ~(0xFFu << kDAccShift);
+        for (int k = 0; k < KPT; ++k) code[k] &= ~(0xFFu << kSAccShift);
         __syncthreads();
         if (tid < 8) misc[tid] = 0;
+        return true;
+    };
+
+    for (int s = 0; s < 3; ++s)
+        if (!run_scale(std::false_type{}, s)) {
+            __syncthreads();
+            return false;
+        }
+    if (!run_scale(std::true_type{}, 3)) {
+        __syncthreads();
+        return false;
     }
     __syncthreads();
-    // the record the hashed kernel continues from
+    // the record the hashed kernel continues from: scales 0..3 are decided
     if (tid == 0) {
-        part[0] = 1u;
+        part[0] = 4u;
         part[1] = best_count;
         part[2] = (uint32_t)best_scale;
         part[3] = (uint32_t)best_rot;
