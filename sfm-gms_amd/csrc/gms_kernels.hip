@@ -574,6 +574,7 @@ __device__ __forceinline__ void hash_pair(const FilterParams& p, uint32_t* smem,
                     const int rot = ROT ? (item & 7) : 0;
                     const int half = item & 1;  // !ROT only
                     const uint32_t ni = live ? nleft[i] : 0u;
+                    if (__ballot(ni != 0) == 0ull) continue;  // none of this wave's cells has a match under this grid type
                     const uint32_t di = desc[i];
                     const uint32_t bi = ni ? ~tab[(di >> 16) << 2] : 0u;  // (max count << 11) | (2047 - j*)
                     const int j = 2047 - (int)(bi & kRMask);
@@ -1101,6 +1102,7 @@ __device__ __forceinline__ bool dense_pair(const FilterParams& p, uint32_t* smem
                 const int half = item & 1;  // !ROT only
                 const int ix = i % kLeftW, iy = i / kLeftW;
                 const uint32_t ni = live ? nleft8[i] : 0u;
+                if (__ballot(ni != 0) == 0ull) continue;  // none of this wave's cells has a match under this grid type
                 const uint32_t best = smem[i * (kDenseRow / 4)] & ((1u << kDTagShift) - 1u);  // ((max count - 1) << 11) | E(j*), lowest j* among maxima
                 const uint32_t ej = ni ? (best & kDEMask) : (uint32_t)(kDenseRightN + 3);
                 const int j = kDenseRightN + 3 - (int)ej;
@@ -1285,11 +1287,11 @@ filter_kernel_dense(FilterParams p)
 // ------------------------------------------------------------------------------------------------
 // Scale hypotheses on the byte matrix (dense_scales_pair): the right grids of scales 0, 1 and 2 are 20 x 20,
 // 10 x 10 and 14 x 14, so their motion matrices (400 x 400, 400 x 100, 400 x 196 bytes) fit the LDS like the default
-// case; 28 x 28 and 40 x 40 (scales 3 and 4) do not. With scale hypotheses a launch therefore runs two kernels: this
-// one evaluates scales 0..2 (all rotations) and leaves the best hypothesis so far -- count, (scale, rotation), the
+// case; scale 3 (28 x 28: 400 rows of 788 bytes) fits in three bands of left rows; scale 4 (40 x 40) does not pay. With scale hypotheses a launch therefore runs two kernels: this
+// one evaluates scales 0..3 (all rotations) and leaves the best hypothesis so far -- count, (scale, rotation), the
 // inlier bit of every match -- in a per-pair workspace record; filter_kernel then picks the record up, evaluates
-// scales 3 and 4 on the hashed path, and selects and copies out as always (getInlierMask's order is scale-outer,
-// rotation-inner with strict '>', so "best of 0..2, then 3, 4" is the same comparison sequence). A pair this kernel
+// scale 4 on the hashed path, and selects and copies out as always (getInlierMask's order is scale-outer,
+// rotation-inner with strict '>', so "best of 0..3, then 4" is the same comparison sequence). A pair this kernel
 // cannot take (a cell above 255 matches, inputs outside the parity domain) gets an empty record and the hashed path
 // evaluates all five scales.
 // Everything is dense_pair() with a runtime row stride; the records are not kept (nothing is copied out here).
@@ -1501,6 +1503,7 @@ __device__ __forceinline__ bool dense_scales_pair(const FilterParams& p, uint32_
                         const int half = item & 1;  // !ROT only
                         const int ix = i % kLeftW, iy = i / kLeftW;
                         const uint32_t ni = live ? nleft8[i] : 0u;
+                        if (__ballot(ni != 0) == 0ull) continue;  // none of this wave's cells has a match under this grid type
                         const uint32_t hdr = ((uint32_t)i - cell0) * (stride >> 2);
                         const uint32_t best = smem[hdr] & ((1u << kDTagShift) - 1u);
                         const uint32_t ej = ni ? (best & 0x7FFu) : nr + 3u;
