@@ -35,7 +35,7 @@ Headline (`python bench.py`, defaults: 4096 pairs per step, 20 steps, 3 warm-up;
 | PMC traffic per launch (`r01_pmc_traffic.json`; FETCH_SIZE ×2 per the gfx950 calibration, + WRITE_SIZE) | {t['hbm_bytes_per_launch']/1e9:.2f} GB = {t['hbm_bytes_per_launch']/t['algorithmic_bytes_per_launch']:.2f} × algorithmic (reads {t['hbm_read_bytes_per_launch']/1e9:.2f} GB, writes {t['hbm_write_bytes_per_launch']/1e9:.3f} GB = 16·K·P + results) |
 | CPU baseline, oracle port on the GPU box's host (EPYC 9575F), 16 threads, one pair per thread | {b['cpu_baseline']['value']:.0f} pairs/s ({b['cpu_baseline']['value_1thread']:.0f} pairs/s on 1 thread) → GPU/CPU(16 thr) = {b['gpu_vs_cpu']:.0f}× |
 | parity inside the bench | 256 sampled pairs bit-exact vs the oracle |
-| same pairs with flags (true, true, 6.0) — 8 rot × 5 scale × 4 grids (`FeatureMatchUtil.cpp:69`): scales 0..2 on the byte matrix, 3..4 hashed (§4.3) | {rs['value']/1e3:.0f} k pairs/s; CPU 16 threads {rs['cpu_baseline']['value']:.0f} pairs/s → {rs['value']/rs['cpu_baseline']['value']:.0f}× |
+| same pairs with flags (true, true, 6.0) — 8 rot × 5 scale × 4 grids (`FeatureMatchUtil.cpp:69`): scales 0..3 on the byte matrix, scale 4 hashed (§4.3) | {rs['value']/1e3:.0f} k pairs/s; CPU 16 threads {rs['cpu_baseline']['value']:.0f} pairs/s → {rs['value']/rs['cpu_baseline']['value']:.0f}× |
 
 `FETCH_SIZE` counts requests on the L2's memory side, Infinity Cache hits included (MI355X_MICROARCH.md), so the traffic
 figure is an upper bound on HBM bytes; the calibration kernel (`tools/ubench/fetch_calib.hip`, 2 GiB buffer) shows the
@@ -79,7 +79,7 @@ new = f"""| 3-shape batch: 1080p, 10k matches/pair, 4096 pairs resident per step
 
 Roofline (algorithmic 32·M + 16·K bytes per pair): {b['roofline']['achieved']:.0f} GB/s of 8000 GB/s = {b['roofline']['frac']:.3f}; PMC-measured HBM-side traffic {t['hbm_bytes_per_launch']/1e9:.2f} GB
 per launch against {t['algorithmic_bytes_per_launch']/1e9:.2f} GB algorithmic. Targets of BASELINE.json: ≥ 10× CPU — met ({b['gpu_vs_cpu']:.0f}× vs 16 host threads); ≥ 40 % of HBM roofline —
-met at {100*b['roofline']['frac']:.0f} % with the byte-matrix kernel for the default flags (the hashed path, still used for scale hypotheses 3 and 4 and for crowded cells, sits at 19 % on the same pairs; see DESIGN.md §4, §6);
+met at {100*b['roofline']['frac']:.0f} % with the byte-matrix kernel for the default flags (the hashed path, still used for scale hypothesis 4 and for crowded cells, sits at 19 % on the same pairs; see DESIGN.md §4, §6);
 """
 s = s[:a] + new + s[z:]
 open('BASELINE.md', 'w').write(s)
