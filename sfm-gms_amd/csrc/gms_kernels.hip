@@ -1433,6 +1433,19 @@ __device__ __forceinline__ bool dense_scales_pair(const FilterParams& p, uint32_
     // are taken 8 at a time, each band with one halo row on either side in LDS (at most 10 rows = 157 600 bytes); per
     // grid type a band bins the matches of the rows it holds, verifies and marks its own rows' cells and takes every
     // increment back before the next band.
+    // With rotation a thread always verifies the same rotation (item & 7 == tid & 7): where the rotation pattern sends each
+    // of the eight outer neighbours is worked out once, as (dx + 1) | (dy + 1) << 2 in four bits per neighbour.
+    uint32_t rot_pack = 0;
+    if (ROT) {
+#pragma unroll
+        for (int k8 = 0; k8 < 8; ++k8) {
+            const int k = k8 < 4 ? k8 : k8 + 1;
+            constexpr int kRingIndex[9] = {0, 1, 2, 7, -1, 3, 6, 5, 4};  // position -> ring index
+            const int q = rotated_position(tid & 7, kRingIndex[k]);
+            rot_pack |= (uint32_t)((position_dx(q) + 1) | ((position_dy(q) + 1) << 2)) << (4 * k8);
+        }
+    }
+
     auto run_scale = [&](auto banded_c, const int s) {
         constexpr bool BANDED = decltype(banded_c)::value;
         const uint32_t wr = (uint32_t)p.right_w[s], nr = wr * wr;
@@ -1499,7 +1512,6 @@ __device__ __forceinline__ bool dense_scales_pair(const FilterParams& p, uint32_
                     for (int item = tid; item < ((n_items + 63) & ~63); item += NT) {
                         const bool live = item < n_items;
                         const int i = (int)own0 + (live ? (ROT ? (item >> 3) : (item >> 1)) : 0);
-                        const int rot = ROT ? (item & 7) : 0;
                         const int half = item & 1;  // !ROT only
                         const int ix = i % kLeftW, iy = i / kLeftW;
                         const uint32_t ni = live ? nleft8[i] : 0u;
@@ -1518,10 +1530,9 @@ __device__ __forceinline__ bool dense_scales_pair(const FilterParams& p, uint32_
                                 if (ROT) {
                                     const int k8 = h + c;
                                     const int k = k8 < 4 ? k8 : k8 + 1;
-                                    constexpr int kRingIndex[9] = {0, 1, 2, 7, -1, 3, 6, 5, 4};
-                                    const int q = rotated_position(rot, kRingIndex[k]);
                                     ldx = (k % 3) - 1; ldy = (k / 3) - 1;
-                                    rdx = position_dx(q); rdy = position_dy(q);
+                                    rdx = (int)((rot_pack >> (4 * k8)) & 3u) - 1;
+                                    rdy = (int)((rot_pack >> (4 * k8 + 2)) & 3u) - 1;
                                 } else {
                                     ldx = half ? ((c + 5) % 3) - 1 : (c % 3) - 1;
                                     ldy = half ? ((c + 5) / 3) - 1 : (c / 3) - 1;
