@@ -441,6 +441,18 @@ __device__ __forceinline__ void hash_pair(const FilterParams& p, uint32_t* smem,
     __syncthreads();
     GMS_STAMP(1);  // region tables
 
+    // With rotation a thread always verifies the same rotation (item & 7 == tid & 7): where the rotation pattern sends each
+    // of the eight outer neighbours is worked out once, as (dx + 1) | (dy + 1) << 2 in four bits per neighbour.
+    uint32_t rot_pack = 0;
+    if (ROT) {
+#pragma unroll
+        for (int k8 = 0; k8 < 8; ++k8) {
+            const int k = k8 < 4 ? k8 : k8 + 1;
+            constexpr int kRingIndex[9] = {0, 1, 2, 7, -1, 3, 6, 5, 4};  // position -> ring index
+            const int q = rotated_position(tid & 7, kRingIndex[k]);
+            rot_pack |= (uint32_t)((position_dx(q) + 1) | ((position_dy(q) + 1) << 2)) << (4 * k8);
+        }
+    }
     for (int s = scales_done; s < n_scales; ++s) {
         const int wr = p.right_w[s], hr = p.right_h[s];
 
@@ -571,7 +583,6 @@ __device__ __forceinline__ void hash_pair(const FilterParams& p, uint32_t* smem,
                 for (int item = tid; item < ((kItems + 63) & ~63); item += NT) {
                     const bool live = item < kItems;
                     const int i = live ? (ROT ? (item >> 3) : (item >> 1)) : 0;
-                    const int rot = ROT ? (item & 7) : 0;
                     const int half = item & 1;  // !ROT only
                     const uint32_t ni = live ? nleft[i] : 0u;
                     if (__ballot(ni != 0) == 0ull) continue;  // none of this wave's cells has a match under this grid type
@@ -596,10 +607,9 @@ __device__ __forceinline__ void hash_pair(const FilterParams& p, uint32_t* smem,
                             }
                             int ldx, ldy, rdx, rdy;
                             if (ROT) {
-                                constexpr int kRingIndex[9] = {0, 1, 2, 7, -1, 3, 6, 5, 4};  // position -> ring index
-                                const int q = rotated_position(rot, kRingIndex[k]);          // k is a compile-time constant here
-                                ldx = (k % 3) - 1; ldy = (k / 3) - 1;
-                                rdx = position_dx(q); rdy = position_dy(q);
+                                ldx = (k % 3) - 1; ldy = (k / 3) - 1;  // k is a compile-time constant here
+                                rdx = (int)((rot_pack >> (4 * (h + c))) & 3u) - 1;
+                                rdy = (int)((rot_pack >> (4 * (h + c) + 2)) & 3u) - 1;
                             } else {
                                 // k = c or c + 5, both compile-time: select by lane parity
                                 ldx = half ? ((c + 5) % 3) - 1 : (c % 3) - 1;
