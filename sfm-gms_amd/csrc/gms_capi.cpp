@@ -264,11 +264,14 @@ int gms_filter_device(gms_ctx* c, const float* d_pts, const int64_t* d_frame_off
             const char* e = std::getenv("GMS_BAND");
             return !e || std::atoi(e) != 0;
         }();
-        if (band_on && !with_rotation && !with_scale) {
-            // Default flags: the three-band LDS kernels, a slice of the batch at a time so that the per-pair workspace
-            // (code words, histogram, mask) stays bounded; pairs they flag (a cell above 65 535 matches) fall through to
-            // the HBM-slab kernel, which looks at flagged pairs only.
-            const size_t per_pair = gms::band_ws_bytes_per_pair(mcap, d_mask == nullptr);
+        if (band_on) {
+            // The LDS kernels for large pairs, a slice of the batch at a time so that the per-pair workspace (lists, histogram,
+            // masks) stays bounded: three bands of rows for the default flags, tiles of left cells with three launches per
+            // scale hypothesis otherwise. Pairs they flag (a cell above 65 535 matches) fall through to the HBM-slab kernel,
+            // which looks at flagged pairs only.
+            const bool plain = !with_rotation && !with_scale;
+            const size_t per_pair = plain ? gms::band_ws_bytes_per_pair(mcap, d_mask == nullptr)
+                                          : gms::tile_ws_bytes_per_pair(p, mcap, d_mask == nullptr);
             const size_t budget = (size_t)4 << 30;
             size_t slice = budget / per_pair;
             if (slice < 1) slice = 1;
@@ -283,7 +286,8 @@ int gms_filter_device(gms_ctx* c, const float* d_pts, const int64_t* d_frame_off
                 ps.results = d_results + s0;
                 ps.n_pairs = (n_pairs - s0 < (int)slice) ? n_pairs - s0 : (int)slice;
                 const uint32_t* flags = nullptr;
-                GMS_HIP(gms::launch_filter_band(ps, mcap, c->band_ws.p, &flags, c->stream));
+                if (plain) GMS_HIP(gms::launch_filter_band(ps, mcap, c->band_ws.p, &flags, c->stream));
+                else GMS_HIP(gms::launch_filter_tiles(ps, mcap, c->band_ws.p, &flags, c->stream));
                 ps.pair_flags = flags;
                 const int wg = ps.n_pairs < c->n_cus ? ps.n_pairs : c->n_cus;
                 GMS_HIP(gms::launch_filter_big(ps, mcap, wg, (uint32_t*)c->big_ws.p, c->stream));

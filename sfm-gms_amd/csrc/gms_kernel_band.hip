@@ -373,7 +373,7 @@ __device__ __forceinline__ uint32_t mask_bits16(const uint8_t* mask, int first, 
 }
 
 __global__ void __launch_bounds__(1024)
-band_compact_kernel(FilterParams p, const uint32_t* flags, uint8_t* mask_ws, int mcap)
+band_compact_kernel(FilterParams p, const uint32_t* flags, uint8_t* mask_ws, const uint32_t* state, int mcap)
 {
     __shared__ uint32_t wave_tile[16], wave_before[16];
     const int tile = blockIdx.x, pi = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -436,11 +436,363 @@ band_compact_kernel(FilterParams p, const uint32_t* flags, uint8_t* mask_ws, int
     if (tid == 0 && tile == n_tiles - 1) {
         gms_pair_result r;
         r.n_inliers = failed ? 0 : (int)total;
-        r.best_scale = (failed || total == 0) ? -1 : 0;
-        r.best_rot = (failed || total == 0) ? -1 : 1;
+        // default flags: the one hypothesis (scale 0, rotation 1); otherwise what tile_select_kernel recorded
+        r.best_scale = (failed || total == 0) ? -1 : (state ? (int)state[pi * 4 + 1] : 0);
+        r.best_rot = (failed || total == 0) ? -1 : (state ? (int)state[pi * 4 + 2] : 1);
         r.status = failed ? GMS_ERR_DOMAIN : GMS_OK;
         p.results[pi] = r;
     }
+}
+
+// ================================================================================================================================
+// Large pairs with rotation and/or scale hypotheses (BASELINE config 4: 4K pairs, 50k features, FeatureMatchUtil.cpp:69 flags).
+//
+// The same 16-bit LDS matrix, generalised from bands of rows to TILES of left cells: a scale's right grid has nr = wr * wr
+// cells, a left cell's row is [header | nr x u16], and a workgroup keeps an own block of R x C left cells plus a halo ring
+// (whatever of the ring is inside the grid) -- sized so that the block fits 144 KB: 7 x 20 own cells at scale 0 (20 x 20 right
+// cells), the whole grid at scale 1 (10 x 10), 16 x 20 at scale 2 (14 x 14), 7 x 7 at scale 3 (28 x 28), 4 x 5 at scale 4
+// (40 x 40). One workgroup per (tile, grid type); tiles and types are independent (each ORs rotation bits into the pair's
+// byte-per-match hypothesis mask). Per scale three launches -- tile_codes_kernel (code words with this scale's right cell,
+// appended to the lists of the at most 2 x 2 tiles that keep the match's left cell), tile_filter_kernel (bin, verify under
+// all rotations, mark), tile_select_kernel (inliers per rotation, getInlierMask's strict '>' against the best hypothesis
+// so far, whose mask it replaces when beaten) -- and after the last scale band_compact_kernel copies the survivors out.
+// Pairs with a cell above 65 535 matches are flagged for the HBM-slab kernel as in the default-flag path.
+// ================================================================================================================================
+struct TileGeom {
+    int scale;          // index into FilterParams::right_w / right_h
+    int wr, nr;         // right grid width, cells
+    int own_r, own_c;   // own block of left cells
+    int tiles_y, tiles_x;
+    uint32_t row_bytes; // 4 + 2 * nr
+};
+constexpr int kMaxTiles = 32;
+constexpr uint32_t kTileMatrixBytes = 144u * 1024u;
+constexpr uint32_t kTileNleftOff = kTileMatrixBytes;                 // [400] u32
+constexpr uint32_t kTileFineOff = kTileNleftOff + 4u * kLeftN;       // [1600] u32
+constexpr uint32_t kTileMiscOff = kTileFineOff + 4u * kFineN;        // [16] u32
+constexpr uint32_t kTileLdsBytes = kTileMiscOff + 64u;
+static_assert(kTileLdsBytes <= kLdsBytes, "tile layout exceeds the LDS");
+// code word: E' = nr - r (1..nr) : 11 | hx : 6 | hy : 6 | binned : 1
+constexpr int kTHxShift = 11, kTHyShift = 17;
+constexpr uint32_t kTBinned = 1u << 23;
+
+namespace {
+// tiles whose kept rows (own + halo) contain left row r: [lo, hi]
+__device__ __forceinline__ void tiles_holding(int r, int own, int n_tiles, int& lo, int& hi)
+{
+    lo = r >= 1 ? (r - 1) / own : 0;
+    hi = min((r + 1) / own, n_tiles - 1);
+}
+}  // namespace
+
+__global__ void __launch_bounds__(1024)
+tile_codes_kernel(FilterParams p, TileGeom gm, uint2* lists, uint32_t* list_len, uint32_t* nfine_g, uint32_t* flags,
+                  uint8_t* rotmask, int mcap)
+{
+    __shared__ uint32_t hist[kFineN];
+    __shared__ uint32_t cnt_l[kMaxTiles], base_g[kMaxTiles];
+    const int pi = blockIdx.y, tid = threadIdx.x;
+    const int n_tiles = gm.tiles_y * gm.tiles_x;
+    const gms_pair pr = p.pairs[pi];
+    const int m = pr.m;
+    const bool bad_pair = m < 0 || m > mcap || pr.frame_a < 0 || pr.frame_a >= p.n_frames || pr.frame_b < 0 ||
+                          pr.frame_b >= p.n_frames;
+    if (bad_pair) {
+        if (blockIdx.x == 0 && tid == 0) atomicOr(&flags[pi], kFlagDomain);
+        return;
+    }
+    const int base = blockIdx.x * 4096;
+    if (base >= m) return;  // workgroup-uniform
+    const int64_t offA = p.frame_off[pr.frame_a], offB = p.frame_off[pr.frame_b];
+    const int nA = (int)(p.frame_off[pr.frame_a + 1] - offA), nB = (int)(p.frame_off[pr.frame_b + 1] - offB);
+    if (nA <= 0 || nB <= 0) {
+        if (blockIdx.x == 0 && tid == 0) atomicOr(&flags[pi], kFlagDomain);
+        return;
+    }
+    const float2* __restrict__ ptsA = p.pts + offA;
+    const float2* __restrict__ ptsB = p.pts + offB;
+    const gms_dmatch* __restrict__ matches = p.matches + pr.match_off;
+    uint8_t* rm = rotmask + (size_t)pi * mcap;
+
+    for (int j = tid; j < kFineN; j += 1024) hist[j] = 0;
+    if (tid < kMaxTiles) cnt_l[tid] = 0;
+    __syncthreads();
+    uint2 qt[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) qt[k] = *reinterpret_cast<const uint2*>(&matches[min(base + k * 1024 + tid, m - 1)]);
+    float2 a[4], b[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        a[k] = ptsA[min(qt[k].x, (uint32_t)(nA - 1))];
+        b[k] = ptsB[min(qt[k].y, (uint32_t)(nB - 1))];
+    }
+    const float fwr = (float)gm.wr;
+    bool any_bad = false;
+    uint32_t cw[4], rank[4][4], tile_of[4][4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int i = base + k * 1024 + tid;
+        const bool live = i < m;
+        const uint32_t worst = max(max(__float_as_uint(a[k].x), __float_as_uint(a[k].y)),
+                                   max(__float_as_uint(b[k].x), __float_as_uint(b[k].y)));
+        const float fx = 20.0f * a[k].x, fy = 20.0f * a[k].y;   // mulss, rounded to fp32
+        const uint32_t hx = (uint32_t)(int)(fx + fx), hy = (uint32_t)(int)(fy + fy);  // floor(2f), 2f exact
+        // getGridIndexRight of this scale: (int)(wr * x) + (int)(wr * y) * wr, no bounds test (clamped 24-bit form, exact below nr)
+        const uint32_t rx = (uint32_t)(int)(fwr * b[k].x), ry = (uint32_t)(int)(fwr * b[k].y);
+        const uint32_t r = __umul24(min(ry, 4096u), (uint32_t)gm.wr) + min(rx, 4096u);
+        const bool ok = qt[k].x < (uint32_t)nA && qt[k].y < (uint32_t)nB && worst < 0x49800000u && r < (uint32_t)gm.nr;
+        const bool binned = live && ok && hx < 40u && hy < 40u;
+        if (binned) atomicAdd(&hist[hy * kFineW + hx], 1u);
+        any_bad |= live && !ok;
+        if (live) rm[i] = 0;
+        cw[k] = binned ? (((uint32_t)gm.nr - r) | (hx << kTHxShift) | (hy << kTHyShift) | kTBinned) : 0u;
+        // the tiles that keep this match's left cell under any grid type: rows hy >> 1 and (hy + 1) >> 1, columns likewise
+        int ty_lo = 0, ty_hi = -1, tx_lo = 0, tx_hi = -1, dummy;
+        if (binned) {
+            tiles_holding((int)(hy >> 1), gm.own_r, gm.tiles_y, ty_lo, dummy);
+            tiles_holding((int)min((hy + 1u) >> 1, 19u), gm.own_r, gm.tiles_y, dummy, ty_hi);
+            tiles_holding((int)(hx >> 1), gm.own_c, gm.tiles_x, tx_lo, dummy);
+            tiles_holding((int)min((hx + 1u) >> 1, 19u), gm.own_c, gm.tiles_x, dummy, tx_hi);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int ty = ty_lo + (q >> 1), tx = tx_lo + (q & 1);
+            const bool need = ty <= ty_hi && tx <= tx_hi;
+            tile_of[k][q] = need ? (uint32_t)(ty * gm.tiles_x + tx) : 0u;
+            rank[k][q] = need ? atomicAdd(&cnt_l[tile_of[k][q]], 1u) : 0xFFFFFFFFu;
+        }
+    }
+    if (any_bad) atomicOr(&flags[pi], kFlagDomain);
+    __syncthreads();
+    uint32_t* nf = nfine_g + (size_t)pi * kFineN;
+    for (int j = tid; j < kFineN; j += 1024)
+        if (hist[j]) atomicAdd(&nf[j], hist[j]);
+    if (tid < n_tiles) base_g[tid] = cnt_l[tid] ? atomicAdd(&list_len[pi * kMaxTiles + tid], cnt_l[tid]) : 0u;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (rank[k][q] != 0xFFFFFFFFu)
+                lists[((size_t)pi * n_tiles + tile_of[k][q]) * mcap + base_g[tile_of[k][q]] + rank[k][q]] =
+                    make_uint2(cw[k], (uint32_t)(base + k * 1024 + tid));
+}
+
+template <bool ROT>
+__global__ void __launch_bounds__(1024)
+tile_filter_kernel(FilterParams p, TileGeom gm, const uint2* lists, const uint32_t* list_len, const uint32_t* nfine_g,
+                   uint32_t* flags, uint32_t* rotmask32, int mcap)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    const int n_tiles = gm.tiles_y * gm.tiles_x;
+    const int tile = blockIdx.x % n_tiles, g = blockIdx.x / n_tiles, pi = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
+    const gms_pair pr = p.pairs[pi];
+    const int m = pr.m;
+    if (m <= 0 || m > mcap) return;
+    if (flags[pi] & (kFlagDomain | kFlagGeneral)) return;  // written by earlier launches
+    const uint2* __restrict__ list = lists + ((size_t)pi * n_tiles + tile) * mcap;
+    const int len = (int)list_len[pi * kMaxTiles + tile];
+    const uint32_t* __restrict__ nf = nfine_g + (size_t)pi * kFineN;
+    uint32_t* rm32 = rotmask32 + ((size_t)pi * mcap >> 2);
+
+    const uint8_t* bytes = reinterpret_cast<const uint8_t*>(smem);
+    uint32_t* nleft = smem + kTileNleftOff / 4;
+    uint32_t* nfine = smem + kTileFineOff / 4;
+    uint32_t* misc = smem + kTileMiscOff / 4;
+    const int ty = tile / gm.tiles_x, tx = tile % gm.tiles_x;
+    const int y0 = ty * gm.own_r, y1 = min(y0 + gm.own_r, kLeftH), x0 = tx * gm.own_c, x1 = min(x0 + gm.own_c, kLeftW);  // own cells
+    const int ky0 = max(y0 - 1, 0), ky1 = min(y1 + 1, kLeftH), kx0 = max(x0 - 1, 0), kx1 = min(x1 + 1, kLeftW);         // cells kept
+    const uint32_t kw = (uint32_t)(kx1 - kx0), kh = (uint32_t)(ky1 - ky0), ow = (uint32_t)(x1 - x0), oh = (uint32_t)(y1 - y0);
+    const uint32_t row_bytes = gm.row_bytes, wr = (uint32_t)gm.wr, nr = (uint32_t)gm.nr;
+    const uint32_t clear16 = (kw * kh * row_bytes + 15u) >> 4;
+    const int gx = g & 1, gy = g >> 1;
+
+    for (int j = tid; j < kFineN; j += 1024) nfine[j] = nf[j];
+    if (tid == 0) misc[0] = 0;
+    __syncthreads();
+    auto nleft_of = [&](int cell, int sx, int sy) -> uint32_t {
+        const int hx0 = 2 * (cell % kLeftW) - sx, hy0 = 2 * (cell / kLeftW) - sy;
+        uint32_t n = 0;
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) {
+                const int hx = hx0 + dx, hy = hy0 + dy;
+                if (hx >= 0 && hy >= 0) n += nfine[hy * kFineW + hx];
+            }
+        return n;
+    };
+    for (int item = tid; item < 4 * kLeftN; item += 1024) {
+        const int gg = item / kLeftN;
+        if (nleft_of(item - gg * kLeftN, gg & 1, gg >> 1) > 65535u) misc[0] = 1;
+    }
+    if (tid < kLeftN) nleft[tid] = nleft_of(tid, gx, gy);
+    {
+        const uint4 z4 = make_uint4(0, 0, 0, 0);
+        uint4* d4 = reinterpret_cast<uint4*>(smem);
+        for (uint32_t i = tid; i < clear16; i += 1024) d4[i] = z4;
+    }
+    __syncthreads();
+    if (misc[0]) {  // the same decision in every workgroup of the pair
+        if (blockIdx.x == 0 && tid == 0) atomicOr(&flags[pi], kFlagGeneral);
+        return;
+    }
+
+    // ---- assignMatchPairs for the cells this tile keeps
+    stream_list(list, len, tid, [&](uint32_t cw, int) {
+        const uint32_t lx = (((cw >> kTHxShift) & 63u) + (uint32_t)gx) >> 1;
+        const uint32_t ly = (((cw >> kTHyShift) & 63u) + (uint32_t)gy) >> 1;
+        // x >= 20 || y >= 20 -> -1 (DLL@0x180047d3d); cells outside the kept block belong to other tiles
+        if ((cw & kTBinned) && lx - (uint32_t)kx0 < kw && ly - (uint32_t)ky0 < kh && lx < (uint32_t)kLeftW && ly < (uint32_t)kLeftH) {
+            const uint32_t e = cw & 0x7FFu;  // E' = nr - r
+            const uint32_t row = (__umul24(ly - (uint32_t)ky0, kw) + (lx - (uint32_t)kx0)) * row_bytes;
+            const uint32_t at = row + 4u + 2u * (e - 1u);
+            const uint32_t sh = (at & 2u) << 3;
+            const uint32_t old = atomicAdd(lds_at(smem, at & ~3u), 1u << sh);
+            atomicMax(lds_at(smem, row), (((old >> sh) & 0xFFFFu) << 11) | e);
+        }
+    });
+    __syncthreads();
+
+    // ---- verifyCellPairs for the own cells: two lanes per cell without rotation, one lane per (cell, rotation) with
+    uint32_t rot_pack = 0;
+    if (ROT) {
+#pragma unroll
+        for (int k8 = 0; k8 < 8; ++k8) {
+            const int k = k8 < 4 ? k8 : k8 + 1;
+            const int u = (int)((0x45637210u >> (4 * k8)) & 15u);  // position k -> ring index: {0,1,2,7,.,3,6,5,4}
+            // ring 0,1,2,5,8,7,6,3 clockwise; pattern rot sends ring index u to (u - rot) mod 8 (see gms_kernels.hip)
+            const int q = (int)((0x36785210u >> ((((u - (tid & 7)) & 7)) << 2)) & 15u);
+            const int dx = (int)((0x24924u >> (q << 1)) & 3u) - 1, dy = (int)((0x2a540u >> (q << 1)) & 3u) - 1;
+            (void)k;
+            rot_pack |= (uint32_t)((dx + 1) | ((dy + 1) << 2)) << (4 * k8);
+        }
+    }
+    {
+        const int n_items = (int)(ow * oh) * (ROT ? 8 : 2);
+        for (int item = tid; item < ((n_items + 63) & ~63); item += 1024) {
+            const bool live = item < n_items;
+            const uint32_t c = live ? (uint32_t)(ROT ? item >> 3 : item >> 1) : 0u;
+            const int half = item & 1;  // !ROT only
+            const int ix = x0 + (int)(c % ow), iy = y0 + (int)(c / ow);
+            const int i = iy * kLeftW + ix;
+            const uint32_t hdr_off = (__umul24((uint32_t)(iy - ky0), kw) + (uint32_t)(ix - kx0)) * row_bytes;
+            const uint32_t ni = live ? nleft[i] : 0u;
+            if (__ballot(ni != 0) == 0ull) continue;
+            const uint32_t best = smem[hdr_off >> 2];  // ((max count - 1) << 11) | E'(j*), lowest j* among maxima
+            const uint32_t ej = ni ? (best & 0x7FFu) : nr;
+            const uint32_t j = nr - ej;
+            const int jy = (int)(j / wr), jx = (int)(j - (uint32_t)jy * wr);
+            uint32_t score = 0, T = 0, np = 0;
+#pragma unroll
+            for (int q = 0; q < (ROT ? 8 : 4); ++q) {
+                int ldx, ldy, rdx, rdy;
+                if (ROT) {
+                    const int k = q < 4 ? q : q + 1;
+                    ldx = (k % 3) - 1; ldy = (k / 3) - 1;
+                    rdx = (int)((rot_pack >> (4 * q)) & 3u) - 1;
+                    rdy = (int)((rot_pack >> (4 * q + 2)) & 3u) - 1;
+                } else {
+                    const int k = half ? q + 5 : q;  // lane 0: neighbours 0..3, lane 1: neighbours 5..8 (4 is the centre)
+                    ldx = (k % 3) - 1; ldy = (k / 3) - 1;
+                    rdx = ldx; rdy = ldy;
+                }
+                const int lx = ix + ldx, ly = iy + ldy, rx = jx + rdx, ry = jy + rdy;
+                const bool okl = ni != 0 && (uint32_t)lx < (uint32_t)kLeftW && (uint32_t)ly < (uint32_t)kLeftH;  // ll != -1
+                const bool okp = okl && (uint32_t)rx < wr && (uint32_t)ry < wr;                                    // rr != -1
+                if (okp) {  // within one cell of an own cell: kept
+                    const uint32_t at = (__umul24((uint32_t)(ly - ky0), kw) + (uint32_t)(lx - kx0)) * row_bytes + 4u +
+                                        2u * (nr - 1u - (uint32_t)(rx + ry * (int)wr));  // entries are stored by E' - 1 = nr - 1 - r
+                    score += *reinterpret_cast<const uint16_t*>(bytes + at);
+                    T += nleft[ly * kLeftW + lx];
+                    np += 1;
+                }
+            }
+            if (!ROT) {
+                score += dpp_xor1(score);
+                T += dpp_xor1(T);
+                np += dpp_xor1(np);
+            }
+            score += (best >> 11) + 1u;  // centre pair (k = 4): ll = i, rr = j*, the arg-max count itself
+            T += ni;
+            np += 1;
+            uint32_t pass = 0;
+            if (live && ni != 0 && (ROT || half == 0)) pass = band_threshold_rejects(T, np, score, p.threshold_factor) ? 0u : 1u;
+            uint32_t bits = pass;
+            bool writer = live && ni != 0 && half == 0;
+            if (ROT) {
+                const unsigned long long bal = __ballot(pass);
+                bits = (uint32_t)(bal >> (lane & 56)) & 0xFFu;
+                writer = live && ni != 0 && (lane & 7) == 0;
+            }
+            if (writer) smem[hdr_off >> 2] = (ej << 8) | bits;  // cellPairs[i] (every lane of the cell has read the header above)
+        }
+    }
+    __syncthreads();
+
+    // ---- mark: cellPairs[l] == r for the matches whose left cell is one of the own cells; rotation bits into the byte mask
+    stream_list(list, len, tid, [&](uint32_t cw, int i) {
+        const uint32_t lx = (((cw >> kTHxShift) & 63u) + (uint32_t)gx) >> 1;
+        const uint32_t ly = (((cw >> kTHyShift) & 63u) + (uint32_t)gy) >> 1;
+        if ((cw & kTBinned) && lx - (uint32_t)x0 < ow && ly - (uint32_t)y0 < oh) {
+            const uint32_t cp = smem[((__umul24(ly - (uint32_t)ky0, kw) + (lx - (uint32_t)kx0)) * row_bytes) >> 2];
+            if ((cp >> 8) == (cw & 0x7FFu) && (cp & 0xFFu) != 0) atomicOr(&rm32[i >> 2], (cp & 0xFFu) << ((i & 3) << 3));
+        }
+    });
+}
+
+// inliers per rotation of the scale just filtered; getInlierMask's strict '>' (scale outer, rotation inner) against the best
+// hypothesis so far; state = {best count, best scale, best rotation, -} per pair; bestmask = the winner's inlier bytes
+template <bool ROT>
+__global__ void __launch_bounds__(1024)
+tile_select_kernel(FilterParams p, int scale, const uint8_t* rotmask, uint8_t* bestmask_ws, uint32_t* state, const uint32_t* flags,
+                   int mcap)
+{
+    __shared__ uint32_t cnt[8];
+    __shared__ int winner_s;
+    const int pi = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const gms_pair pr = p.pairs[pi];
+    const int m = pr.m;
+    if (m <= 0 || m > mcap || (flags[pi] & (kFlagDomain | kFlagGeneral))) return;
+    const uint8_t* rm = rotmask + (size_t)pi * mcap;
+    uint8_t* bm = p.mask ? p.mask + pr.match_off : bestmask_ws + (size_t)pi * mcap;
+    constexpr int kNRot = ROT ? 8 : 1;
+    if (tid < 8) cnt[tid] = 0;
+    __syncthreads();
+    uint32_t c[kNRot];
+#pragma unroll
+    for (int r = 0; r < kNRot; ++r) c[r] = 0;
+    for (int i0 = 0; i0 < m; i0 += 1024) {
+        const int i = i0 + tid;
+        const uint32_t b = i < m ? rm[i] : 0u;
+#pragma unroll
+        for (int r = 0; r < kNRot; ++r) c[r] += (uint32_t)__popcll(__ballot((b >> r) & 1u));
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int r = 0; r < kNRot; ++r)
+            if (c[r]) atomicAdd(&cnt[r], c[r]);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t best = state[pi * 4 + 0];
+        int w = -1;
+        for (int r = 0; r < kNRot; ++r)
+            if (cnt[r] > best) {
+                best = cnt[r];
+                w = r;
+            }
+        winner_s = w;
+        if (w >= 0) {
+            state[pi * 4 + 0] = best;
+            state[pi * 4 + 1] = (uint32_t)scale;
+            state[pi * 4 + 2] = (uint32_t)(w + 1);
+        }
+    }
+    __syncthreads();
+    const int w = winner_s;
+    if (w >= 0 || scale == 0)  // (the first scale also initialises the mask: nothing may ever win)
+        for (int i = tid; i < m; i += 1024) bm[i] = w >= 0 ? (rm[i] >> w) & 1u : 0u;
 }
 
 // ---- launch helpers ----------------------------------------------------------------------------------------------------
@@ -477,7 +829,116 @@ hipError_t launch_filter_band(const FilterParams& p, int mcap, void* ws, const u
     hipLaunchKernelGGL(band_filter_kernel, dim3(per_pair, (unsigned)n), dim3(1024), kBandLdsBytes, stream, p, lists, list_len,
                        nfine, flags, mask_ws, mcap);
     hipLaunchKernelGGL(band_compact_kernel, dim3((unsigned)((mcap + 16383) / 16384), (unsigned)n), dim3(1024), 0, stream, p, flags,
-                       mask_ws, mcap);
+                       mask_ws, (const uint32_t*)nullptr, mcap);
+    *flags_out = flags;
+    return hipGetLastError();
+}
+
+
+// ---- rotation / scale hypotheses for large pairs ------------------------------------------------------------------------------
+static TileGeom tile_geom(const FilterParams& p, int scale)
+{
+    TileGeom g;
+    g.scale = scale;
+    g.wr = p.right_w[scale];
+    g.nr = g.wr * p.right_h[scale];
+    g.row_bytes = 4u + 2u * (uint32_t)g.nr;
+    // the own block (R x C left cells) whose kept block (own + halo ring, clipped to the grid) fits the matrix area with the
+    // fewest tiles, then the fewest kept cells (every kept cell beyond the own ones is a match streamed twice)
+    const int cap = (int)(kTileMatrixBytes / g.row_bytes);  // cells that fit
+    auto kept = [](int own, int n) { return own >= n ? n : (own + 2 < n ? own + 2 : n); };
+    int best_tiles = 1 << 30, best_kept = 1 << 30;
+    g.own_r = g.own_c = 0;
+    for (int r = 3; r <= kLeftH; ++r)
+        for (int c = 3; c <= kLeftW; ++c) {
+            if (kept(r, kLeftH) * kept(c, kLeftW) > cap) continue;
+            const int ty = (kLeftH + r - 1) / r, tx = (kLeftW + c - 1) / c;
+            const int total_kept = ty * tx * kept(r, kLeftH) * kept(c, kLeftW);
+            if (ty * tx < best_tiles || (ty * tx == best_tiles && total_kept < best_kept)) {
+                best_tiles = ty * tx;
+                best_kept = total_kept;
+                g.own_r = r;
+                g.own_c = c;
+            }
+        }
+    if (g.own_r == 0) {  // (cannot happen for the reference's five right grids: 3 x 3 own cells need 25 kept cells)
+        g.own_r = g.own_c = 1;
+        g.tiles_y = g.tiles_x = 1 << 10;
+        return g;
+    }
+    g.tiles_y = (kLeftH + g.own_r - 1) / g.own_r;
+    g.tiles_x = (kLeftW + g.own_c - 1) / g.own_c;
+    return g;
+}
+
+size_t tile_ws_bytes_per_pair(const FilterParams& p, int mcap, bool need_mask)
+{
+    int max_tiles = 1;
+    const int n_scales = p.with_scale ? 5 : 1;
+    for (int s = 0; s < n_scales; ++s) {
+        const TileGeom g = tile_geom(p, s);
+        max_tiles = g.tiles_y * g.tiles_x > max_tiles ? g.tiles_y * g.tiles_x : max_tiles;
+    }
+    return (size_t)max_tiles * mcap * 8 + (size_t)kFineN * 4 + kMaxTiles * 4 + 4 + 16 + (size_t)mcap + (need_mask ? (size_t)mcap : 0) + 64;
+}
+
+// ws layout for n pairs: lists [n][tiles][mcap] uint2 | nfine [n][1600] | list_len [n][32] | flags [n] | state [n][4] |
+//                        rotmask [n][mcap] u8 | bestmask [n][mcap] u8 (if p.mask is null)
+hipError_t launch_filter_tiles(const FilterParams& p, int mcap, void* ws, const uint32_t** flags_out, hipStream_t stream)
+{
+    const int n = p.n_pairs;
+    if (n <= 0) return hipSuccess;
+    const int n_scales = p.with_scale ? 5 : 1;
+    int max_tiles = 1;
+    for (int s = 0; s < n_scales; ++s) {
+        const TileGeom g = tile_geom(p, s);
+        if (g.tiles_y * g.tiles_x > kMaxTiles || g.own_r < 1 || g.own_c < 1) return hipErrorInvalidValue;
+        max_tiles = g.tiles_y * g.tiles_x > max_tiles ? g.tiles_y * g.tiles_x : max_tiles;
+    }
+    uint2* lists = reinterpret_cast<uint2*>(ws);
+    uint32_t* nfine = reinterpret_cast<uint32_t*>(lists + (size_t)n * max_tiles * mcap);
+    uint32_t* list_len = nfine + (size_t)n * kFineN;
+    uint32_t* flags = list_len + (size_t)n * kMaxTiles;
+    uint32_t* state = flags + n;
+    uint8_t* rotmask = reinterpret_cast<uint8_t*>(state + (size_t)n * 4);
+    uint8_t* bestmask = rotmask + (size_t)n * mcap;
+    hipError_t e = hipMemsetAsync(flags, 0, (size_t)n * 5 * 4, stream);  // flags + state
+    if (e != hipSuccess) return e;
+    if (p.mask == nullptr) {
+        e = hipMemsetAsync(bestmask, 0, (size_t)n * mcap, stream);
+        if (e != hipSuccess) return e;
+    }
+    static bool attr_set = false;
+    if (!attr_set) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(tile_filter_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)kLdsBytes);
+        if (e != hipSuccess) return e;
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(tile_filter_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)kLdsBytes);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    const bool rot = p.with_rotation != 0;
+    for (int s = 0; s < n_scales; ++s) {
+        const TileGeom g = tile_geom(p, s);
+        const int n_tiles = g.tiles_y * g.tiles_x;
+        e = hipMemsetAsync(nfine, 0, ((size_t)n * kFineN + (size_t)n * kMaxTiles) * 4, stream);  // histogram + list lengths
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(tile_codes_kernel, dim3((unsigned)((mcap + 4095) / 4096), (unsigned)n), dim3(1024), 0, stream, p, g, lists,
+                           list_len, nfine, flags, rotmask, mcap);
+        if (rot)
+            hipLaunchKernelGGL(tile_filter_kernel<true>, dim3((unsigned)(n_tiles * 4), (unsigned)n), dim3(1024), kTileLdsBytes, stream, p, g,
+                               lists, list_len, nfine, flags, reinterpret_cast<uint32_t*>(rotmask), mcap);
+        else
+            hipLaunchKernelGGL(tile_filter_kernel<false>, dim3((unsigned)(n_tiles * 4), (unsigned)n), dim3(1024), kTileLdsBytes, stream, p, g,
+                               lists, list_len, nfine, flags, reinterpret_cast<uint32_t*>(rotmask), mcap);
+        if (rot)
+            hipLaunchKernelGGL(tile_select_kernel<true>, dim3((unsigned)n), dim3(1024), 0, stream, p, s, rotmask, bestmask, state, flags, mcap);
+        else
+            hipLaunchKernelGGL(tile_select_kernel<false>, dim3((unsigned)n), dim3(1024), 0, stream, p, s, rotmask, bestmask, state, flags, mcap);
+    }
+    hipLaunchKernelGGL(band_compact_kernel, dim3((unsigned)((mcap + 16383) / 16384), (unsigned)n), dim3(1024), 0, stream, p, flags,
+                       bestmask, (const uint32_t*)state, mcap);
     *flags_out = flags;
     return hipGetLastError();
 }

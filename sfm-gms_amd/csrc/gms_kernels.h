@@ -65,6 +65,9 @@ hipError_t launch_filter_big(const FilterParams& p, int mcap, int n_workgroups, 
 // left to launch_filter_big (bit 1)
 size_t     band_ws_bytes_per_pair(int mcap, bool need_mask);
 hipError_t launch_filter_band(const FilterParams& p, int mcap, void* ws, const uint32_t** flags_out, hipStream_t stream);
+// large pairs with rotation / scale hypotheses (gms_kernel_band.hip): tiled 16-bit matrix, three launches per scale
+size_t     tile_ws_bytes_per_pair(const FilterParams& p, int mcap, bool need_mask);
+hipError_t launch_filter_tiles(const FilterParams& p, int mcap, void* ws, const uint32_t** flags_out, hipStream_t stream);
 hipError_t launch_threshold(const int32_t* d_T, const int32_t* d_n, const int32_t* d_score, double factor,
                             int count, uint8_t* d_out, hipStream_t stream);
 
