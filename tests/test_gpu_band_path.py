@@ -133,3 +133,86 @@ def test_out_of_domain_input_fails_the_pair_only(ctx, oracle, pkg, synth):
     for i in (0, 2):
         o, k = int(pairs["match_off"][i]), int(res["n_inliers"][i])
         assert k > 1000 and out[o:o + k].tobytes() == wout[o:o + k].tobytes()
+
+
+# ---- rotation / scale hypotheses on large pairs: tiles of left cells, three launches per scale (gms_kernel_band.hip) -------------
+ROT_SCALE = [(True, False), (False, True), (True, True)]
+
+
+@pytest.mark.parametrize("rot,scale", ROT_SCALE)
+@pytest.mark.parametrize("n", [16385, 40000, 131072])
+def test_tiles_sizes_and_flags(ctx, oracle, n, rot, scale):
+    theta, sc = (90.0, 0.5) if (rot and scale) else (45.0, 1.0) if rot else (0.0, 2.0)
+    c = cases.random_pair(90 + n % 7, n=n, size1=(3840, 2160), inlier_frac=0.5, theta_deg=theta, scale=sc)
+    assert _check(ctx, oracle, c, rot, scale) > n // 20
+
+
+@pytest.mark.parametrize("sc,theta", [(1.0, 0.0), (0.5, 180.0), (0.7071, 270.0), (1.4142, 135.0), (2.0, 315.0)])
+def test_tiles_every_scale_hypothesis_wins_once(ctx, oracle, sc, theta):
+    c = cases.random_pair(120 + int(sc * 10), n=30000, inlier_frac=0.6, theta_deg=theta, scale=sc)
+    got, res = ctx.match(c["size1"], c["size2"], c["kp1"], c["kp2"], c["matches"], True, True, 6.0, return_result=True)
+    rc, want, _, wres = oracle.match(c["size1"], c["size2"], c["kp1"], c["kp2"], c["matches"], True, True, 6.0)
+    assert rc == 0 and got.tobytes() == want.tobytes()
+    assert (res["n_inliers"], res["best_scale"], res["best_rot"]) == (wres["n_inliers"], wres["best_scale"], wres["best_rot"])
+
+
+@pytest.mark.parametrize("rows", [(6.5, 7.0, 7.5, 13.5, 14.0), (4.75, 5.25, 9.75, 10.25, 14.75, 15.25), (3.75, 4.25, 7.75, 8.25, 11.75, 12.25, 15.75, 16.25)])
+def test_tiles_matches_on_tile_borders(ctx, oracle, rows):
+    """Left points on and around the rows where the tiles of the various scales meet (7/14, 5/10/15, 4/8/12/16), all hypotheses."""
+    c = _border_case(6, 45000, np.array(rows))
+    assert _check(ctx, oracle, c, True, True) > 3000
+    # the same along x: transpose the case
+    for k in ("kp1", "kp2"):
+        x = c[k]["x"].copy()
+        c[k]["x"] = c[k]["y"] * (c["size1"][0] / c["size1"][1])
+        c[k]["y"] = x * (c["size1"][1] / c["size1"][0])
+    _check(ctx, oracle, c, True, True)
+
+
+def test_tiles_cell_above_65535_falls_through(ctx, oracle):
+    rng = np.random.default_rng(9)
+    w, h = 2000, 1000
+    n_hot, n_rest = 66000, 14000
+    hot1 = np.stack([rng.uniform(1000, 1099, n_hot), rng.uniform(500, 549, n_hot)], axis=1)
+    rest1 = np.stack([rng.uniform(0, w - 1, n_rest), rng.uniform(0, h - 1, n_rest)], axis=1)
+    xy1 = np.concatenate([hot1, rest1]).astype(np.float32)
+    xy2 = np.clip(xy1 + rng.normal(0, 1.5, xy1.shape), 0, [w - 0.01, h - 0.01]).astype(np.float32)
+    n = n_hot + n_rest
+    c = cases._pair(xy1, xy2, np.arange(n), np.arange(n), (w, h), (w, h))
+    c["matches"] = c["matches"][rng.permutation(n)]
+    assert _check(ctx, oracle, c, True, False) > n_hot
+
+
+@pytest.mark.parametrize("want_mask", [True, False])
+def test_tiles_mixed_batch(ctx, oracle, pkg, synth, want_mask):
+    """Ragged pairs incl. an empty one, one with no inliers and one failing, rotation + scale, with and without the mask."""
+    batch = importlib.import_module("sfm-gms_amd.batch")
+    size = (1920, 1080)
+    n_frames, n_kp = 4, 30000
+    frames = synth.make_sequence(46, n_frames, size=size, n_kp=n_kp)
+    lengths = [30000, 17001, 0, 333, 25000, 16385]
+    pairs = np.zeros(len(lengths), dtype=pkg.PAIR_DTYPE)
+    matches, off = [], 0
+    total = pkg.all_pairs_count(n_frames)
+    rng = np.random.default_rng(3)
+    for i, ln in enumerate(lengths):
+        a, b = pkg.pair_from_index((i * 5) % total, n_frames)
+        mt = synth.sequence_matches(4600 + i, n_kp, n_kp, 0.0 if i == 4 else 0.5)[:ln].copy()
+        if i == 1:
+            mt["queryIdx"][777] = -3  # out of range: this pair fails
+        pairs[i] = (a, b, len(mt), 0, off)
+        matches.append(mt)
+        off += len(mt)
+    matches = np.concatenate(matches)
+    table = batch.FrameTable(ctx, frames, [size] * n_frames)
+    kp_all = np.concatenate(frames)
+    wh = np.array([size] * n_frames, dtype=np.int32).reshape(-1)
+    failed, wout, wres, wmask = oracle.batch(kp_all, table.frame_off_host, wh, pairs, matches, True, True, 6.0, 4)
+    assert failed == 1
+    out, res, mask = batch.filter_pairs(ctx, table, pairs, matches, True, True, 6.0, want_mask=want_mask)
+    assert res.tobytes() == wres.tobytes(), (res, wres)
+    if want_mask:
+        assert np.array_equal(mask, wmask)
+    for i in range(len(pairs)):
+        o, k = int(pairs["match_off"][i]), int(res["n_inliers"][i])
+        assert out[o:o + k].tobytes() == wout[o:o + k].tobytes()
