@@ -53,4 +53,19 @@ for feats in (50000, 168750):
         d = json.loads(r.stdout.strip().splitlines()[-1])
         out[f"batch256_{feats}_default_flags_band{band}"] = {"pairs_per_s": d["value"], "gmatches_per_s": d["value"] * feats / 1e9,
                                                               "ms_per_256_pairs": d["ms_per_step"]}
+# the same with rotation + scale hypotheses (BASELINE config 4's flags): tiled LDS kernels vs the slab kernel alone, 64 pairs resident
+code = """
+import sys, json, importlib, argparse, torch
+sys.path.insert(0, %r)
+import bench
+pkg = importlib.import_module("sfm-gms_amd"); synth = importlib.import_module("sfm-gms_amd.synth")
+ctx = pkg.GmsContext(0); dev = torch.device("cuda", 0); stream = torch.cuda.Stream(device=dev); ctx.set_stream(stream.cuda_stream)
+args = argparse.Namespace(pairs=64, frames=16, features=50000, inlier_frac=0.5)
+wl = bench.build_workload(args, 0, 1, dev, pkg, synth, ctx)
+w, k = bench.timed_steps(ctx, wl, stream, 3, 1, True, True, None)
+print(json.dumps({"pairs_per_s": 64 * 3 / w, "ms_per_64_pairs": w / 3 * 1e3}))
+""" % ROOT
+for band in ("1", "0"):
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, GMS_BAND=band))
+    out[f"batch64_50000_rot_scale_band{band}"] = json.loads(r.stdout.strip().splitlines()[-1])
 print(json.dumps(out, indent=1))
