@@ -37,6 +37,12 @@ for flags in ((False, False), (True, True)):
     cpu = timeit(lambda: gms_oracle.match(c["size1"], c["size2"], c["kp1"], c["kp2"], c["matches"], *flags), 3)
     out[f"one_shot_10k_rot{int(flags[0])}_scale{int(flags[1])}"] = {
         "gpu_call_ms_incl_pcie": gpu * 1e3, "gpu_pairs_per_s": 1 / gpu, "cpu_oracle_ms_1thread": cpu * 1e3}
+c = cases.random_pair(11, n=500, size1=(640, 480), inlier_frac=0.6)  # BASELINE config 1
+for flags in ((False, False), (True, True)):
+    gpu = timeit(lambda: ctx.match(c["size1"], c["size2"], c["kp1"], c["kp2"], c["matches"], *flags), 50)
+    cpu = timeit(lambda: gms_oracle.match(c["size1"], c["size2"], c["kp1"], c["kp2"], c["matches"], *flags), 5)
+    out[f"config1_500_rot{int(flags[0])}_scale{int(flags[1])}"] = {
+        "gpu_call_ms_incl_pcie": gpu * 1e3, "cpu_oracle_ms_1thread": cpu * 1e3}
 c = cases.random_pair(104, n=50000, size1=(3840, 2160), inlier_frac=0.5)
 for flags in ((False, False), (True, True)):
     gpu = timeit(lambda: ctx.match(c["size1"], c["size2"], c["kp1"], c["kp2"], c["matches"], *flags), 5)

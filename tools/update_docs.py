@@ -58,7 +58,9 @@ records each workgroup's start and landing time).
 """
 side = f"""Side measurements (`r01_side_measurements.json`): the one-shot host-pointer call `gms_match` on a 10k-match pair takes
 {m['one_shot_10k_rot0_scale0']['gpu_call_ms_incl_pcie']:.2f} ms end to end including the PCIe copies ({m['one_shot_10k_rot0_scale0']['gpu_pairs_per_s']:.0f} pairs/s; the oracle needs {m['one_shot_10k_rot0_scale0']['cpu_oracle_ms_1thread']:.2f} ms on one core) and {m['one_shot_10k_rot1_scale1']['gpu_call_ms_incl_pcie']:.2f} ms with
-rotation + scale (oracle {m['one_shot_10k_rot1_scale1']['cpu_oracle_ms_1thread']:.0f} ms) — PCIe-inclusive rates, never the headline `value`. BASELINE config 4 (3840×2160,
+rotation + scale (oracle {m['one_shot_10k_rot1_scale1']['cpu_oracle_ms_1thread']:.0f} ms) — PCIe-inclusive rates, never the headline `value`. BASELINE config 1
+(640×480, 500 matches): {m['config1_500_rot0_scale0']['gpu_call_ms_incl_pcie']:.3f} / {m['config1_500_rot1_scale1']['gpu_call_ms_incl_pcie']:.3f} ms per call without / with rotation + scale (oracle {m['config1_500_rot0_scale0']['cpu_oracle_ms_1thread']:.3f} / {m['config1_500_rot1_scale1']['cpu_oracle_ms_1thread']:.2f} ms;
+at this size a call is launch + copy latency). BASELINE config 4 (3840×2160,
 50k matches): {m['config4_50k_rot0_scale0']['gpu_call_ms_incl_pcie']:.2f} ms per call with the default flags (band kernels; oracle {m['config4_50k_rot0_scale0']['cpu_oracle_ms_1thread']:.1f} ms), {m['config4_50k_rot1_scale1']['gpu_call_ms_incl_pcie']:.2f} ms with rotation + scale
 (tile kernels; oracle {m['config4_50k_rot1_scale1']['cpu_oracle_ms_1thread']:.0f} ms; {m['batch64_50000_rot_scale_band1']['pairs_per_s']/1e3:.0f} k pairs/s with 64 pairs resident, the slab kernel alone {m['batch64_50000_rot_scale_band0']['pairs_per_s']/1e3:.1f} k). Device-resident batches of 256 large pairs, default flags: {m['batch256_50000_default_flags_band1']['pairs_per_s']/1e3:.0f} k pairs/s at 50k matches
 ({m['batch256_50000_default_flags_band1']['gmatches_per_s']:.1f} G matches/s; slab kernel alone {m['batch256_50000_default_flags_band0']['pairs_per_s']/1e3:.0f} k), {m['batch256_168750_default_flags_band1']['pairs_per_s']/1e3:.0f} k pairs/s at 168 750 matches (slab kernel alone {m['batch256_168750_default_flags_band0']['pairs_per_s']/1e3:.0f} k).
