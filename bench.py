@@ -230,7 +230,8 @@ def main():
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "kernel": "gms::filter_kernel_dense<10, false, 1024>",
                          "kernel_ms_per_launch": kern_ms, "algorithmic_bytes_per_launch": alg_bytes},
         }
-        if not args.no_cpu:
+        run_cpu = not args.no_cpu and world == 1  # the CPU baseline is timed on rank 0 of the 1-GPU run only
+        if run_cpu:
             rate_mt, rate1, ok, n = cpu_leg(args, wl, pkg, False, False, args.cpu_pairs, args.cpu_threads)
             line["cpu_baseline"] = {"value": rate_mt, "unit": "pairs/s", "cores": args.cpu_threads, "kind": "port",
                                     "sample": f"first {n} pairs of the step's batch, oracle/gms_ref.c, one pair "
@@ -238,15 +239,15 @@ def main():
                                     "host_cpus": os.cpu_count()}
             line["parity"] = {"pairs_checked": n, "bit_exact": ok}
             line["gpu_vs_cpu"] = value / rate_mt
-        if not args.no_extra:
+        if not args.no_extra and world == 1:
             sub = dict(wl)
             n_sub = min(wl["n_pairs"], 512)
             sub["n_pairs"] = n_sub
-            w2, k2 = timed_steps(ctx, sub, stream, 3, 1, True, True, None)
+            w2, k2 = timed_steps(ctx, sub, stream, 8, 2, True, True, None)
             extra = {"workload": "same pairs, matchGMS(withRotation=true, withScale=true, 6.0) "
                                  "(FeatureMatchUtil.cpp:69 flags), 8 rot x 5 scale x 4 grids",
-                     "pairs_per_step": n_sub, "value": n_sub * 3 / w2, "unit": "pairs/s", "kernel_ms_per_launch": k2}
-            if not args.no_cpu:
+                     "pairs_per_step": n_sub, "value": n_sub * 8 / w2, "unit": "pairs/s", "kernel_ms_per_launch": k2}
+            if run_cpu:
                 rate_mt2, rate12, ok2, n2 = cpu_leg(args, sub, pkg, True, True, min(32, args.cpu_pairs),
                                                     args.cpu_threads)
                 extra["cpu_baseline"] = {"value": rate_mt2, "cores": args.cpu_threads, "value_1thread": rate12,
