@@ -658,13 +658,11 @@ tile_filter_kernel(FilterParams p, TileGeom gm, const uint2* lists, const uint32
     uint32_t rot_pack = 0;
     if (ROT) {
 #pragma unroll
-        for (int k8 = 0; k8 < 8; ++k8) {
-            const int k = k8 < 4 ? k8 : k8 + 1;
-            const int u = (int)((0x45637210u >> (4 * k8)) & 15u);  // position k -> ring index: {0,1,2,7,.,3,6,5,4}
+        for (int k8 = 0; k8 < 8; ++k8) {  // k8-th outer neighbour = position k8 (k8 < 4) or k8 + 1
+            const int u = (int)((0x45637210u >> (4 * k8)) & 15u);  // position -> ring index: {0,1,2,7,.,3,6,5,4}
             // ring 0,1,2,5,8,7,6,3 clockwise; pattern rot sends ring index u to (u - rot) mod 8 (see gms_kernels.hip)
             const int q = (int)((0x36785210u >> ((((u - (tid & 7)) & 7)) << 2)) & 15u);
             const int dx = (int)((0x24924u >> (q << 1)) & 3u) - 1, dy = (int)((0x2a540u >> (q << 1)) & 3u) - 1;
-            (void)k;
             rot_pack |= (uint32_t)((dx + 1) | ((dy + 1) << 2)) << (4 * k8);
         }
     }
