@@ -436,7 +436,7 @@ band_compact_kernel(FilterParams p, const uint32_t* flags, uint8_t* mask_ws, con
     if (tid == 0 && tile == n_tiles - 1) {
         gms_pair_result r;
         r.n_inliers = failed ? 0 : (int)total;
-        // default flags: the one hypothesis (scale 0, rotation 1); otherwise what tile_select_kernel recorded
+        // default flags: the one hypothesis (scale 0, rotation 1); otherwise what tile_apply_kernel recorded
         r.best_scale = (failed || total == 0) ? -1 : (state ? (int)state[pi * 4 + 1] : 0);
         r.best_rot = (failed || total == 0) ? -1 : (state ? (int)state[pi * 4 + 2] : 1);
         r.status = failed ? GMS_ERR_DOMAIN : GMS_OK;
@@ -452,10 +452,10 @@ band_compact_kernel(FilterParams p, const uint32_t* flags, uint8_t* mask_ws, con
 // (whatever of the ring is inside the grid) -- sized so that the block fits 144 KB: 7 x 20 own cells at scale 0 (20 x 20 right
 // cells), the whole grid at scale 1 (10 x 10), 16 x 20 at scale 2 (14 x 14), 7 x 7 at scale 3 (28 x 28), 4 x 5 at scale 4
 // (40 x 40). One workgroup per (tile, grid type); tiles and types are independent (each ORs rotation bits into the pair's
-// byte-per-match hypothesis mask). Per scale three launches -- tile_codes_kernel (code words with this scale's right cell,
+// byte-per-match hypothesis mask). Per scale four launches -- tile_codes_kernel (code words with this scale's right cell,
 // appended to the lists of the at most 2 x 2 tiles that keep the match's left cell), tile_filter_kernel (bin, verify under
-// all rotations, mark), tile_select_kernel (inliers per rotation, getInlierMask's strict '>' against the best hypothesis
-// so far, whose mask it replaces when beaten) -- and after the last scale band_compact_kernel copies the survivors out.
+// all rotations, mark), tile_count_kernel + tile_apply_kernel (inliers per rotation, getInlierMask's strict '>' against the
+// best hypothesis so far, whose mask is replaced when beaten) -- and after the last scale band_compact_kernel copies the survivors out.
 // Pairs with a cell above 65 535 matches are flagged for the HBM-slab kernel as in the default-flag path.
 // ================================================================================================================================
 struct TileGeom {
@@ -739,58 +739,73 @@ tile_filter_kernel(FilterParams p, TileGeom gm, const uint2* lists, const uint32
     });
 }
 
-// inliers per rotation of the scale just filtered; getInlierMask's strict '>' (scale outer, rotation inner) against the best
-// hypothesis so far; state = {best count, best scale, best rotation, -} per pair; bestmask = the winner's inlier bytes
+// Inliers per rotation of the scale just filtered (tile_count_kernel: grid 16k-match tiles x pairs, into cnt_g[pair][8]), then
+// getInlierMask's strict '>' (scale outer, rotation inner) against the best hypothesis so far (tile_apply_kernel: every
+// workgroup of a pair reads the same counts and the same incoming state, so all take the same decision; the winner's inlier
+// bytes replace the best mask tile by tile, workgroup 0 writes the outgoing state). state = {best count, best scale, best
+// rotation, -} per pair, ping-ponged between two arrays from scale to scale.
 template <bool ROT>
 __global__ void __launch_bounds__(1024)
-tile_select_kernel(FilterParams p, int scale, const uint8_t* rotmask, uint8_t* bestmask_ws, uint32_t* state, const uint32_t* flags,
-                   int mcap)
+tile_count_kernel(FilterParams p, const uint8_t* rotmask, uint32_t* cnt_g, const uint32_t* flags, int mcap)
 {
     __shared__ uint32_t cnt[8];
-    __shared__ int winner_s;
-    const int pi = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
-    const gms_pair pr = p.pairs[pi];
-    const int m = pr.m;
-    if (m <= 0 || m > mcap || (flags[pi] & (kFlagDomain | kFlagGeneral))) return;
-    const uint8_t* rm = rotmask + (size_t)pi * mcap;
-    uint8_t* bm = p.mask ? p.mask + pr.match_off : bestmask_ws + (size_t)pi * mcap;
+    const int tile = blockIdx.x, pi = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
+    const int m = p.pairs[pi].m;
+    if (m <= 0 || m > mcap || tile * 16384 >= m || (flags[pi] & (kFlagDomain | kFlagGeneral))) return;
     constexpr int kNRot = ROT ? 8 : 1;
     if (tid < 8) cnt[tid] = 0;
     __syncthreads();
+    const int first = tile * 16384 + tid * 16;  // 16 consecutive mask bytes per thread (the slab is 64-byte aligned)
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (first < m) v = *reinterpret_cast<const uint4*>(rotmask + (size_t)pi * mcap + first);  // bytes beyond m are zero (never marked)
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
     uint32_t c[kNRot];
 #pragma unroll
-    for (int r = 0; r < kNRot; ++r) c[r] = 0;
-    for (int i0 = 0; i0 < m; i0 += 1024) {
-        const int i = i0 + tid;
-        const uint32_t b = i < m ? rm[i] : 0u;
+    for (int r = 0; r < kNRot; ++r) {
+        uint32_t acc = 0;
 #pragma unroll
-        for (int r = 0; r < kNRot; ++r) c[r] += (uint32_t)__popcll(__ballot((b >> r) & 1u));
+        for (int q = 0; q < 4; ++q) acc += (((w[q] >> r) & 0x01010101u) * 0x01010101u) >> 24;  // bytes with bit r set
+        c[r] = acc;
     }
-    if (lane == 0) {
 #pragma unroll
-        for (int r = 0; r < kNRot; ++r)
-            if (c[r]) atomicAdd(&cnt[r], c[r]);
+    for (int r = 0; r < kNRot; ++r) {
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) c[r] += __shfl_xor(c[r], d);
+        if (lane == 0 && c[r]) atomicAdd(&cnt[r], c[r]);
     }
     __syncthreads();
-    if (tid == 0) {
-        uint32_t best = state[pi * 4 + 0];
-        int w = -1;
-        for (int r = 0; r < kNRot; ++r)
-            if (cnt[r] > best) {
-                best = cnt[r];
-                w = r;
-            }
-        winner_s = w;
-        if (w >= 0) {
-            state[pi * 4 + 0] = best;
-            state[pi * 4 + 1] = (uint32_t)scale;
-            state[pi * 4 + 2] = (uint32_t)(w + 1);
+    if (tid < kNRot && cnt[tid]) atomicAdd(&cnt_g[pi * 8 + tid], cnt[tid]);
+}
+
+template <bool ROT>
+__global__ void __launch_bounds__(1024)
+tile_apply_kernel(FilterParams p, int scale, const uint8_t* rotmask, uint8_t* bestmask_ws, const uint32_t* cnt_g,
+                  const uint32_t* state_in, uint32_t* state_out, const uint32_t* flags, int mcap)
+{
+    const int tile = blockIdx.x, pi = blockIdx.y, tid = threadIdx.x;
+    const gms_pair pr = p.pairs[pi];
+    const int m = pr.m;
+    if (m <= 0 || m > mcap || (flags[pi] & (kFlagDomain | kFlagGeneral))) return;
+    constexpr int kNRot = ROT ? 8 : 1;
+    uint32_t best = state_in[pi * 4 + 0];
+    int w = -1;
+#pragma unroll
+    for (int r = 0; r < kNRot; ++r) {
+        const uint32_t c = cnt_g[pi * 8 + r];
+        if (c > best) {
+            best = c;
+            w = r;
         }
     }
-    __syncthreads();
-    const int w = winner_s;
-    if (w >= 0 || scale == 0)  // (the first scale also initialises the mask: nothing may ever win)
-        for (int i = tid; i < m; i += 1024) bm[i] = w >= 0 ? (rm[i] >> w) & 1u : 0u;
+    if (tile == 0 && tid == 0) {
+        state_out[pi * 4 + 0] = best;
+        state_out[pi * 4 + 1] = w >= 0 ? (uint32_t)scale : state_in[pi * 4 + 1];
+        state_out[pi * 4 + 2] = w >= 0 ? (uint32_t)(w + 1) : state_in[pi * 4 + 2];
+    }
+    if (w < 0 && scale != 0) return;  // (the first scale also initialises the mask: nothing may ever win)
+    const uint8_t* rm = rotmask + (size_t)pi * mcap;
+    uint8_t* bm = p.mask ? p.mask + pr.match_off : bestmask_ws + (size_t)pi * mcap;
+    for (int i = tile * 16384 + tid; i < min(m, (tile + 1) * 16384); i += 1024) bm[i] = w >= 0 ? (rm[i] >> w) & 1u : 0u;
 }
 
 // ---- launch helpers ----------------------------------------------------------------------------------------------------
@@ -877,11 +892,11 @@ size_t tile_ws_bytes_per_pair(const FilterParams& p, int mcap, bool need_mask)
         const TileGeom g = tile_geom(p, s);
         max_tiles = g.tiles_y * g.tiles_x > max_tiles ? g.tiles_y * g.tiles_x : max_tiles;
     }
-    return (size_t)max_tiles * mcap * 8 + (size_t)kFineN * 4 + kMaxTiles * 4 + 4 + 16 + (size_t)mcap + (need_mask ? (size_t)mcap : 0) + 64;
+    return (size_t)max_tiles * mcap * 8 + (size_t)kFineN * 4 + kMaxTiles * 4 + 32 + 4 + 32 + (size_t)mcap + (need_mask ? (size_t)mcap : 0) + 64;
 }
 
-// ws layout for n pairs: lists [n][tiles][mcap] uint2 | nfine [n][1600] | list_len [n][32] | flags [n] | state [n][4] |
-//                        rotmask [n][mcap] u8 | bestmask [n][mcap] u8 (if p.mask is null)
+// ws layout for n pairs: lists [n][tiles][mcap] uint2 | nfine [n][1600] | list_len [n][32] | cnt [n][8] | flags [n] |
+//                        state [2][n][4] | rotmask [n][mcap] u8 | bestmask [n][mcap] u8 (if p.mask is null)
 hipError_t launch_filter_tiles(const FilterParams& p, int mcap, void* ws, const uint32_t** flags_out, hipStream_t stream)
 {
     const int n = p.n_pairs;
@@ -896,11 +911,12 @@ hipError_t launch_filter_tiles(const FilterParams& p, int mcap, void* ws, const 
     uint2* lists = reinterpret_cast<uint2*>(ws);
     uint32_t* nfine = reinterpret_cast<uint32_t*>(lists + (size_t)n * max_tiles * mcap);
     uint32_t* list_len = nfine + (size_t)n * kFineN;
-    uint32_t* flags = list_len + (size_t)n * kMaxTiles;
-    uint32_t* state = flags + n;
-    uint8_t* rotmask = reinterpret_cast<uint8_t*>(state + (size_t)n * 4);
+    uint32_t* cnt = list_len + (size_t)n * kMaxTiles;
+    uint32_t* flags = cnt + (size_t)n * 8;
+    uint32_t* state = flags + n;  // two arrays of n x 4, used alternately
+    uint8_t* rotmask = reinterpret_cast<uint8_t*>((reinterpret_cast<uintptr_t>(state + (size_t)n * 8) + 15) & ~(uintptr_t)15);  // read 16 bytes at a time
     uint8_t* bestmask = rotmask + (size_t)n * mcap;
-    hipError_t e = hipMemsetAsync(flags, 0, (size_t)n * 5 * 4, stream);  // flags + state
+    hipError_t e = hipMemsetAsync(flags, 0, (size_t)n * 9 * 4, stream);  // flags + both states
     if (e != hipSuccess) return e;
     if (p.mask == nullptr) {
         e = hipMemsetAsync(bestmask, 0, (size_t)n * mcap, stream);
@@ -920,7 +936,7 @@ hipError_t launch_filter_tiles(const FilterParams& p, int mcap, void* ws, const 
     for (int s = 0; s < n_scales; ++s) {
         const TileGeom g = tile_geom(p, s);
         const int n_tiles = g.tiles_y * g.tiles_x;
-        e = hipMemsetAsync(nfine, 0, ((size_t)n * kFineN + (size_t)n * kMaxTiles) * 4, stream);  // histogram + list lengths
+        e = hipMemsetAsync(nfine, 0, ((size_t)n * kFineN + (size_t)n * kMaxTiles + (size_t)n * 8) * 4, stream);  // histogram, list lengths, counts
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(tile_codes_kernel, dim3((unsigned)((mcap + 4095) / 4096), (unsigned)n), dim3(1024), 0, stream, p, g, lists,
                            list_len, nfine, flags, rotmask, mcap);
@@ -930,13 +946,19 @@ hipError_t launch_filter_tiles(const FilterParams& p, int mcap, void* ws, const 
         else
             hipLaunchKernelGGL(tile_filter_kernel<false>, dim3((unsigned)(n_tiles * 4), (unsigned)n), dim3(1024), kTileLdsBytes, stream, p, g,
                                lists, list_len, nfine, flags, reinterpret_cast<uint32_t*>(rotmask), mcap);
-        if (rot)
-            hipLaunchKernelGGL(tile_select_kernel<true>, dim3((unsigned)n), dim3(1024), 0, stream, p, s, rotmask, bestmask, state, flags, mcap);
-        else
-            hipLaunchKernelGGL(tile_select_kernel<false>, dim3((unsigned)n), dim3(1024), 0, stream, p, s, rotmask, bestmask, state, flags, mcap);
+        const dim3 tg((unsigned)((mcap + 16383) / 16384), (unsigned)n);
+        const uint32_t* st_in = state + (size_t)(s & 1) * n * 4;
+        uint32_t* st_out = state + (size_t)((s + 1) & 1) * n * 4;
+        if (rot) {
+            hipLaunchKernelGGL(tile_count_kernel<true>, tg, dim3(1024), 0, stream, p, rotmask, cnt, flags, mcap);
+            hipLaunchKernelGGL(tile_apply_kernel<true>, tg, dim3(1024), 0, stream, p, s, rotmask, bestmask, cnt, st_in, st_out, flags, mcap);
+        } else {
+            hipLaunchKernelGGL(tile_count_kernel<false>, tg, dim3(1024), 0, stream, p, rotmask, cnt, flags, mcap);
+            hipLaunchKernelGGL(tile_apply_kernel<false>, tg, dim3(1024), 0, stream, p, s, rotmask, bestmask, cnt, st_in, st_out, flags, mcap);
+        }
     }
     hipLaunchKernelGGL(band_compact_kernel, dim3((unsigned)((mcap + 16383) / 16384), (unsigned)n), dim3(1024), 0, stream, p, flags,
-                       bestmask, (const uint32_t*)state, mcap);
+                       bestmask, (const uint32_t*)(state + (size_t)(n_scales & 1) * n * 4), mcap);
     *flags_out = flags;
     return hipGetLastError();
 }
