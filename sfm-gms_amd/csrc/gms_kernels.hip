@@ -1036,7 +1036,7 @@ __device__ __forceinline__ bool dense_pair(const FilterParams& p, uint32_t* smem
             if (!kPackCell) row1[k] = binned ? __umul24(l1, kDenseRow) : 0u;
         }
         if (any_bad) misc[8] = 1;   // benign races: every writer stores 1
-        if (spill) misc[11] = 1;
+        if (spill) misc[13] = 1;  // (its own flag: misc[11] is written again while slower waves may still be reading this one)
     }
     GMS_STAMP(13);    // bin: codes + half-cell histogram
     __syncthreads();  // histogram complete; every read of the staged frame is done
@@ -1052,21 +1052,37 @@ __device__ __forceinline__ bool dense_pair(const FilterParams& p, uint32_t* smem
     }
     __syncthreads();
     GMS_STAMP(2);  // clear
-    if ((misc[8] | misc[11]) != 0) {  // workgroup-uniform; nothing has been written to global memory yet
-        __syncthreads();              // everybody has read the flags before the general path reuses the LDS
+    if (misc[8] != 0) {    // an input outside the parity domain (workgroup-uniform; nothing has been written to global memory yet)
+        __syncthreads();   // everybody has read the flag before the general path reuses the LDS
         return false;
     }
+    const bool spilled = misc[13] != 0;  // a half cell above 255 matches: straight to the crowded mode below
 
     const bool thr_fast = threshold_fast_ok(p.threshold_factor);
     const uint32_t f2i = dense_factor_sq(p.threshold_factor);
+    uint32_t* nl32 = nfine32;  // crowded mode: nLeft as 16-bit counters, two buffers of 400 (one per parity of the grid type)
+    auto cell_of = [&](int k, uint32_t cw, uint32_t q_mask) -> uint32_t {
+        if (kPackCell) return ((cw >> kDCellShift) & 0x1FFu) + (cw & q_mask);
+        return (((__umul24(cw & q_mask, kDenseRow) + row1[k]) >> 2) * 649u) >> 16;  // row / 404 for rows below 400
+    };
+
+    // The four grid types. CROWDED = some left cell holds more than 255 matches: a matrix entry still only overflows its byte
+    // when ONE (left cell, right cell) pair collects more than 255, which crowded scenes rarely do -- so the same byte matrix
+    // is used, with nLeft counted per grid type into 16-bit counters (one more LDS atomic per match, over the then useless
+    // half-cell histogram) and every returned count checked. Returns 0 = done, 1 = a cell above 255 matches (run again
+    // CROWDED), 2 = a matrix entry at its limit (the general path takes the pair).
+    auto run_types = [&](auto crowded_c) -> int {
+    constexpr bool CROWDED = decltype(crowded_c)::value;
     for (int g = 0; g < 4; ++g) {
         const int gx = g & 1, gy = g >> 1;
         const uint32_t q_mask = (uint32_t)(gx + 20 * gy);                                 // l = l1 + (q & q_mask)
         const uint32_t out_mask = kDNever | (gx ? kDEdgeX : 0u) | (gy ? kDEdgeY : 0u);    // x >= 20 || y >= 20 -> -1 (DLL@0x180047d3d)
         const uint32_t key_tag = (uint32_t)g << kDTagShift;
-        if (tid < kLeftN) {
-            // nLeft of this grid type, once per cell (read by verify, behind the next barrier); above 255 the byte matrix
-            // cannot hold the cell's row
+        uint32_t* nl32cur = nl32 + (g & 1) * (kLeftN / 2);
+        const uint16_t* nl16cur = reinterpret_cast<const uint16_t*>(nl32cur);
+        if (!CROWDED && tid < kLeftN) {
+            // nLeft of this grid type, once per cell (read by verify, behind the next barrier); above 255 a row's entries
+            // are no longer guaranteed to fit their bytes
             const uint32_t n = dense_nleft(nfine8, tid % kLeftW, tid / kLeftW, gx, gy);
             if (n > 255u) misc[11] = 1;
             nleft8[tid] = (uint8_t)n;
@@ -1083,23 +1099,28 @@ __device__ __forceinline__ bool dense_pair(const FilterParams& p, uint32_t* smem
                 at[c] = row[c] + ((cw >> kDEShift) & kDEMask);
                 old[c] = 0;
                 // shift counts are taken modulo 32: at << 3 selects the byte (at & 3)
-                if ((cw & out_mask) == 0) old[c] = atomicAdd(lds_at(smem, at[c] & ~3u), 1u << ((at[c] << 3) & 31u));
+                if ((cw & out_mask) == 0) {
+                    old[c] = atomicAdd(lds_at(smem, at[c] & ~3u), 1u << ((at[c] << 3) & 31u));
+                    if (CROWDED) {
+                        const uint32_t l = cell_of(k0 + c, cw, q_mask);
+                        atomicAdd(&nl32cur[l >> 1], 1u << ((l & 1u) << 4));
+                    }
+                }
             }
             __builtin_amdgcn_sched_barrier(0);  // all of the chunk's atomics are issued before any result is read
 #pragma unroll
             for (int c = 0; c < kChunk; ++c) {
                 const uint32_t cw = code[k0 + c];
-                const uint32_t before = (old[c] >> ((at[c] << 3) & 31u)) & 255u;  // <= 254
+                const uint32_t before = (old[c] >> ((at[c] << 3) & 31u)) & 255u;  // <= 254, or ...
+                if (CROWDED && (cw & out_mask) == 0 && before == 255u) misc[12] = 1;  // ... the entry's byte has just wrapped
                 if ((cw & out_mask) == 0) atomicMax(lds_at(smem, row[c]), key_tag | (before << 11) | ((cw >> kDEShift) & kDEMask));
             }
         }
         GMS_STAMP(3);  // insert
         __syncthreads();
         GMS_STAMP(11);  // insert: wait for the other waves
-        if (misc[11] != 0) {  // a cell above 255 matches under this grid type (workgroup-uniform; still nothing written out)
-            __syncthreads();
-            return false;
-        }
+        if (!CROWDED && misc[11] != 0) return 1;  // a cell above 255 matches under this grid type (workgroup-uniform)
+        if (CROWDED && misc[12] != 0) return 2;   // a (left cell, right cell) pair above 255 matches
 
         // ---- verifyCellPairs. Without rotation: two lanes per left cell, four neighbours each, joined by one DPP
         //      exchange; with rotation: one lane per (cell, rotation).
@@ -1111,7 +1132,7 @@ __device__ __forceinline__ bool dense_pair(const FilterParams& p, uint32_t* smem
                 const int rot = ROT ? (item & 7) : 0;
                 const int half = item & 1;  // !ROT only
                 const int ix = i % kLeftW, iy = i / kLeftW;
-                const uint32_t ni = live ? nleft8[i] : 0u;
+                const uint32_t ni = live ? (CROWDED ? (uint32_t)nl16cur[i] : (uint32_t)nleft8[i]) : 0u;
                 if (__ballot(ni != 0) == 0ull) continue;  // none of this wave's cells has a match under this grid type
                 const uint32_t best = smem[i * (kDenseRow / 4)] & ((1u << kDTagShift) - 1u);  // ((max count - 1) << 11) | E(j*), lowest j* among maxima
                 const uint32_t ej = ni ? (best & kDEMask) : (uint32_t)(kDenseRightN + 3);
@@ -1140,7 +1161,7 @@ __device__ __forceinline__ bool dense_pair(const FilterParams& p, uint32_t* smem
                         const bool okl = ni != 0 && (uint32_t)lx < (uint32_t)kLeftW && (uint32_t)ly < (uint32_t)kLeftH;  // ll != -1
                         const bool okp = okl && (uint32_t)rx < (uint32_t)kDenseRightW && (uint32_t)ry < (uint32_t)kDenseRightW;  // rr != -1
                         const uint32_t ll = okl ? (uint32_t)(lx + ly * kLeftW) : 0u;
-                        const uint32_t nll = nleft8[ll];
+                        const uint32_t nll = CROWDED ? (uint32_t)nl16cur[ll] : (uint32_t)nleft8[ll];
                         const uint32_t cnt = dense8[ll * kDenseRow + (okp ? (uint32_t)(kDenseRightN + 3 - (rx + ry * kDenseRightW)) : 4u)];
                         score += okp ? cnt : 0u;
                         tn += okp ? ((nll << 4) | 1u) : 0u;
@@ -1154,7 +1175,8 @@ __device__ __forceinline__ bool dense_pair(const FilterParams& p, uint32_t* smem
                 tn += (ni << 4) | 1u;
                 uint32_t pass = 0;
                 if (ni != 0 && (ROT || half == 0))
-                    pass = dense_threshold_rejects(tn >> 4, tn & 15u, score, p.threshold_factor, thr_fast, f2i) ? 0u : 1u;
+                    pass = (CROWDED ? threshold_rejects(tn >> 4, tn & 15u, score, p.threshold_factor, thr_fast)
+                                    : dense_threshold_rejects(tn >> 4, tn & 15u, score, p.threshold_factor, thr_fast, f2i)) ? 0u : 1u;
                 uint32_t bits = pass;
                 bool writer = ni != 0 && half == 0;
                 if (ROT) {
@@ -1191,9 +1213,35 @@ __device__ __forceinline__ bool dense_pair(const FilterParams& p, uint32_t* smem
                 if (x < 256u) code[k] |= x << kDAccShift;
             }
         }
+        if (CROWDED && tid < kLeftN / 2) nl32[((g + 1) & 1) * (kLeftN / 2) + tid] = 0;  // the next grid type's counters (last read two barriers ago)
         __syncthreads();  // the next grid type writes the headers; after the last one the matrix area is reused below
         GMS_STAMP(6);  // mark
     }
+    return 0;
+    };
+
+    int status = 1;
+    if (!spilled) status = run_types(std::false_type{});
+    if (status == 1) {
+        // crowded: start over on a clean matrix (the abandoned grid type's bytes may have wrapped), no inlier bits yet
+        __syncthreads();
+        {
+            const uint4 z4 = make_uint4(0, 0, 0, 0);
+            uint4* d4 = reinterpret_cast<uint4*>(smem);
+            for (uint32_t i = tid; i < kDenseBytes / 16; i += NT) d4[i] = z4;
+            if (tid < kLeftN) nl32[tid] = 0;
+            if (tid == 0) misc[11] = 0;
+        }
+#pragma unroll
+        for (int k = 0; k < KPT; ++k) code[k] &= ~((kPackCell ? 1u : 0xFFu) << kDAccShift);  // (the packed cell sits right above the one bit)
+        __syncthreads();
+        status = run_types(std::true_type{});
+    }
+    if (status != 0) {
+        __syncthreads();  // everybody has read the flags before the general path reuses the LDS
+        return false;
+    }
+
 
     // ---- run() return value per rotation and getInlierMask's strict '>' over the rotations (one scale). Without
     //      rotation there is one hypothesis: it wins iff it keeps anything, which the scan below reports anyway.
@@ -1420,7 +1468,7 @@ __device__ __forceinline__ bool dense_scales_pair(const FilterParams& p, uint32_
             rs[k] = binned ? (r[1] | (r[2] << 8) | (r[3] << 16)) : 0u;
         }
         if (any_bad) misc[8] = 1;
-        if (spill) misc[11] = 1;
+        if (spill) misc[13] = 1;  // (not misc[11]: that one is written again while slower waves may still be reading this)
     }
     __syncthreads();
     {
@@ -1429,7 +1477,7 @@ __device__ __forceinline__ bool dense_scales_pair(const FilterParams& p, uint32_
         for (uint32_t i = tid; i < staged16; i += NT) d4[i] = z4;
     }
     __syncthreads();
-    if ((misc[8] | misc[11]) != 0) {  // workgroup-uniform
+    if ((misc[8] | misc[13]) != 0) {  // workgroup-uniform
         __syncthreads();
         return false;
     }

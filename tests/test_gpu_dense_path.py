@@ -91,6 +91,30 @@ def test_one_matrix_entry_reaches_255(ctx, oracle):
     assert kept >= 255
 
 
+@pytest.mark.parametrize("rot", [False, True])
+@pytest.mark.parametrize("n", [256, 257, 300, 600])
+def test_one_matrix_entry_above_255(ctx, oracle, n, rot):
+    """More than 255 matches from one left cell into one right cell: in the crowded mode the entry's byte would wrap; the pair
+    has to be recognised and handed to the general path."""
+    c = _case([((0.5, 0.5), (12.5, 3.5), n, (0.3, 0.3))], background=True)
+    assert _check(ctx, oracle, c, rot) >= n
+
+
+@pytest.mark.parametrize("rot", [False, True])
+def test_crowded_scene_stays_on_the_byte_matrix(ctx, oracle, rot):
+    """Many cells far above 255 matches but spread over many right cells each (noisy correspondences): no entry reaches 255, the
+    crowded mode (16-bit nLeft counters) finishes the pair."""
+    rng = np.random.default_rng(31)
+    n = 9000
+    xy1 = np.stack([rng.uniform(0.35 * W, 0.65 * W, n), rng.uniform(0.35 * H, 0.65 * H, n)], axis=1)   # 6 x 6 cells, 250 each
+    xy2 = xy1 + rng.normal(0, 60.0, xy1.shape)                                                          # smeared over neighbouring right cells
+    xy1 = np.clip(xy1, 0, [W - 0.01, H - 0.01]).astype(np.float32)
+    xy2 = np.clip(xy2, 0, [W - 0.01, H - 0.01]).astype(np.float32)
+    c = cases._pair(xy1, xy2, np.arange(n), np.arange(n), (W, H), (W, H))
+    c["matches"] = c["matches"][rng.permutation(n)]
+    _check(ctx, oracle, c, rot)
+
+
 def test_all_matches_in_the_last_half_cell(ctx, oracle):
     """Points with x, y in the last half cell: binned under grid type 1 only (x >= 20 || y >= 20 elsewhere)."""
     _check(ctx, oracle, _case([((19.8, 19.8), (19.8, 19.8), 200, (0.15, 0.15))], background=False), False)
