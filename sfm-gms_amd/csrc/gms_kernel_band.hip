@@ -757,8 +757,15 @@ tile_count_kernel(FilterParams p, const uint8_t* rotmask, uint32_t* cnt_g, const
     __syncthreads();
     const int first = tile * 16384 + tid * 16;  // 16 consecutive mask bytes per thread (the slab is 64-byte aligned)
     uint4 v = make_uint4(0, 0, 0, 0);
-    if (first < m) v = *reinterpret_cast<const uint4*>(rotmask + (size_t)pi * mcap + first);  // bytes beyond m are zero (never marked)
-    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    if (first < m) v = *reinterpret_cast<const uint4*>(rotmask + (size_t)pi * mcap + first);
+    uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    if (first + 16 > m) {  // the slab beyond this pair's m matches holds whatever an earlier, larger pair left there
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int left = m - (first + 4 * q);  // bytes of this dword that belong to the pair
+            w[q] = left >= 4 ? w[q] : left <= 0 ? 0u : (w[q] & ((1u << (8 * left)) - 1u));
+        }
+    }
     uint32_t c[kNRot];
 #pragma unroll
     for (int r = 0; r < kNRot; ++r) {

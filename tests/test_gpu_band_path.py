@@ -216,3 +216,14 @@ def test_tiles_mixed_batch(ctx, oracle, pkg, synth, want_mask):
     for i in range(len(pairs)):
         o, k = int(pairs["match_off"][i]), int(res["n_inliers"][i])
         assert out[o:o + k].tobytes() == wout[o:o + k].tobytes()
+
+
+def test_tiles_workspace_left_by_a_larger_pair(ctx, oracle):
+    """A pair with rotation hypotheses after a larger one on the same context: the hypothesis mask slab beyond the second pair's
+    matches still holds the first pair's bits and must not be counted (m deliberately not a multiple of 16)."""
+    big = cases.random_pair(131, n=90000, inlier_frac=0.7, theta_deg=45.0)
+    _check(ctx, oracle, big, True, False)
+    for n in (20003, 16391, 33333):
+        small = cases.random_pair(132 + n % 5, n=n, inlier_frac=0.3, theta_deg=90.0, scale=0.5)
+        _check(ctx, oracle, small, True, True)
+        _check(ctx, oracle, small, True, False)
