@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Extended randomised parity sweep on the GPU (diagnostic; the committed suite is tests/test_gpu_fuzz.py): pairs of every
 size class (register + LDS kernels, 16-match-per-thread variant, band / tile kernels), clustered and lattice keypoints, all
-flag combinations and a few threshold factors, each compared bit for bit with the oracle. python tools/fuzz_gpu.py [seconds]"""
+flag combinations and a few threshold factors, each compared bit for bit with the oracle.
+python tools/fuzz_gpu.py [seconds] [batch]   (batch: random ragged batches through the device-resident path)"""
 import importlib
 import os
 import sys
@@ -60,8 +61,54 @@ def case(seed):
                 matches=synth.make_matches(q, t, rng)), FLAGS[int(rng.integers(0, 4))], thr
 
 
+def batch_main(budget):
+    """Random batches through the device-resident path (one launch per batch, workspaces reused from batch to batch)."""
+    batch = importlib.import_module("sfm-gms_amd.batch")
+    ctx = pkg.GmsContext(0)
+    t0, n, bad = time.time(), 0, 0
+    seed = int(os.environ.get("FUZZ_SEED0", "0"))
+    while time.time() - t0 < budget:
+        rng = np.random.default_rng(123000 + seed)
+        n_pairs = int(rng.integers(1, 9))
+        frames, sizes, pairs, matches, off = [], [], [], [], 0
+        for i in range(n_pairs):
+            c, _, _ = case(seed * 16 + i)
+            mt = c["matches"]
+            if rng.uniform() < 0.15:
+                mt = mt[:0]
+            frames += [c["kp1"], c["kp2"]]
+            sizes += [c["size1"], c["size2"]]
+            pairs.append((2 * i, 2 * i + 1, len(mt), 0, off))
+            matches.append(mt)
+            off += len(mt)
+        pairs = np.array(pairs, dtype=pkg.PAIR_DTYPE)
+        matches = np.concatenate(matches) if off else np.zeros(0, dtype=pkg.DMATCH_DTYPE)
+        flags = FLAGS[int(rng.integers(0, 4))]
+        thr = float(rng.choice([6.0, 6.0, 2.0]))
+        want_mask = bool(rng.integers(0, 2))
+        table = batch.FrameTable(ctx, frames, sizes)
+        out, res, mask = batch.filter_pairs(ctx, table, pairs, matches, flags[0], flags[1], thr, want_mask=want_mask)
+        wh = np.array(sizes, dtype=np.int32).reshape(-1)
+        failed, wout, wres, wmask = gms_oracle.batch(np.concatenate(frames), table.frame_off_host, wh, pairs, matches, flags[0], flags[1], thr, 8)
+        ok = failed == 0 and res.tobytes() == wres.tobytes() and (not want_mask or np.array_equal(mask, wmask))
+        for i in range(len(pairs)):
+            o, k = int(pairs["match_off"][i]), int(res["n_inliers"][i])
+            ok = ok and out[o:o + k].tobytes() == wout[o:o + k].tobytes()
+        if not ok:
+            bad += 1
+            print("BATCH MISMATCH seed", seed, "m", pairs["m"].tolist(), "flags", flags, "thr", thr, "mask", want_mask, res.tolist(), wres.tolist(), flush=True)
+        n += 1
+        seed += 1
+        if n % 20 == 0:
+            print(f"{n} batches, {bad} mismatches, {time.time() - t0:.0f} s", flush=True)
+    print(f"done: {n} batches, {bad} mismatches")
+    sys.exit(1 if bad else 0)
+
+
 def main():
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+    if len(sys.argv) > 2 and sys.argv[2] == "batch":
+        batch_main(budget)
     ctx = pkg.GmsContext(0)
     t0, n, bad = time.time(), 0, 0
     seed = int(os.environ.get("FUZZ_SEED0", "0"))
