@@ -1477,10 +1477,12 @@ __device__ __forceinline__ bool dense_scales_pair(const FilterParams& p, uint32_
         for (uint32_t i = tid; i < staged16; i += NT) d4[i] = z4;
     }
     __syncthreads();
-    if ((misc[8] | misc[13]) != 0) {  // workgroup-uniform
+    if (misc[8] != 0) {  // an input outside the parity domain (workgroup-uniform)
         __syncthreads();
         return false;
     }
+    const bool spilled = misc[13] != 0;  // a half cell above 255 matches: crowded from the start (see dense_pair)
+    uint32_t* nl32 = nfine32;            // crowded mode: nLeft as 16-bit counters, two buffers of 400
 
     const bool thr_fast = threshold_fast_ok(p.threshold_factor);
     const uint32_t f2i = dense_factor_sq(p.threshold_factor);
@@ -1504,8 +1506,10 @@ __device__ __forceinline__ bool dense_scales_pair(const FilterParams& p, uint32_
         }
     }
 
-    auto run_scale = [&](auto banded_c, const int s) {
+    // returns 0 = done, 1 = a cell above 255 matches (everything is run again CROWDED), 2 = a matrix entry at its limit
+    auto run_scale = [&](auto banded_c, auto crowded_c, const int s) -> int {
         constexpr bool BANDED = decltype(banded_c)::value;
+        constexpr bool CROWDED = decltype(crowded_c)::value;
         const uint32_t wr = (uint32_t)p.right_w[s], nr = wr * wr;
         const uint32_t stride = 4u + nr;                 // header dword + one byte per right cell
         const uint32_t wr_magic = 65535u / wr + 1u;      // j / wr == (j * magic) >> 16 for j * wr < 65536
@@ -1516,15 +1520,25 @@ __device__ __forceinline__ bool dense_scales_pair(const FilterParams& p, uint32_
                 if (!(code[k] & kDNever)) code[k] = (code[k] & ~(kSEMask << kDEShift)) | ((nr + 3u - r) << kDEShift);
             }
         }
-        bool ok_all = true;
+        int status = 0;
         for (int g = 0; g < 4; ++g) {
             const int gx = g & 1, gy = g >> 1;
             const uint32_t q_mask = (uint32_t)(gx + 20 * gy);
             const uint32_t out_mask = kDNever | (gx ? kDEdgeX : 0u) | (gy ? kDEdgeY : 0u);
-            if (tid < kLeftN) {
+            uint32_t* nl32cur = nl32 + (g & 1) * (kLeftN / 2);
+            const uint16_t* nl16cur = reinterpret_cast<const uint16_t*>(nl32cur);
+            if (!CROWDED && tid < kLeftN) {
                 const uint32_t n = dense_nleft(nfine8, tid % kLeftW, tid / kLeftW, gx, gy);
                 if (n > 255u) misc[11] = 1;
                 nleft8[tid] = (uint8_t)n;
+            }
+            if (CROWDED) {  // nLeft of this grid type by counting (read by verify, behind the first barrier below)
+#pragma unroll
+                for (int k = 0; k < KPT; ++k) {
+                    const uint32_t cw = code[k];
+                    const uint32_t l = cell1[k] + (cw & q_mask);
+                    if ((cw & out_mask) == 0) atomicAdd(&nl32cur[l >> 1], 1u << ((l & 1u) << 4));
+                }
             }
             constexpr int kBandRows = 8;
             for (int band = 0; band < (BANDED ? (kLeftH + kBandRows - 1) / kBandRows : 1); ++band) {
@@ -1555,12 +1569,17 @@ __device__ __forceinline__ bool dense_scales_pair(const FilterParams& p, uint32_
 #pragma unroll
                     for (int c = 0; c < kChunk; ++c) {
                         const uint32_t before = (old[c] >> ((at[c] << 3) & 31u)) & 255u;
+                        if (CROWDED && in[c] && before == 255u) misc[12] = 1;  // the entry's byte has just wrapped
                         if (in[c]) atomicMax(lds_at(smem, row[c]), key_tag | (before << 11) | ((code[k0 + c] >> kDEShift) & kSEMask));
                     }
                 }
                 __syncthreads();
-                if (misc[11] != 0) {  // a cell above 255 matches (workgroup-uniform; nothing has been written out)
-                    ok_all = false;
+                if (!CROWDED && misc[11] != 0) {  // a cell above 255 matches (workgroup-uniform; nothing has been written out)
+                    status = 1;
+                    break;
+                }
+                if (CROWDED && misc[12] != 0) {  // a (left cell, right cell) pair above 255 matches
+                    status = 2;
                     break;
                 }
 
@@ -1572,7 +1591,7 @@ __device__ __forceinline__ bool dense_scales_pair(const FilterParams& p, uint32_
                         const int i = (int)own0 + (live ? (ROT ? (item >> 3) : (item >> 1)) : 0);
                         const int half = item & 1;  // !ROT only
                         const int ix = i % kLeftW, iy = i / kLeftW;
-                        const uint32_t ni = live ? nleft8[i] : 0u;
+                        const uint32_t ni = live ? (CROWDED ? (uint32_t)nl16cur[i] : (uint32_t)nleft8[i]) : 0u;
                         if (__ballot(ni != 0) == 0ull) continue;  // none of this wave's cells has a match under this grid type
                         const uint32_t hdr = ((uint32_t)i - cell0) * (stride >> 2);
                         const uint32_t best = smem[hdr] & ((1u << kDTagShift) - 1u);
@@ -1601,7 +1620,7 @@ __device__ __forceinline__ bool dense_scales_pair(const FilterParams& p, uint32_
                                 const bool okl = ni != 0 && (uint32_t)lx < (uint32_t)kLeftW && (uint32_t)ly < (uint32_t)kLeftH;
                                 const bool okp = okl && (uint32_t)rx < wr && (uint32_t)ry < wr;
                                 const uint32_t ll = okl ? (uint32_t)(lx + ly * kLeftW) : (uint32_t)i;  // within one row of an own row: held
-                                const uint32_t nll = nleft8[ll];
+                                const uint32_t nll = CROWDED ? (uint32_t)nl16cur[ll] : (uint32_t)nleft8[ll];
                                 const uint32_t cnt = dense8[(ll - cell0) * stride + (okp ? nr + 3u - (uint32_t)(rx + ry * (int)wr) : 4u)];
                                 score += okp ? cnt : 0u;
                                 tn += okp ? ((nll << 4) | 1u) : 0u;
@@ -1615,7 +1634,8 @@ __device__ __forceinline__ bool dense_scales_pair(const FilterParams& p, uint32_
                         tn += (ni << 4) | 1u;
                         uint32_t pass = 0;
                         if (ni != 0 && (ROT || half == 0))
-                            pass = dense_threshold_rejects(tn >> 4, tn & 15u, score, p.threshold_factor, thr_fast, f2i) ? 0u : 1u;
+                            pass = (CROWDED ? threshold_rejects(tn >> 4, tn & 15u, score, p.threshold_factor, thr_fast)
+                                            : dense_threshold_rejects(tn >> 4, tn & 15u, score, p.threshold_factor, thr_fast, f2i)) ? 0u : 1u;
                         uint32_t bits = pass;
                         bool writer = ni != 0 && half == 0;
                         if (ROT) {
@@ -1630,6 +1650,7 @@ __device__ __forceinline__ bool dense_scales_pair(const FilterParams& p, uint32_
 
                 // ---- mark the matches of the own rows; every increment of the rows held is taken back
                 {
+                    if (CROWDED && tid < kLeftN / 2) nl32[((g + 1) & 1) * (kLeftN / 2) + tid] = 0;  // the next grid type's counters (idle now; a barrier follows)
                     uint32_t cr[KPT];
 #pragma unroll
                     for (int k = 0; k < KPT; ++k) {
@@ -1651,9 +1672,9 @@ __device__ __forceinline__ bool dense_scales_pair(const FilterParams& p, uint32_
                 }
                 __syncthreads();
             }
-            if (!ok_all) break;
+            if (status != 0) break;
         }
-        if (!ok_all) return false;
+        if (status != 0) return status;
         // the next scale lays its rows out differently: no header of this one may survive as a count byte
         for (uint32_t c = tid; c < (uint32_t)kLeftN; c += NT)
             if (!BANDED || c < 10u * kLeftW) smem[c * (stride >> 2)] = 0;
@@ -1701,15 +1722,33 @@ __device__ __forceinline__ bool dense_scales_pair(const FilterParams& p, uint32_
         for (int k = 0; k < KPT; ++k) code[k] &= ~(0xFFu << kSAccShift);
         __syncthreads();
         if (tid < 8) misc[tid] = 0;
-        return true;
+        return 0;
     };
 
-    for (int s = 0; s < 3; ++s)
-        if (!run_scale(std::false_type{}, s)) {
-            __syncthreads();
-            return false;
+    int status = spilled ? 1 : 0;
+    for (int s = 0; s < 3 && status == 0; ++s) status = run_scale(std::false_type{}, std::false_type{}, s);
+    if (status == 0) status = run_scale(std::true_type{}, std::false_type{}, 3);
+    if (status == 1) {
+        // crowded (dense_pair has the same mode): everything again on a clean matrix, nLeft counted into 16-bit counters and
+        // every returned entry count checked; the cell populations do not depend on the scale, so this shows at scale 0
+        __syncthreads();
+        {
+            const uint4 z4 = make_uint4(0, 0, 0, 0);
+            uint4* d4 = reinterpret_cast<uint4*>(smem);
+            for (uint32_t i = tid; i < kDenseBytes / 16; i += NT) d4[i] = z4;
+            if (tid < kLeftN) nl32[tid] = 0;
+            if (tid < 8) misc[tid] = 0;
         }
-    if (!run_scale(std::true_type{}, 3)) {
+#pragma unroll
+        for (int k = 0; k < KPT; ++k) code[k] &= ~(0xFFu << kSAccShift);  // (the code words still hold scale 0's right cell: the check trips there)
+        best_count = 0;
+        best_scale = best_rot = -1;
+        __syncthreads();
+        status = 0;
+        for (int s = 0; s < 3 && status == 0; ++s) status = run_scale(std::false_type{}, std::true_type{}, s);
+        if (status == 0) status = run_scale(std::true_type{}, std::true_type{}, 3);
+    }
+    if (status != 0) {
         __syncthreads();
         return false;
     }

@@ -40,5 +40,11 @@ for name, fn in (("uniform", orig), ("crowded", squeezed)):
     w, k = bench.timed_steps(ctx, wl, stream, 10, 2, False, False, None)
     rate_mt, rate1, ok, n = bench.cpu_leg(argparse.Namespace(cpu_pairs=64, cpu_threads=16), wl, pkg, False, False, 64, 16)
     out[name] = {"pairs_per_s": 4096 * 10 / w, "kernel_ms": k, "parity_64_pairs": ok}
+    sub = dict(wl)
+    sub["n_pairs"] = 512
+    w2, k2 = bench.timed_steps(ctx, sub, stream, 6, 2, True, True, None)
+    rate_mt2, rate12, ok2, n2 = bench.cpu_leg(argparse.Namespace(cpu_pairs=16, cpu_threads=16), sub, pkg, True, True, 16, 16)
+    out[name]["rot_scale_pairs_per_s"] = 512 * 6 / w2
+    out[name]["rot_scale_parity_16_pairs"] = ok2
     ctx.close()
 print(json.dumps(out, indent=1))
