@@ -61,7 +61,8 @@ image, ≈277 matches per populated cell): every pair trips the first `nLeft` ch
 the same byte matrix (an entry only wraps when ONE (left cell, right cell) pair collects more than 255 matches; every returned
 count is checked, and then the hashed path takes over), `nLeft` counted per grid type into 16-bit counters with one more LDS
 atomic per match — {cs['crowded']['pairs_per_s']/1e6:.2f} M pairs/s ({cs['uniform']['pairs_per_s']/1e6:.2f} M in the same run for the uniform sequence; 3.88 M before the crowded mode
-existed, when such pairs went to the hashed path), bit-exact.
+existed, when such pairs went to the hashed path), bit-exact. With rotation + scale the dense-scales kernel has the same mode:
+{cs['crowded']['rot_scale_pairs_per_s']/1e3:.0f} k pairs/s on the crowded sequence ({cs['uniform']['rot_scale_pairs_per_s']/1e3:.0f} k on the uniform one in the same run: fewer populated cells, fewer verify waves).
 
 """
 side = f"""Side measurements (`r01_side_measurements.json`): the one-shot host-pointer call `gms_match` on a 10k-match pair takes
