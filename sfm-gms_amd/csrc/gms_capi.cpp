@@ -224,7 +224,7 @@ int gms_filter_device(gms_ctx* c, const float* d_pts, const int64_t* d_frame_off
         return !e || std::atoi(e) != 0;
     }();
     p.dense = (dense_on && !with_scale) ? 1 : 0;
-    p.stagger_cycles = (n_pairs >= 4 * p.stagger_blocks) ? (stagger_us >= 0 ? stagger_us : (p.dense ? 30 : 72)) * 2400 : 0;
+    p.stagger_cycles = (n_pairs >= 4 * p.stagger_blocks) ? (stagger_us >= 0 ? stagger_us : (p.dense ? 26 : 72)) * 2400 : 0;
 #ifdef GMS_PHASE_TIMING
     p.diag = g_diag;
 #endif
