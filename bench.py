@@ -1,34 +1,39 @@
 #!/usr/bin/env python3
 """bench.py -- GMS-filtered image pairs per second on MI355X (BASELINE.json metric).
 
-A "step" is one pass of the hot path (gms_filter_device, one launch) over one batch of synthetic image
-pairs whose keypoint tables and putative matches are already resident in HBM. Workload = BASELINE
-config 3 ("1080p sequence, 10k features per frame, all pairs sharded across GPUs") at the flags the
-reference's DisparityUtil.cpp:149,299 call sites use (withRotation=false, withScale=false, 6.0); the
-(true, true) flags of FeatureMatchUtil.cpp:69 are reported beside it under "rot_scale".
+Workload = BASELINE config 3: ONE synthetic 1000-frame 1080p sequence, 10k keypoints per frame (an 80 MB table of
+normalised points, replicated on every GPU), all 499 500 pairs (a < b) in lexicographic order; rank r owns the contiguous
+block shard_range(499500, r, world) of that one list. A "step" is one pass of the hot path (gms_filter_device, one
+launch) over the next chunk of `--pairs` pairs of the rank's block, with the chunk's putative matches (M = 10k per pair,
+generated on the device, a pure function of the global pair index) already resident in HBM; every step works on a
+different chunk. Flags of the headline: the reference's DisparityUtil.cpp:149,299 call sites (withRotation=false,
+withScale=false, 6.0); the (true, true) flags of FeatureMatchUtil.cpp:69 are reported beside it under "rot_scale".
 
-  python bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W         (N > 1 without a launcher: starts the N ranks itself)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
          --master-port P bench.py --gpus N --steps K --warmup W
 
-Pairs are independent: each rank owns a contiguous shard of the global pair list and
-there is no collective on the data path ("scaling": "weak": pairs per GPU are fixed). torch is used for
-device memory, streams, events and the rendezvous only.
+Pairs are independent: no collective on the data path ("scaling": "weak": pairs per GPU per step are
+fixed). The rendezvous (barrier around the timed region, MAX of the ranks' times, SUM of the parity counts) runs over
+gloo on CPU tensors -- the path needs no RCCL. Every rank checks every 997th global pair it filtered against the CPU
+oracle, outside the timed region; a mismatch makes the run exit non-zero.
 """
 import argparse
 import importlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 import numpy as np
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 PKG = "sfm-gms_amd"
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s achievable by a copy
+SIZE = (1920, 1080)
 
 
 def parse():
@@ -36,231 +41,274 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--pairs", type=int, default=4096, help="image pairs per step per GPU")
-    ap.add_argument("--frames", type=int, default=128, help="frames of the synthetic sequence per GPU shard")
+    ap.add_argument("--pairs", type=int, default=4096, help="image pairs per step per GPU (one chunk)")
+    ap.add_argument("--frames", type=int, default=1000, help="frames of the synthetic sequence (config 3: 1000)")
     ap.add_argument("--features", type=int, default=10000)
     ap.add_argument("--inlier-frac", type=float, default=0.5)
-    ap.add_argument("--cpu-pairs", type=int, default=256, help="sample size of the CPU baseline / parity check")
-    ap.add_argument("--cpu-threads", type=int, default=16)
+    ap.add_argument("--max-resident", type=int, default=24,
+                    help="chunks kept resident in HBM (1.3 GB each at the defaults); more steps cycle through them")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the all-core CPU baseline (0 = every CPU this process may use)")
+    ap.add_argument("--cpu-reps", type=int, default=5)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg (profiling runs)")
     ap.add_argument("--no-extra", action="store_true", help="skip the rot+scale side measurement")
     return ap.parse_args()
 
 
-def build_workload(args, rank, world, dev, pkg, synth, ctx):
-    """Frames of one synthetic 1080p sequence + this rank's shard of the pair list, all on the GPU."""
-    size = (1920, 1080)
-    n_kp = args.features
-    frames = synth.make_sequence(1000 + rank, args.frames, size=size, n_kp=n_kp)
-    batch = importlib.import_module(PKG + ".batch")
-    table = batch.FrameTable(ctx, frames, [size] * args.frames, device=dev)
-
-    # global pair list of the whole job = world * pairs; this rank takes its contiguous block
-    n_total = args.pairs * world
-    lo, hi = pkg.shard_range(n_total, rank, world)
-    n_pairs = hi - lo
-    all_pairs = pkg.all_pairs_count(args.frames)
-    pairs = np.zeros(n_pairs, dtype=pkg.PAIR_DTYPE)
-    for i in range(n_pairs):
-        a, b = pkg.pair_from_index((i * 7919 + rank) % all_pairs, args.frames)
-        pairs[i] = (a, b, n_kp, 0, i * n_kp)
-
-    # putative matches generated on the device (M = N1, queryIdx = i; a fraction are true correspondences
-    # i -> i, the rest uniformly random), like BFMatcher output without cross-check
-    g = torch.Generator(device=dev)
-    g.manual_seed(0x5F3759DF ^ (77 + rank))
-    total_m = n_pairs * n_kp
-    q = torch.arange(n_kp, device=dev, dtype=torch.int32).repeat(n_pairs)
-    is_in = torch.rand(total_m, device=dev, generator=g) < args.inlier_frac
-    rnd = torch.randint(0, n_kp, (total_m,), device=dev, generator=g, dtype=torch.int32)
-    t = torch.where(is_in, q, rnd)
-    dist = torch.rand(total_m, device=dev, generator=g) * 256.0
-    d_matches = torch.empty((total_m, 4), dtype=torch.int32, device=dev)
-    d_matches[:, 0] = q
-    d_matches[:, 1] = t
-    d_matches[:, 2] = 0
-    d_matches[:, 3] = dist.view(torch.int32)
-    del q, is_in, rnd, t, dist
-    d_pairs = torch.from_numpy(pairs.view(np.uint8).reshape(-1)).to(dev)
-    d_out = torch.zeros((total_m, 4), dtype=torch.int32, device=dev)
-    d_res = torch.zeros((n_pairs, 4), dtype=torch.int32, device=dev)
-    return dict(size=size, frames=frames, table=table, pairs=pairs, d_pairs=d_pairs, d_matches=d_matches,
-                d_out=d_out, d_res=d_res, n_pairs=n_pairs, n_kp=n_kp)
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as child processes (before anything here has
+    touched the GPU), relay their output, exit with their code."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
 
 
-def launch(ctx, wl, rot, scale):
-    t = wl["table"]
-    ctx.filter_device(t.d_pts.data_ptr(), t.d_frame_off.data_ptr(), t.n_frames, wl["d_pairs"].data_ptr(),
-                      wl["n_pairs"], wl["n_kp"], wl["d_matches"].data_ptr(), wl["d_out"].data_ptr(),
-                      wl["d_res"].data_ptr(), None, rot, scale, 6.0)
+class Workload:
+    """This rank's share of config 3, resident on the GPU: the frame table and `n_res` chunks of pairs + matches."""
+
+    def __init__(self, args, rank, world, dev, pkg, ctx):
+        import torch
+        synth = importlib.import_module(PKG + ".synth")
+        batch = importlib.import_module(PKG + ".batch")
+        self.dist = importlib.import_module(PKG + ".dist")
+        self.n_kp = args.features
+        self.frames = synth.make_sequence(1000, args.frames, size=SIZE, n_kp=self.n_kp)  # the same sequence on every rank
+        self.table = batch.FrameTable(ctx, self.frames, [SIZE] * args.frames, device=dev)
+        n_chunks = min(args.warmup + args.steps, max(1, args.max_resident))
+        self.plan = self.dist.RankPlan(args.frames, self.n_kp, args.pairs, n_chunks, rank, world)
+        self.n_pairs = self.plan.chunk
+        self.chunks = []
+        for c in range(n_chunks):
+            pairs = self.plan.chunk_pairs(c)
+            total_m = self.n_pairs * self.n_kp
+            self.chunks.append(dict(
+                pairs=pairs,
+                d_pairs=torch.from_numpy(pairs.view(np.uint8).reshape(-1)).to(dev),
+                d_matches=self.dist.synth_matches_device(self.plan.starts[c], self.n_pairs, self.n_kp, args.inlier_frac, dev),
+                d_out=torch.zeros((total_m, 4), dtype=torch.int32, device=dev),
+                d_res=torch.zeros((self.n_pairs, 4), dtype=torch.int32, device=dev)))
+        torch.cuda.synchronize()
+
+    def launch(self, ctx, c, rot, scale, n_pairs=None):
+        t, ch = self.table, self.chunks[c % len(self.chunks)]
+        ctx.filter_device(t.d_pts.data_ptr(), t.d_frame_off.data_ptr(), t.n_frames, ch["d_pairs"].data_ptr(),
+                          n_pairs or self.n_pairs, self.n_kp, ch["d_matches"].data_ptr(), ch["d_out"].data_ptr(),
+                          ch["d_res"].data_ptr(), None, rot, scale, 6.0)
+
+    def host_pairs(self, pkg, c, idx):
+        """Host copies of pairs `idx` (indices inside chunk c): (pair table rebased to 0, matches, gpu out, gpu results)."""
+        ch = self.chunks[c]
+        n_kp = self.n_kp
+        idx = list(idx)
+        sel = ch["pairs"][idx].copy()
+        if idx == list(range(idx[0], idx[0] + len(idx))):  # a run of consecutive pairs: one copy each
+            m = ch["d_matches"][idx[0] * n_kp:(idx[-1] + 1) * n_kp].cpu().numpy()
+            o = ch["d_out"][idx[0] * n_kp:(idx[-1] + 1) * n_kp].cpu().numpy()
+        else:
+            m = np.concatenate([ch["d_matches"][i * n_kp:(i + 1) * n_kp].cpu().numpy() for i in idx])
+            o = np.concatenate([ch["d_out"][i * n_kp:(i + 1) * n_kp].cpu().numpy() for i in idx])
+        sel["match_off"] = np.arange(len(idx), dtype=np.int64) * n_kp
+        res = ch["d_res"].cpu().numpy().view(pkg.RESULT_DTYPE).reshape(-1)[idx]
+        return (sel, m.view(np.uint8).reshape(-1).view(pkg.DMATCH_DTYPE), o.view(np.uint8).reshape(-1).view(pkg.DMATCH_DTYPE), res)
 
 
-def timed_steps(ctx, wl, stream, steps, warmup, rot, scale, dist):
-    """W warm-up steps, then exactly K steps between barrier + synchronize brackets. Returns
-    (wall seconds of the K steps, mean kernel ms per launch from HIP events on the launch stream)."""
+def timed_steps(ctx, wl, stream, steps, warmup, rot, scale, dist, first_chunk=0, n_pairs=None):
+    """W warm-up steps, then exactly K steps between barrier + synchronize brackets. Returns (wall seconds of the K steps,
+    mean ms per launch from HIP events recorded on the launch stream)."""
+    import torch
     with torch.cuda.stream(stream):
-        for _ in range(warmup):
-            launch(ctx, wl, rot, scale)
+        for s in range(warmup):
+            wl.launch(ctx, first_chunk + s, rot, scale, n_pairs)
     torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
+    wl.dist.barrier(dist)
     torch.cuda.synchronize()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
     t0 = time.perf_counter()
     with torch.cuda.stream(stream):
         for s in range(steps):
             ev[s][0].record(stream)
-            launch(ctx, wl, rot, scale)
+            wl.launch(ctx, first_chunk + warmup + s, rot, scale, n_pairs)
             ev[s][1].record(stream)
     torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
+    wl.dist.barrier(dist)
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
-    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
-    return wall, kern_ms
+    return wall, float(np.mean([a.elapsed_time(b) for a, b in ev]))
 
 
-def cpu_leg(args, wl, pkg, rot, scale, n_sample, threads):
-    """Oracle (CPU restatement of the reference's matchGMS) on a bounded sample of the same pairs:
-    returns (pairs/s all threads, pairs/s one thread, parity ok, sample description)."""
+def oracle_module():
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import gms_oracle
-    n = min(n_sample, wl["n_pairs"])
-    n_kp = wl["n_kp"]
-    pairs = wl["pairs"][:n].copy()
-    matches = wl["d_matches"][: n * n_kp].cpu().numpy().view(pkg.DMATCH_DTYPE).reshape(-1)
-    kp_all = np.concatenate(wl["frames"])
-    foff = wl["table"].frame_off_host
-    wh = np.array([wl["size"]] * len(wl["frames"]), dtype=np.int32).reshape(-1)
-    # parity of the GPU output on the sample (d_out/d_res hold the last launch with these flags)
-    gpu_out = wl["d_out"][: n * n_kp].cpu().numpy().view(pkg.DMATCH_DTYPE).reshape(-1)
-    gpu_res = wl["d_res"][:n].cpu().numpy().view(pkg.RESULT_DTYPE).reshape(-1)
+    return gms_oracle
 
-    def run(sel, nthreads, reps):
-        best = None
-        for _ in range(reps):
+
+def check_parity(wl, pkg, chunk_ids, rot, scale, sample=None):
+    """Every 997th global pair among the given chunks (or `sample` = {chunk: [local indices]}) against the CPU oracle, from
+    what the last launch on those chunks left in d_out / d_res. Returns (pairs checked, pairs that differ)."""
+    oracle = oracle_module()
+    kp_all = np.concatenate(wl.frames)
+    foff = wl.table.frame_off_host
+    wh = np.array([SIZE] * len(wl.frames), dtype=np.int32).reshape(-1)
+    checked = bad = 0
+    for c in chunk_ids:
+        idx = sample[c] if sample is not None else [j for _, j in wl.plan.chunk_sample(c)]
+        if not idx:
+            continue
+        sel, m, gpu_out, gpu_res = wl.host_pairs(pkg, c, idx)
+        failed, out, res, _ = oracle.batch(kp_all, foff, wh, sel, m, rot, scale, 6.0, 1)
+        for i in range(len(idx)):
+            k, o = int(res["n_inliers"][i]), int(sel["match_off"][i])
+            same = (failed == 0 and gpu_res["status"][i] == 0 and res[i].tobytes() == gpu_res[i].tobytes() and
+                    out[o:o + k].tobytes() == gpu_out[o:o + k].tobytes())
+            checked += 1
+            bad += 0 if same else 1
+    return checked, bad
+
+
+def cpu_baseline(args, wl, pkg, rot, scale, budget_s):
+    """The oracle (CPU restatement of the reference's matchGMS, one pair per thread) on the first pairs of chunk 0, at 1, 16 and
+    all threads; median of --cpu-reps repetitions each, sample sizes chosen for about `budget_s` seconds of CPU work in all."""
+    oracle = oracle_module()
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    all_threads = args.cpu_threads if args.cpu_threads > 0 else avail
+    kp_all = np.concatenate(wl.frames)
+    foff = wl.table.frame_off_host
+    wh = np.array([SIZE] * len(wl.frames), dtype=np.int32).reshape(-1)
+    reps = max(1, args.cpu_reps)
+
+    def run(n, threads):
+        n = max(1, min(n, wl.n_pairs))
+        sel, m, _, _ = wl.host_pairs(pkg, 0, list(range(n)))
+        times = []
+        for _ in range(reps + 1):  # one warm-up
             t0 = time.perf_counter()
-            failed, out, res, _ = gms_oracle.batch(kp_all, foff, wh, sel, matches, rot, scale, 6.0, nthreads)
-            dt = time.perf_counter() - t0
+            failed, _, _, _ = oracle.batch(kp_all, foff, wh, sel, m, rot, scale, 6.0, threads)
+            times.append(time.perf_counter() - t0)
             assert failed == 0
-            best = dt if best is None else min(best, dt)
-        return len(sel) / best, out, res
+        return n / float(np.median(times[1:])), n
 
-    rate1, _, _ = run(pairs[: max(8, n // 8)], 1, 2)
-    rate_mt, out, res = run(pairs, threads, 3)
-    ok = bool(np.array_equal(res["n_inliers"], gpu_res["n_inliers"]) and
-              np.array_equal(res["best_scale"], gpu_res["best_scale"]) and
-              np.array_equal(res["best_rot"], gpu_res["best_rot"]))
-    if ok:
-        for i in range(n):
-            k = int(res["n_inliers"][i])
-            o = int(pairs["match_off"][i])
-            if out[o:o + k].tobytes() != gpu_out[o:o + k].tobytes():
-                ok = False
-                break
-    return rate_mt, rate1, ok, n
+    # size the samples from a quick single-thread probe: each of the three legs gets a third of the budget
+    r_probe, n_probe = run(8, 1)
+    per_leg = budget_s / 3.0 / (reps + 1)
+    legs = {}
+    for threads in sorted({1, min(16, all_threads), all_threads}):
+        n = int(min(wl.n_pairs, max(threads, r_probe * per_leg * min(threads, 64) ** 0.9)))
+        rate, n_used = run(n, threads)
+        legs[threads] = {"pairs_per_s": rate, "pairs": n_used}
+    best = max(legs, key=lambda t: legs[t]["pairs_per_s"])
+    return {"value": legs[best]["pairs_per_s"], "unit": "pairs/s", "cores": best, "kind": "port",
+            "sample": f"first {legs[best]['pairs']} pairs of the rank's first chunk, oracle/gms_ref.c, one pair per thread, "
+                      f"median of {reps}",
+            "by_threads": {str(t): legs[t] for t in legs}, "cpus_available": avail, "host_cpus": os.cpu_count()}
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = None
-    # GMS_BENCH_ONE_DEVICE=1 is a rehearsal mode for a one-GPU box: every rank uses cuda:0 and the rendezvous
-    # runs over gloo (RCCL refuses two ranks on one device). The driver's multi-GPU runs do not set it.
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s)")
+
+    import torch
+    pkg = importlib.import_module(PKG)
+    distmod = importlib.import_module(PKG + ".dist")
+    # GMS_BENCH_ONE_DEVICE=1 is a rehearsal mode for a one-GPU box: every rank uses cuda:0. The driver never sets it.
     one_device = os.environ.get("GMS_BENCH_ONE_DEVICE", "0") == "1"
     dev_index = 0 if one_device else local_rank
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(dev_index)
-        if one_device:
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+    dist = distmod.init_rendezvous(world)  # gloo; None for one rank
     dev = torch.device("cuda", dev_index)
     torch.cuda.set_device(dev)
 
-    pkg = importlib.import_module(PKG)
-    synth = importlib.import_module(PKG + ".synth")
     ctx = pkg.GmsContext(dev_index)  # raises if the HIP extension is missing: no fallback
     stream = torch.cuda.Stream(device=dev)
     ctx.set_stream(stream.cuda_stream)
-
-    wl = build_workload(args, rank, world, dev, pkg, synth, ctx)
-    torch.cuda.synchronize()
+    wl = Workload(args, rank, world, dev, pkg, ctx)
+    n_res = len(wl.chunks)
 
     wall, kern_ms = timed_steps(ctx, wl, stream, args.steps, args.warmup, False, False, dist)
-    # whole-job aggregate: every rank ran the same number of pairs; time = max over ranks
-    t = torch.tensor([wall], dtype=torch.float64, device="cpu" if one_device else dev)
-    if dist is not None:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    wall_max = float(t.item())
-    pairs_total = args.pairs * world * args.steps
-    value = pairs_total / wall_max
+    wall_max = distmod.max_over_ranks(wall, dist)  # whole-job time = the slowest rank
+    value = wl.n_pairs * world * args.steps / wall_max
 
+    # ---- parity on every rank: the sampled pairs of every resident chunk, as the timed launches left them
+    checked, bad = check_parity(wl, pkg, range(n_res), False, False)
+    checked_all, bad_all = distmod.sum_over_ranks([checked, bad], dist)
+
+    ok = bad_all == 0
     if rank == 0:
-        n_kp = wl["n_kp"]
-        res = wl["d_res"].cpu().numpy().view(pkg.RESULT_DTYPE).reshape(-1)
-        assert (res["status"] == 0).all()
-        kept = int(res["n_inliers"].astype(np.int64).sum())
+        n_kp = wl.n_kp
+        kept = 0
+        for ch in wl.chunks:
+            res = ch["d_res"].cpu().numpy().view(pkg.RESULT_DTYPE).reshape(-1)
+            assert (res["status"] == 0).all()
+            kept += int(res["n_inliers"].astype(np.int64).sum())
+        kept_per_launch = kept / n_res
         # algorithmic bytes per launch: 32*M + 16*K per pair (SURVEY.md 8d)
-        alg_bytes = 32.0 * n_kp * wl["n_pairs"] + 16.0 * kept
+        alg_bytes = 32.0 * n_kp * wl.n_pairs + 16.0 * kept_per_launch
         achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
-            try:
-                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
         line = {
             "metric": "gms_filtered_image_pairs_per_sec", "value": value, "unit": "pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": wall_max / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "i32", "data": "synthetic",
-            "config": {"workload": "config3 1080p sequence: 10k keypoints/frame, M=10k putative matches/pair, "
-                                   "matchGMS(withRotation=false, withScale=false, thresholdFactor=6.0)",
-                       "image_size": [1920, 1080], "features": n_kp, "pairs_per_step_per_gpu": args.pairs,
-                       "frames_per_gpu": args.frames, "inlier_frac": args.inlier_frac,
-                       "mean_kept_per_pair": kept / wl["n_pairs"], "sharding": f"pairs x{world}, no collective"},
+            "config": {"workload": "config3: one 1080p sequence, all N(N-1)/2 pairs in lexicographic order, 10k keypoints/frame, "
+                                   "M=10k putative matches/pair, matchGMS(withRotation=false, withScale=false, thresholdFactor=6.0)",
+                       "image_size": list(SIZE), "frames": args.frames, "features": n_kp,
+                       "frame_table_bytes": 8 * n_kp * args.frames, "total_pairs": wl.plan.total_pairs,
+                       "pairs_per_step_per_gpu": wl.n_pairs, "resident_chunks_per_gpu": n_res,
+                       "inlier_frac": args.inlier_frac, "mean_kept_per_pair": kept_per_launch / wl.n_pairs,
+                       "sharding": f"contiguous blocks of the pair list x{world}, no collective; rendezvous over gloo"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "kernel": "gms::filter_kernel_dense<10, false, 1024>",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "kernel": "gms::filter_kernel_dense<10, false, 1024>",
                          "kernel_ms_per_launch": kern_ms, "algorithmic_bytes_per_launch": alg_bytes},
+            "parity": {"pairs_checked": checked_all, "mismatches": bad_all, "bit_exact": ok,
+                       "rule": f"every {distmod.PARITY_EVERY}th global pair of every resident chunk, on every rank, vs oracle/gms_ref.c"},
         }
-        run_cpu = not args.no_cpu and world == 1  # the CPU baseline is timed on rank 0 of the 1-GPU run only
-        if run_cpu:
-            rate_mt, rate1, ok, n = cpu_leg(args, wl, pkg, False, False, args.cpu_pairs, args.cpu_threads)
-            line["cpu_baseline"] = {"value": rate_mt, "unit": "pairs/s", "cores": args.cpu_threads, "kind": "port",
-                                    "sample": f"first {n} pairs of the step's batch, oracle/gms_ref.c, one pair "
-                                              f"per thread, best of 3", "value_1thread": rate1,
-                                    "host_cpus": os.cpu_count()}
-            line["parity"] = {"pairs_checked": n, "bit_exact": ok}
-            line["gpu_vs_cpu"] = value / rate_mt
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):  # measured in a separate rocprofv3 --pmc run (tools/pmc_collect.sh), not in this one
+            try:
+                line["roofline"]["traffic_from_profiles"] = json.load(open(tpath))
+            except Exception:
+                pass
+        if not args.no_cpu and world == 1:
+            line["cpu_baseline"] = cpu_baseline(args, wl, pkg, False, False, budget_s=12.0)
+            line["gpu_vs_cpu"] = value / line["cpu_baseline"]["value"]
         if not args.no_extra and world == 1:
-            sub = dict(wl)
-            n_sub = min(wl["n_pairs"], 512)
-            sub["n_pairs"] = n_sub
-            w2, k2 = timed_steps(ctx, sub, stream, 8, 2, True, True, None)
-            extra = {"workload": "same pairs, matchGMS(withRotation=true, withScale=true, 6.0) "
+            # the reference's SfM call-site flags on the head of the same chunks
+            n_sub = min(wl.n_pairs, 512)
+            w2, k2 = timed_steps(ctx, wl, stream, 8, 2, True, True, None, n_pairs=n_sub)
+            used = sorted({(2 + s) % n_res for s in range(8)})
+            c2, b2 = check_parity(wl, pkg, used, True, True, sample={c: list(range(0, n_sub, 97)) for c in used})
+            kept2 = np.mean([int(wl.chunks[c]["d_res"][:n_sub, 0].sum().item()) for c in used])
+            alg2 = 32.0 * n_kp * n_sub + 16.0 * kept2
+            extra = {"workload": "head of the same chunks, matchGMS(withRotation=true, withScale=true, 6.0) "
                                  "(FeatureMatchUtil.cpp:69 flags), 8 rot x 5 scale x 4 grids",
-                     "pairs_per_step": n_sub, "value": n_sub * 8 / w2, "unit": "pairs/s", "kernel_ms_per_launch": k2}
-            if run_cpu:
-                rate_mt2, rate12, ok2, n2 = cpu_leg(args, sub, pkg, True, True, min(32, args.cpu_pairs),
-                                                    args.cpu_threads)
-                extra["cpu_baseline"] = {"value": rate_mt2, "cores": args.cpu_threads, "value_1thread": rate12,
-                                         "sample": f"first {n2} pairs"}
-                extra["parity"] = {"pairs_checked": n2, "bit_exact": ok2}
+                     "pairs_per_step": n_sub, "value": n_sub * 8 / w2, "unit": "pairs/s", "ms_per_step": k2,
+                     "roofline": {"bound": "hbm", "achieved": alg2 / (k2 * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                  "frac": alg2 / (k2 * 1e-3) / 1e9 / HBM_PEAK_GBPS, "traffic": None,
+                                  "kernel": "all kernels of the launch (HIP events around gms_filter_device)",
+                                  "kernel_ms_per_launch": k2, "algorithmic_bytes_per_launch": alg2},
+                     "parity": {"pairs_checked": c2, "mismatches": b2, "bit_exact": b2 == 0}}
+            ok = ok and b2 == 0
+            if not args.no_cpu:
+                extra["cpu_baseline"] = cpu_baseline(args, wl, pkg, True, True, budget_s=12.0)
+                extra["gpu_vs_cpu"] = extra["value"] / extra["cpu_baseline"]["value"]
             line["rot_scale"] = extra
         print(json.dumps(line))
-    elif not args.no_extra:
-        pass
+        sys.stdout.flush()
+    distmod.barrier(dist)
     if dist is not None:
-        dist.barrier()
         dist.destroy_process_group()
     ctx.close()
+    if not ok:
+        sys.exit("bench.py: GPU output differs from the oracle on the parity sample")
 
 
 if __name__ == "__main__":

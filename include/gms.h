@@ -32,6 +32,8 @@ extern "C" {
 #define GMS_ERR_HIP       (-3) /* a HIP runtime call failed (gms_last_hip_error() has the code)  */
 #define GMS_ERR_NO_DEVICE (-4) /* no usable gfx950 device                                        */
 #define GMS_ERR_CAPACITY  (-5) /* m exceeds what this build supports (see gms_max_matches())     */
+#define GMS_ERR_NOT_RESERVED (-6) /* a workspace would have to grow while the stream is being captured: call
+                                     gms_ctx_reserve() for this shape first                          */
 
 /* ---- PODs, bit-compatible with the reference's element types ------------------------------- */
 
@@ -92,16 +94,27 @@ int gms_match_ctx(gms_ctx* ctx,
                   int with_rotation, int with_scale, double threshold_factor,
                   gms_dmatch* out, int* n_out, gms_pair_result* result);
 
-/* ---- context -------------------------------------------------------------------------------- */
+/* ---- context --------------------------------------------------------------------------------
+ * One context per (process, device). Every entry point that takes a context serialises on it (a context may be
+ * shared by host threads); work is ordered on the context's current stream. If the stream is changed while earlier
+ * launches are still running, later launches that reuse the context's internal workspaces wait for them (an event). */
 int  gms_ctx_create(int device, gms_ctx** out_ctx);
 int  gms_ctx_destroy(gms_ctx* ctx);
 /* Launch on a caller-owned hipStream_t (pass it as void*); NULL selects the context's own stream. */
 int  gms_ctx_set_stream(gms_ctx* ctx, void* hip_stream);
 int  gms_ctx_synchronize(gms_ctx* ctx);
+/* Sizes the internal workspaces for gms_filter_device calls of up to n_pairs pairs of up to max_m matches under the
+ * given flags. After it, such calls neither allocate nor synchronise -- they are pure stream-ordered launches and can
+ * be captured into a hipGraph. May allocate and synchronise itself. */
+int  gms_ctx_reserve(gms_ctx* ctx, int n_pairs, int max_m, int with_rotation, int with_scale);
 
 /* ---- device-resident batch path (throughput API) ---------------------------------------------
  * All d_* pointers are device pointers on the context's device; calls are stream-ordered on the
- * context's stream and do not synchronise.
+ * context's stream. gms_normalize_device never synchronises. gms_filter_device does not synchronise or allocate
+ * once the shape has been reserved (gms_ctx_reserve); without a reservation it grows its workspaces on first
+ * use of a larger shape (one hipStreamSynchronize + hipMalloc then), and returns GMS_ERR_NOT_RESERVED instead
+ * if that would have to happen inside a stream capture. Batches of pairs up to 16 384 matches under the
+ * default flags need no workspace at all.
  *
  * gms_normalize_device: GMSMatcher::normalizePoints (DLL@0x180048420) for every keypoint of every
  * frame: d_pts[2*i] = kp[i].x / (float)w[frame], d_pts[2*i+1] = kp[i].y / (float)h[frame]
@@ -122,6 +135,20 @@ int gms_filter_device(gms_ctx* ctx, const float* d_pts, const int64_t* d_frame_o
                       const gms_dmatch* d_matches,
                       int with_rotation, int with_scale, double threshold_factor,
                       gms_dmatch* d_out, gms_pair_result* d_results, uint8_t* d_mask);
+
+/* ---- host-pointer batch path -------------------------------------------------------------------
+ * The throughput entry for callers that hold everything in host memory (a C++ caller of the reference looping over
+ * image pairs: FeatureMatchUtil.cpp:66-69 once per pair): the frames' keypoints are uploaded and normalised once,
+ * then the pair list is cut into chunks that travel through pinned staging buffers on two streams -- chunk k+1 is
+ * uploaded while chunk k is filtered and chunk k-1 comes back. Synchronous: returns when out/results are complete.
+ *   kp/frame_off/wh   keypoints of all frames back to back, n_frames+1 offsets, (w, h) per frame
+ *   pairs/matches     as gms_filter_device, host memory; match_off indexes `matches` and `out` alike
+ *   out               pair i's survivors verbatim at out[match_off .. match_off + results[i].n_inliers)
+ * Returns GMS_OK, or the first error; pairs outside the parity domain are reported per pair in results[i].status. */
+int gms_filter_host_batch(gms_ctx* ctx, const gms_keypoint* kp, const int64_t* frame_off, const int32_t* wh,
+                          int n_frames, const gms_pair* pairs, int n_pairs, const gms_dmatch* matches,
+                          int with_rotation, int with_scale, double threshold_factor,
+                          gms_dmatch* out, gms_pair_result* results);
 
 /* ---- introspection --------------------------------------------------------------------------- */
 int         gms_max_matches(void);        /* largest m per pair this build accepts                 */

@@ -12,7 +12,7 @@ import ctypes as C
 import numpy as np
 
 from .capi import load_library
-from .types import (DMATCH_DTYPE, KEYPOINT_DTYPE, RESULT_DTYPE, GMS_OK, GmsError)
+from .types import (DMATCH_DTYPE, KEYPOINT_DTYPE, PAIR_DTYPE, RESULT_DTYPE, GMS_OK, GmsError)
 
 
 def _as(arr, dtype, name):
@@ -85,7 +85,34 @@ class GmsContext:
         kept = out[: n_out.value].copy()
         return (kept, res[0]) if return_result else kept
 
+    # -- host-pointer batch path: many pairs per call, pinned staging and two streams inside the library ------------
+    def filter_host_batch(self, keypoints_per_frame, sizes, pairs, matches, withRotation=False, withScale=False,
+                          thresholdFactor=6.0):
+        """gms_filter_host_batch: `pairs` (PAIR_DTYPE) index `matches` (DMATCH_DTYPE) by match_off. Returns
+        (out, results): pair i's survivors at out[match_off : match_off + results[i].n_inliers]."""
+        counts = np.array([len(k) for k in keypoints_per_frame], dtype=np.int64)
+        frame_off = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+        kp = (np.concatenate([_as(k, KEYPOINT_DTYPE, "keypoints") for k in keypoints_per_frame])
+              if frame_off[-1] else np.zeros(1, dtype=KEYPOINT_DTYPE))
+        wh = np.ascontiguousarray(np.asarray(sizes, dtype=np.int32).reshape(-1, 2))
+        if wh.shape[0] != len(counts):
+            raise ValueError("one (width, height) per frame")
+        pairs = _as(pairs, PAIR_DTYPE, "pairs")
+        mt = _as(matches, DMATCH_DTYPE, "matches")
+        out = np.zeros(max(len(mt), 1), dtype=DMATCH_DTYPE)
+        res = np.zeros(max(len(pairs), 1), dtype=RESULT_DTYPE)
+        rc = self._lib.gms_filter_host_batch(self._h, kp.ctypes.data, frame_off.ctypes.data, wh.ctypes.data, len(counts),
+                                             pairs.ctypes.data, len(pairs), mt.ctypes.data, int(bool(withRotation)),
+                                             int(bool(withScale)), float(thresholdFactor), out.ctypes.data, res.ctypes.data)
+        _check(rc, self._lib, "gms_filter_host_batch")
+        return out[: len(mt)], res[: len(pairs)]
+
     # -- device-resident batch path (raw device pointers; torch tensors' data_ptr() are fine) ---------
+    def reserve(self, n_pairs, max_m, withRotation=False, withScale=False):
+        """gms_ctx_reserve: after it, filter_device calls of that shape neither allocate nor synchronise."""
+        _check(self._lib.gms_ctx_reserve(self._h, int(n_pairs), int(max_m), int(bool(withRotation)), int(bool(withScale))),
+               self._lib, "gms_ctx_reserve")
+
     def normalize_device(self, d_kp, d_frame_off, d_wh, n_frames, total_kp, d_pts):
         _check(self._lib.gms_normalize_device(self._h, d_kp, d_frame_off, d_wh, int(n_frames), int(total_kp), d_pts),
                self._lib, "gms_normalize_device")

@@ -7,7 +7,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # Every symbol include/gms.h declares; tests check the built library exports all of them.
 EXPORTED_SYMBOLS = [
     "gms_match", "gms_match_ctx", "gms_ctx_create", "gms_ctx_destroy", "gms_ctx_set_stream",
-    "gms_ctx_synchronize", "gms_normalize_device", "gms_filter_device", "gms_max_matches",
+    "gms_ctx_synchronize", "gms_ctx_reserve", "gms_normalize_device", "gms_filter_device",
+    "gms_filter_host_batch", "gms_max_matches",
     "gms_last_hip_error", "gms_error_string", "gms_version", "gms_selftest_threshold",
 ]
 
@@ -43,6 +44,8 @@ def load_library():
     lib.gms_ctx_destroy.argtypes = [vp]
     lib.gms_ctx_set_stream.argtypes = [vp, vp]
     lib.gms_ctx_synchronize.argtypes = [vp]
+    lib.gms_ctx_reserve.argtypes = [vp, i32, i32, i32, i32]
+    lib.gms_filter_host_batch.argtypes = [vp, vp, vp, vp, i32, vp, i32, vp, i32, i32, dbl, vp, vp]
     lib.gms_normalize_device.argtypes = [vp, vp, vp, vp, i32, i64, vp]
     lib.gms_filter_device.argtypes = [vp, vp, vp, i32, vp, i32, i32, vp, i32, i32, dbl, vp, vp, vp]
     lib.gms_selftest_threshold.argtypes = [vp, vp, vp, vp, dbl, i32, vp]

@@ -13,6 +13,7 @@
 #include <cstring>
 #include <mutex>
 #include <new>
+#include <vector>
 
 #include "gms.h"
 #include "gms_kernels.h"
@@ -36,8 +37,39 @@ extern "C" int gms_diag_set_buffer(void* d_buf) { g_diag = (unsigned long long*)
             return GMS_ERR_HIP;               \
         }                                     \
     } while (0)
+#define GMS_TRY(call)                \
+    do {                             \
+        const int rc_ = (call);      \
+        if (rc_ != GMS_OK) return rc_; \
+    } while (0)
 
 namespace {
+
+// Diagnostic switches, read from the environment ONCE per process (never on the call path):
+//   GMS_DENSE=0          keep every pair on the hashed path
+//   GMS_BAND=0           keep large pairs on the HBM-slab kernel alone
+//   GMS_STAGGER_US=n     spread of the first dispatch round's start times at 10k matches per pair (0 = off)
+//   GMS_BAND_WS_BYTES=n  budget of the large-pair workspace (default 4 GiB); a batch is filtered in slices that fit it
+struct Knobs {
+    bool dense_on = true, band_on = true;
+    int stagger_us = -1;
+    size_t band_ws_budget = (size_t)4 << 30;
+};
+const Knobs& knobs()
+{
+    static const Knobs k = [] {
+        Knobs v;
+        if (const char* e = std::getenv("GMS_DENSE")) v.dense_on = std::atoi(e) != 0;
+        if (const char* e = std::getenv("GMS_BAND")) v.band_on = std::atoi(e) != 0;
+        if (const char* e = std::getenv("GMS_STAGGER_US")) v.stagger_us = std::atoi(e);
+        if (const char* e = std::getenv("GMS_BAND_WS_BYTES")) {
+            const long long b = std::atoll(e);
+            if (b > 0) v.band_ws_budget = (size_t)b;
+        }
+        return v;
+    }();
+    return k;
+}
 
 // mScaleRatios (DLL .data 0x1802c5008) and setScale's cvRound (DLL@0x180048c10, cvtsd2si = lrint).
 void right_grids(int rw[5], int rh[5])
@@ -71,20 +103,216 @@ struct DevBuf {
     }
 };
 
+// page-locked host memory: what the copy engines read and write without a bounce through the runtime's own staging
+struct PinBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    hipError_t reserve(size_t bytes)
+    {
+        if (bytes <= cap) return hipSuccess;
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+        size_t want = bytes < 65536 ? 65536 : bytes + bytes / 4;
+        hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release()
+    {
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+// What one gms_filter_device call needs beyond its arguments.
+struct WsNeed {
+    size_t partial = 0, big = 0, band = 0;
+    size_t slice = 0, per_pair = 0;  // large pairs: pairs per slice of the batch, workspace bytes per pair
+    int kpt = 0, mcap = 0;
+};
+
 }  // namespace
+
+// One lane of the host-pointer paths: pinned staging in both directions, the device arenas they mirror, a stream.
+struct Lane {
+    hipStream_t stream = nullptr;
+    PinBuf hin, hout;
+    DevBuf din, dout;
+};
 
 struct gms_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
-    std::mutex mu;  // serialises the one-shot path's scratch buffers
-    DevBuf kp, foff, wh, pts, pair, matches, out, result, aux, big_ws, band_ws, partial_ws;
+    std::mutex mu;  // every entry point that touches the context's buffers holds it
+    DevBuf aux, big_ws, band_ws, partial_ws;
+    // the workspaces above are shared by every launch of the context: the last launch that used them, and where
+    hipEvent_t ws_event = nullptr;
+    hipStream_t ws_stream = nullptr;
+    bool ws_pending = false;
+    Lane lane[2];     // one-shot calls use lane 0 (on the context's stream); gms_filter_host_batch alternates
+    DevBuf tab_kp, tab_pts, tab_small;  // gms_filter_host_batch: the call's frame table
     int n_cus = 256;  // multiProcessorCount of the device
 };
 
+namespace {
+
+int plan_workspace(const gms_ctx* c, int n_pairs, int max_m, bool rot, bool scale, bool need_mask_ws, WsNeed* w)
+{
+    *w = WsNeed();
+    w->kpt = gms::filter_pick_kpt(max_m);  // 0: too large for the register + LDS kernel
+    if (w->kpt) {
+        if (scale && knobs().dense_on) w->partial = (size_t)n_pairs * gms::kPartialStrideDw * 4;
+        return GMS_OK;
+    }
+    if (max_m > gms::kBigMaxMatches) return GMS_ERR_CAPACITY;
+    w->mcap = gms::big_mcap(max_m);
+    const int n_wg = n_pairs < c->n_cus ? n_pairs : c->n_cus;  // one persistent workgroup per CU at most
+    w->big = (size_t)n_wg * gms::big_ws_stride_dwords(w->mcap) * 4;
+    if (knobs().band_on) {
+        gms::FilterParams p{};
+        p.with_rotation = rot;
+        p.with_scale = scale;
+        right_grids(p.right_w, p.right_h);
+        w->per_pair = (!rot && !scale) ? gms::band_ws_bytes_per_pair(w->mcap, need_mask_ws)
+                                       : gms::tile_ws_bytes_per_pair(p, w->mcap, need_mask_ws);
+        size_t slice = knobs().band_ws_budget / w->per_pair;
+        if (slice < 1) slice = 1;
+        if (slice > (size_t)n_pairs) slice = (size_t)n_pairs;
+        w->slice = slice;
+        w->band = slice * w->per_pair;
+    }
+    return GMS_OK;
+}
+
+// Grows the context's workspaces to `w`. Growing frees the old block, so everything that may still use it is waited for first;
+// inside a stream capture that is impossible (and so is the allocation): GMS_ERR_NOT_RESERVED.
+int grow_workspace(gms_ctx* c, const WsNeed& w, hipStream_t st)
+{
+    if (w.partial <= c->partial_ws.cap && w.big <= c->big_ws.cap && w.band <= c->band_ws.cap) return GMS_OK;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) return GMS_ERR_NOT_RESERVED;
+    GMS_HIP(hipStreamSynchronize(st));
+    if (c->ws_pending) {
+        GMS_HIP(hipEventSynchronize(c->ws_event));
+        c->ws_pending = false;
+    }
+    GMS_HIP(c->partial_ws.reserve(w.partial));
+    GMS_HIP(c->big_ws.reserve(w.big));
+    GMS_HIP(c->band_ws.reserve(w.band));
+    return GMS_OK;
+}
+
+// The filter launches of one call on stream `st`. The caller holds c->mu and has selected the device.
+int filter_launch(gms_ctx* c, hipStream_t st, const float* d_pts, const int64_t* d_frame_off, int n_frames,
+                  const gms_pair* d_pairs, int n_pairs, int max_m, const gms_dmatch* d_matches,
+                  int with_rotation, int with_scale, double threshold_factor,
+                  gms_dmatch* d_out, gms_pair_result* d_results, uint8_t* d_mask)
+{
+    if (n_pairs < 0 || max_m < 0 || n_frames < 0) return GMS_ERR_BAD_ARG;
+    if (n_pairs == 0) return GMS_OK;
+    if (!d_frame_off || !d_pairs || !d_results) return GMS_ERR_BAD_ARG;
+    if (max_m > 0 && (!d_matches || !d_out || !d_pts)) return GMS_ERR_BAD_ARG;
+    WsNeed w;
+    GMS_TRY(plan_workspace(c, n_pairs, max_m, with_rotation != 0, with_scale != 0, d_mask == nullptr, &w));
+    GMS_TRY(grow_workspace(c, w, st));
+    const bool uses_ws = w.partial || w.big || w.band;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    const bool capturing = hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone;
+    if (uses_ws && !capturing && c->ws_pending && c->ws_stream != st) GMS_HIP(hipStreamWaitEvent(st, c->ws_event, 0));
+
+    gms::FilterParams p{};
+    const int kpt = w.kpt;
+    p.table_slots = kpt ? gms::filter_table_slots(kpt) : 0;
+    p.region_shift = kpt ? gms::filter_region_shift(kpt) : 0;
+    p.pts = reinterpret_cast<const float2*>(d_pts);
+    p.frame_off = d_frame_off;
+    p.n_frames = n_frames;
+    p.pairs = d_pairs;
+    p.n_pairs = n_pairs;
+    p.stagger_blocks = c->n_cus;
+    p.matches = d_matches;
+    p.out = d_out;
+    p.results = d_results;
+    p.mask = d_mask;
+    p.with_rotation = with_rotation ? 1 : 0;
+    p.with_scale = with_scale ? 1 : 0;
+    p.threshold_factor = threshold_factor;
+    p.pair_flags = nullptr;
+    p.partial = nullptr;
+    right_grids(p.right_w, p.right_h);
+    // the byte-matrix path is tried first whenever there are no scale hypotheses (the reference's default flags,
+    // DisparityUtil.cpp:149,299)
+    p.dense = (knobs().dense_on && !with_scale) ? 1 : 0;
+    // First-round stagger: the spread is about one pair's duration on the path the launch will mostly take -- 26 us (byte
+    // matrix) / 72 us (hashed) at 10k matches, in proportion to max_m -- in ticks of the 100 MHz wall clock. Only launches of
+    // at least four dispatch rounds are staggered.
+    p.stagger_ticks = 0;
+    if (n_pairs >= 4 * p.stagger_blocks && kpt) {
+        const double us10k = knobs().stagger_us >= 0 ? (double)knobs().stagger_us : (p.dense ? 26.0 : 72.0);
+        p.stagger_ticks = (int)(us10k * 100.0 * std::max(max_m, 1024) / 10000.0);
+    }
+#ifdef GMS_PHASE_TIMING
+    p.diag = g_diag;
+#endif
+    if (kpt && with_scale && knobs().dense_on) {
+        // scale hypotheses: scales 0..3 on the byte matrix, the last on the hashed path (two launches, one record per pair)
+        p.partial = (uint32_t*)c->partial_ws.p;
+        GMS_HIP(gms::launch_filter_scales(p, kpt, n_pairs, st));
+    } else if (kpt) {
+        GMS_HIP(gms::launch_filter(p, kpt, n_pairs, st));
+    } else if (knobs().band_on) {
+        // Large pairs on the LDS kernels, a slice of the batch at a time so that the per-pair workspace (lists, histogram,
+        // masks) stays bounded: three bands of rows for the default flags, tiles of left cells with three launches per
+        // scale hypothesis otherwise. Pairs they flag (a cell above 65 535 matches) fall through to the HBM-slab kernel (a
+        // fixed crew of persistent workgroups), which looks at flagged pairs only.
+        const bool plain = !with_rotation && !with_scale;
+        for (int s0 = 0; s0 < n_pairs; s0 += (int)w.slice) {
+            gms::FilterParams ps = p;
+            ps.pairs = d_pairs + s0;
+            ps.results = d_results + s0;
+            ps.n_pairs = (n_pairs - s0 < (int)w.slice) ? n_pairs - s0 : (int)w.slice;
+            const uint32_t* flags = nullptr;
+            if (plain) GMS_HIP(gms::launch_filter_band(ps, w.mcap, c->band_ws.p, &flags, st));
+            else GMS_HIP(gms::launch_filter_tiles(ps, w.mcap, c->band_ws.p, &flags, st));
+            ps.pair_flags = flags;
+            const int wg = ps.n_pairs < c->n_cus ? ps.n_pairs : c->n_cus;
+            GMS_HIP(gms::launch_filter_big(ps, w.mcap, wg, (uint32_t*)c->big_ws.p, st));
+        }
+    } else {
+        const int n_wg = n_pairs < c->n_cus ? n_pairs : c->n_cus;
+        GMS_HIP(gms::launch_filter_big(p, w.mcap, n_wg, (uint32_t*)c->big_ws.p, st));
+    }
+    if (uses_ws && !capturing) {
+        GMS_HIP(hipEventRecord(c->ws_event, st));
+        c->ws_stream = st;
+        c->ws_pending = true;
+    }
+    return GMS_OK;
+}
+
+// ---- the host-pointer paths --------------------------------------------------------------------------------------------
+// Staging block of a chunk, host (pinned) and device alike:  [ pairs (24 B each, 16-aligned) | matches (16 B each) ]
+// and coming back:                                            [ results (16 B each) | out (16 B each) ]
+size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
+
+// (pt.x, pt.y) of n keypoints, 8 bytes each: all the filter reads of a cv::KeyPoint (DLL@0x1800485d4) and all that has to
+// cross PCIe. Pure data movement; the divide by the image size happens on the GPU (normalize_kernel).
+void pack_xy(const gms_keypoint* kp, size_t n, float* dst)
+{
+    for (size_t i = 0; i < n; ++i) {
+        dst[2 * i] = kp[i].x;
+        dst[2 * i + 1] = kp[i].y;
+    }
+}
+
+}  // namespace
+
 extern "C" {
 
-const char* gms_version(void) { return "mi355-gms 0.1 (gfx950)"; }
+const char* gms_version(void) { return "mi355-gms 0.2 (gfx950)"; }
 
 int gms_last_hip_error(void) { return t_last_hip; }
 
@@ -97,6 +325,7 @@ const char* gms_error_string(int code)
     case GMS_ERR_HIP: return "HIP runtime error";
     case GMS_ERR_NO_DEVICE: return "no usable HIP device";
     case GMS_ERR_CAPACITY: return "too many matches per pair for this build";
+    case GMS_ERR_NOT_RESERVED: return "workspace not reserved for this shape (stream capture in progress)";
     default: return "unknown error";
     }
 }
@@ -119,8 +348,16 @@ int gms_ctx_create(int device, gms_ctx** out_ctx)
     if (!c) return GMS_ERR_BAD_ARG;
     c->device = device;
     e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->lane[1].stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ws_event, hipEventDisableTiming);
+    if (e == hipSuccess) e = gms::init_filter_kernels();
+    if (e == hipSuccess) e = gms::init_band_kernels();
+    if (e == hipSuccess) e = gms::init_big_kernels();
     if (e != hipSuccess) {
         t_last_hip = (int)e;
+        if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+        if (c->lane[1].stream) (void)hipStreamDestroy(c->lane[1].stream);
+        if (c->ws_event) (void)hipEventDestroy(c->ws_event);
         delete c;
         return GMS_ERR_HIP;
     }
@@ -134,11 +371,25 @@ int gms_ctx_create(int device, gms_ctx** out_ctx)
 int gms_ctx_destroy(gms_ctx* c)
 {
     if (!c) return GMS_OK;
-    (void)hipSetDevice(c->device);
-    (void)hipStreamSynchronize(c->stream);
-    DevBuf* bufs[] = {&c->kp, &c->foff, &c->wh, &c->pts, &c->pair, &c->matches, &c->out, &c->result, &c->aux, &c->big_ws, &c->band_ws, &c->partial_ws};
-    for (DevBuf* b : bufs) b->release();
-    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    {
+        std::lock_guard<std::mutex> lock(c->mu);
+        (void)hipSetDevice(c->device);
+        (void)hipStreamSynchronize(c->stream);
+        (void)hipStreamSynchronize(c->own_stream);
+        (void)hipStreamSynchronize(c->lane[1].stream);
+        if (c->ws_pending) (void)hipEventSynchronize(c->ws_event);
+        DevBuf* bufs[] = {&c->aux, &c->big_ws, &c->band_ws, &c->partial_ws, &c->tab_kp, &c->tab_pts, &c->tab_small};
+        for (DevBuf* b : bufs) b->release();
+        for (Lane& l : c->lane) {
+            l.hin.release();
+            l.hout.release();
+            l.din.release();
+            l.dout.release();
+        }
+        (void)hipStreamDestroy(c->lane[1].stream);
+        (void)hipStreamDestroy(c->own_stream);
+        (void)hipEventDestroy(c->ws_event);
+    }
     delete c;
     return GMS_OK;
 }
@@ -146,6 +397,7 @@ int gms_ctx_destroy(gms_ctx* c)
 int gms_ctx_set_stream(gms_ctx* c, void* hip_stream)
 {
     if (!c) return GMS_ERR_BAD_ARG;
+    std::lock_guard<std::mutex> lock(c->mu);
     c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
     return GMS_OK;
 }
@@ -153,9 +405,23 @@ int gms_ctx_set_stream(gms_ctx* c, void* hip_stream)
 int gms_ctx_synchronize(gms_ctx* c)
 {
     if (!c) return GMS_ERR_BAD_ARG;
+    std::lock_guard<std::mutex> lock(c->mu);
     GMS_HIP(hipSetDevice(c->device));
     GMS_HIP(hipStreamSynchronize(c->stream));
     return GMS_OK;
+}
+
+int gms_ctx_reserve(gms_ctx* c, int n_pairs, int max_m, int with_rotation, int with_scale)
+{
+    if (!c || n_pairs < 0 || max_m < 0) return GMS_ERR_BAD_ARG;
+    std::lock_guard<std::mutex> lock(c->mu);
+    GMS_HIP(hipSetDevice(c->device));
+    WsNeed w, w2;
+    // with and without a caller-provided mask array: the larger of the two
+    GMS_TRY(plan_workspace(c, n_pairs, max_m, with_rotation != 0, with_scale != 0, true, &w));
+    GMS_TRY(plan_workspace(c, n_pairs, max_m, with_rotation != 0, with_scale != 0, false, &w2));
+    w.band = std::max(w.band, w2.band);
+    return grow_workspace(c, w, c->stream);
 }
 
 int gms_normalize_device(gms_ctx* c, const gms_keypoint* d_kp, const int64_t* d_frame_off,
@@ -164,8 +430,9 @@ int gms_normalize_device(gms_ctx* c, const gms_keypoint* d_kp, const int64_t* d_
     if (!c || n_frames < 0 || total_kp < 0) return GMS_ERR_BAD_ARG;
     if (total_kp == 0 || n_frames == 0) return GMS_OK;
     if (!d_kp || !d_frame_off || !d_wh || !d_pts) return GMS_ERR_BAD_ARG;
+    std::lock_guard<std::mutex> lock(c->mu);
     GMS_HIP(hipSetDevice(c->device));
-    GMS_HIP(gms::launch_normalize(d_kp, d_frame_off, d_wh, n_frames, total_kp, d_pts, c->stream));
+    GMS_HIP(gms::launch_normalize(d_kp, (int)sizeof(gms_keypoint), d_frame_off, d_wh, n_frames, total_kp, d_pts, c->stream));
     return GMS_OK;
 }
 
@@ -174,130 +441,11 @@ int gms_filter_device(gms_ctx* c, const float* d_pts, const int64_t* d_frame_off
                       int with_rotation, int with_scale, double threshold_factor,
                       gms_dmatch* d_out, gms_pair_result* d_results, uint8_t* d_mask)
 {
-    if (!c || n_pairs < 0 || max_m < 0 || n_frames < 0) return GMS_ERR_BAD_ARG;
-    if (n_pairs == 0) return GMS_OK;
-    if (!d_frame_off || !d_pairs || !d_results) return GMS_ERR_BAD_ARG;
-    if (max_m > 0 && (!d_matches || !d_out || !d_pts)) return GMS_ERR_BAD_ARG;
-    gms::FilterParams p;
-    const int kpt = gms::filter_pick_kpt(max_m);  // 0: too large for the register + LDS kernel
-    if (!kpt && max_m > gms::kBigMaxMatches) return GMS_ERR_CAPACITY;
-    p.table_slots = kpt ? gms::filter_table_slots(kpt) : 0;
-    p.region_shift = kpt ? gms::filter_region_shift(kpt) : 0;
-    if (const char* e = std::getenv("GMS_REGION_SHIFT")) p.region_shift = std::max(p.region_shift, std::atoi(e));  // tuning knob
-    p.pts = reinterpret_cast<const float2*>(d_pts);
-    p.frame_off = d_frame_off;
-    p.n_frames = n_frames;
-    p.pairs = d_pairs;
-    p.n_pairs = n_pairs;
-    // experimental, off by default (measured slower at 10k matches/pair): GMS_PREFETCH_STRIDE=256 touches the
-    // match array of the pair one dispatch round ahead
-    static const int prefetch_stride = [] {
-        const char* e = std::getenv("GMS_PREFETCH_STRIDE");
-        return e ? std::atoi(e) : 0;
-    }();
-    p.prefetch_stride = prefetch_stride;
-    // GMS_STAGGER_US: spread of the first dispatch round's start times (0 turns it off); by default about one
-    // pair's duration at the benchmark shape on the path the launch will mostly take
-    static const int stagger_us = [] {
-        const char* e = std::getenv("GMS_STAGGER_US");
-        return e ? std::atoi(e) : -1;
-    }();
-    p.stagger_blocks = 256;
-    static const int stagger_mode = [] {
-        const char* e = std::getenv("GMS_STAGGER_MODE");
-        return e ? std::atoi(e) : 0;
-    }();
-    p.stagger_mode = stagger_mode;
-    p.matches = d_matches;
-    p.out = d_out;
-    p.results = d_results;
-    p.mask = d_mask;
-    p.with_rotation = with_rotation ? 1 : 0;
-    p.with_scale = with_scale ? 1 : 0;
-    p.threshold_factor = threshold_factor;
-    p.pair_flags = nullptr;
-    p.partial = nullptr;
-    right_grids(p.right_w, p.right_h);
-    // GMS_DENSE=0 keeps every pair on the hashed path (diagnostics); by default the byte-matrix path is tried first
-    // whenever there are no scale hypotheses (the reference's default flags, DisparityUtil.cpp:149,299)
-    static const bool dense_on = [] {
-        const char* e = std::getenv("GMS_DENSE");
-        return !e || std::atoi(e) != 0;
-    }();
-    p.dense = (dense_on && !with_scale) ? 1 : 0;
-    p.stagger_cycles = (n_pairs >= 4 * p.stagger_blocks) ? (stagger_us >= 0 ? stagger_us : (p.dense ? 26 : 72)) * 2400 : 0;
-#ifdef GMS_PHASE_TIMING
-    p.diag = g_diag;
-#endif
+    if (!c) return GMS_ERR_BAD_ARG;
+    std::lock_guard<std::mutex> lock(c->mu);
     GMS_HIP(hipSetDevice(c->device));
-    static const bool use_occ2 = [] {  // GMS_OCC2=1: the two-workgroups-per-CU kernel for pairs it can hold
-        const char* e = std::getenv("GMS_OCC2");
-        return e && std::atoi(e) != 0;
-    }();
-    const int kpt2 = use_occ2 ? gms::occ2_pick_kpt(max_m) : 0;
-    if (kpt2) {
-        p.table_slots = gms::occ2_table_slots(kpt2);
-        GMS_HIP(gms::launch_filter_occ2(p, kpt2, n_pairs, c->stream));
-    } else if (kpt && with_scale && dense_on) {
-        // scale hypotheses: scales 0..2 on the byte matrix, the rest on the hashed path (two launches, one record per pair)
-        const size_t need = (size_t)n_pairs * gms::kPartialStrideDw * 4;
-        if (need > c->partial_ws.cap) {
-            GMS_HIP(hipStreamSynchronize(c->stream));
-            GMS_HIP(c->partial_ws.reserve(need));
-        }
-        p.partial = (uint32_t*)c->partial_ws.p;
-        GMS_HIP(gms::launch_filter_scales(p, kpt, n_pairs, c->stream));
-    } else if (kpt) {
-        GMS_HIP(gms::launch_filter(p, kpt, n_pairs, c->stream));
-    } else {
-        // Large pairs: a fixed crew of persistent workgroups, each with an HBM slab for the pair's code words
-        // and table. The slab is (re)allocated here when it has to grow -- this branch is not stream-capturable.
-        const int mcap = gms::big_mcap(max_m);
-        const int n_wg = n_pairs < c->n_cus ? n_pairs : c->n_cus;  // one persistent workgroup per CU at most
-        const size_t need = (size_t)n_wg * gms::big_ws_stride_dwords(mcap) * 4;
-        if (need > c->big_ws.cap) {
-            GMS_HIP(hipStreamSynchronize(c->stream));
-            GMS_HIP(c->big_ws.reserve(need));
-        }
-        p.stagger_cycles = 0;
-        // GMS_BAND=0 keeps large pairs on the HBM-slab kernel alone (diagnostics)
-        static const bool band_on = [] {
-            const char* e = std::getenv("GMS_BAND");
-            return !e || std::atoi(e) != 0;
-        }();
-        if (band_on) {
-            // The LDS kernels for large pairs, a slice of the batch at a time so that the per-pair workspace (lists, histogram,
-            // masks) stays bounded: three bands of rows for the default flags, tiles of left cells with three launches per
-            // scale hypothesis otherwise. Pairs they flag (a cell above 65 535 matches) fall through to the HBM-slab kernel,
-            // which looks at flagged pairs only.
-            const bool plain = !with_rotation && !with_scale;
-            const size_t per_pair = plain ? gms::band_ws_bytes_per_pair(mcap, d_mask == nullptr)
-                                          : gms::tile_ws_bytes_per_pair(p, mcap, d_mask == nullptr);
-            const size_t budget = (size_t)4 << 30;
-            size_t slice = budget / per_pair;
-            if (slice < 1) slice = 1;
-            if (slice > (size_t)n_pairs) slice = (size_t)n_pairs;
-            if (slice * per_pair > c->band_ws.cap) {
-                GMS_HIP(hipStreamSynchronize(c->stream));
-                GMS_HIP(c->band_ws.reserve(slice * per_pair));
-            }
-            for (int s0 = 0; s0 < n_pairs; s0 += (int)slice) {
-                gms::FilterParams ps = p;
-                ps.pairs = d_pairs + s0;
-                ps.results = d_results + s0;
-                ps.n_pairs = (n_pairs - s0 < (int)slice) ? n_pairs - s0 : (int)slice;
-                const uint32_t* flags = nullptr;
-                if (plain) GMS_HIP(gms::launch_filter_band(ps, mcap, c->band_ws.p, &flags, c->stream));
-                else GMS_HIP(gms::launch_filter_tiles(ps, mcap, c->band_ws.p, &flags, c->stream));
-                ps.pair_flags = flags;
-                const int wg = ps.n_pairs < c->n_cus ? ps.n_pairs : c->n_cus;
-                GMS_HIP(gms::launch_filter_big(ps, mcap, wg, (uint32_t*)c->big_ws.p, c->stream));
-            }
-        } else {
-            GMS_HIP(gms::launch_filter_big(p, mcap, n_wg, (uint32_t*)c->big_ws.p, c->stream));
-        }
-    }
-    return GMS_OK;
+    return filter_launch(c, c->stream, d_pts, d_frame_off, n_frames, d_pairs, n_pairs, max_m, d_matches, with_rotation,
+                         with_scale, threshold_factor, d_out, d_results, d_mask);
 }
 
 int gms_match_ctx(gms_ctx* c, const gms_keypoint* kp1, int n1, int w1, int h1,
@@ -315,52 +463,59 @@ int gms_match_ctx(gms_ctx* c, const gms_keypoint* kp1, int n1, int w1, int h1,
     std::lock_guard<std::mutex> lock(c->mu);
     GMS_HIP(hipSetDevice(c->device));
     hipStream_t st = c->stream;
-    // the three small tables of the call travel as one 64-byte block: frame_off[3] | wh[4] | the pair
+    Lane& L = c->lane[0];
+    // Everything the call sends travels as ONE block through pinned memory (one copy-engine transfer, no bounce through the
+    // runtime's pageable staging):  header (64 B) | matches (16 B each) | (pt.x, pt.y) of both frames (8 B each)
     struct alignas(8) CallHeader {
         int64_t foff[3];
         int32_t wh[4];
         gms_pair pair;
     };
     static_assert(sizeof(CallHeader) == 64 && offsetof(CallHeader, wh) == 24 && offsetof(CallHeader, pair) == 40, "header layout");
-    const CallHeader hdr = {{0, n1, (int64_t)n1 + n2}, {w1, h1, w2, h2}, {0, 1, m, 0, 0}};
     const size_t nkp = (size_t)n1 + (size_t)n2;
-    GMS_HIP(c->kp.reserve(nkp * sizeof(gms_keypoint)));
-    GMS_HIP(c->pts.reserve(nkp * 2 * sizeof(float)));
-    GMS_HIP(c->foff.reserve(sizeof hdr));
-    GMS_HIP(c->matches.reserve((size_t)m * sizeof(gms_dmatch)));
-    GMS_HIP(c->out.reserve((size_t)m * sizeof(gms_dmatch)));
-    GMS_HIP(c->result.reserve(sizeof(gms_pair_result)));
-    if (n1) GMS_HIP(hipMemcpyAsync(c->kp.p, kp1, (size_t)n1 * sizeof(gms_keypoint), hipMemcpyHostToDevice, st));
-    if (n2)
-        GMS_HIP(hipMemcpyAsync((gms_keypoint*)c->kp.p + n1, kp2, (size_t)n2 * sizeof(gms_keypoint),
-                               hipMemcpyHostToDevice, st));
-    GMS_HIP(hipMemcpyAsync(c->foff.p, &hdr, sizeof hdr, hipMemcpyHostToDevice, st));
-    if (m) GMS_HIP(hipMemcpyAsync(c->matches.p, matches, (size_t)m * sizeof(gms_dmatch), hipMemcpyHostToDevice, st));
-    const int64_t* d_foff = (const int64_t*)c->foff.p;
-    const int32_t* d_wh = (const int32_t*)((const char*)c->foff.p + offsetof(CallHeader, wh));
-    const gms_pair* d_pair = (const gms_pair*)((const char*)c->foff.p + offsetof(CallHeader, pair));
-    // the staging copies above read caller/stack memory: finish them before anything can go out of scope
+    const size_t off_m = sizeof(CallHeader), off_xy = off_m + (size_t)m * sizeof(gms_dmatch);
+    const size_t in_bytes = off_xy + nkp * 8;
+    const size_t out_bytes = sizeof(gms_pair_result) + (size_t)m * sizeof(gms_dmatch);  // result | out
+    GMS_HIP(L.hin.reserve(in_bytes));
+    GMS_HIP(L.hout.reserve(out_bytes));
+    // (a DevBuf that grows frees its old block: earlier work of this lane is complete -- every host-pointer call ends
+    // synchronised -- unless the caller switched streams in between, which the synchronize below covers)
+    if (in_bytes > L.din.cap || out_bytes > L.dout.cap || nkp * 8 > c->tab_pts.cap) GMS_HIP(hipDeviceSynchronize());
+    GMS_HIP(L.din.reserve(in_bytes));
+    GMS_HIP(L.dout.reserve(out_bytes));
+    GMS_HIP(c->tab_pts.reserve(nkp * 8));
+    char* hin = (char*)L.hin.p;
+    const CallHeader hdr = {{0, n1, (int64_t)n1 + n2}, {w1, h1, w2, h2}, {0, 1, m, 0, 0}};
+    std::memcpy(hin, &hdr, sizeof hdr);
+    if (m) std::memcpy(hin + off_m, matches, (size_t)m * sizeof(gms_dmatch));
+    pack_xy(kp1, (size_t)n1, (float*)(hin + off_xy));
+    pack_xy(kp2, (size_t)n2, (float*)(hin + off_xy) + 2 * (size_t)n1);
+    GMS_HIP(hipMemcpyAsync(L.din.p, hin, in_bytes, hipMemcpyHostToDevice, st));
+    const char* din = (const char*)L.din.p;
+    const int64_t* d_foff = (const int64_t*)din;
+    const int32_t* d_wh = (const int32_t*)(din + offsetof(CallHeader, wh));
+    const gms_pair* d_pair = (const gms_pair*)(din + offsetof(CallHeader, pair));
+    gms_pair_result* d_res = (gms_pair_result*)L.dout.p;
+    gms_dmatch* d_out = (gms_dmatch*)((char*)L.dout.p + sizeof(gms_pair_result));
+    if (nkp) GMS_HIP(gms::launch_normalize(din + off_xy, 8, d_foff, d_wh, 2, (int64_t)nkp, (float*)c->tab_pts.p, st));
+    GMS_TRY(filter_launch(c, st, (const float*)c->tab_pts.p, d_foff, 2, d_pair, 1, m, (const gms_dmatch*)(din + off_m),
+                          with_rotation, with_scale, threshold_factor, d_out, d_res, nullptr));
+    // Calls up to 16k matches fetch the result record and all m output slots in the same round trip (256 KB over PCIe costs less
+    // than a second synchronisation); larger ones fetch the record first and then exactly the survivors.
+    const bool eager = m <= 16384;
+    GMS_HIP(hipMemcpyAsync(L.hout.p, L.dout.p, eager ? out_bytes : sizeof(gms_pair_result), hipMemcpyDeviceToHost, st));
     GMS_HIP(hipStreamSynchronize(st));
-
-    int rc = gms_normalize_device(c, (const gms_keypoint*)c->kp.p, d_foff, d_wh, 2, (int64_t)nkp, (float*)c->pts.p);
-    if (rc != GMS_OK) return rc;
-    rc = gms_filter_device(c, (const float*)c->pts.p, d_foff, 2, d_pair, 1, m, (const gms_dmatch*)c->matches.p, with_rotation,
-                           with_scale, threshold_factor, (gms_dmatch*)c->out.p, (gms_pair_result*)c->result.p, nullptr);
-    if (rc != GMS_OK) return rc;
-    gms_pair_result r;
-    GMS_HIP(hipMemcpyAsync(&r, c->result.p, sizeof r, hipMemcpyDeviceToHost, st));
-    // Small calls get the output in the same round trip as the result: all m slots are copied (the caller's buffer has room
-    // for m by contract; what lies beyond *n_out is unspecified) instead of waiting for the count first. Measured: pays up to
-    // about 2k matches (32 KB); at 10k the extra bytes cost more than the saved synchronisation.
-    const bool eager = m > 0 && m <= 2048;
-    if (eager) GMS_HIP(hipMemcpyAsync(out, c->out.p, (size_t)m * sizeof(gms_dmatch), hipMemcpyDeviceToHost, st));
-    GMS_HIP(hipStreamSynchronize(st));
+    const gms_pair_result r = *(const gms_pair_result*)L.hout.p;
     if (result) *result = r;
     if (r.status != GMS_OK) return r.status;
-    if (!eager && r.n_inliers > 0) {
-        GMS_HIP(hipMemcpyAsync(out, c->out.p, (size_t)r.n_inliers * sizeof(gms_dmatch), hipMemcpyDeviceToHost, st));
+    if (r.n_inliers < 0 || r.n_inliers > m) return GMS_ERR_HIP;  // (cannot happen: the kernels count what they wrote)
+    const size_t keep_bytes = (size_t)r.n_inliers * sizeof(gms_dmatch);
+    if (!eager && keep_bytes) {
+        GMS_HIP(hipMemcpyAsync((char*)L.hout.p + sizeof(gms_pair_result), d_out, keep_bytes, hipMemcpyDeviceToHost, st));
         GMS_HIP(hipStreamSynchronize(st));
     }
+    // only the survivors reach the caller's array: what lies beyond *n_out is left untouched
+    if (keep_bytes) std::memcpy(out, (const char*)L.hout.p + sizeof(gms_pair_result), keep_bytes);
     *n_out = r.n_inliers;
     return GMS_OK;
 }
@@ -383,6 +538,138 @@ int gms_match(const gms_keypoint* kp1, int n1, int w1, int h1, const gms_keypoin
     }
     return gms_match_ctx(def, kp1, n1, w1, h1, kp2, n2, w2, h2, matches, m, with_rotation, with_scale,
                          threshold_factor, out, n_out, nullptr);
+}
+
+int gms_filter_host_batch(gms_ctx* c, const gms_keypoint* kp, const int64_t* frame_off, const int32_t* wh, int n_frames,
+                          const gms_pair* pairs, int n_pairs, const gms_dmatch* matches,
+                          int with_rotation, int with_scale, double threshold_factor,
+                          gms_dmatch* out, gms_pair_result* results)
+{
+    if (!c || n_frames < 0 || n_pairs < 0) return GMS_ERR_BAD_ARG;
+    if (n_pairs == 0) return GMS_OK;
+    if (!frame_off || !wh || !pairs || !results || n_frames == 0) return GMS_ERR_BAD_ARG;
+    const int64_t total_kp = frame_off[n_frames];
+    if (total_kp < 0 || (total_kp > 0 && !kp)) return GMS_ERR_BAD_ARG;
+    int max_m = 0;
+    for (int i = 0; i < n_pairs; ++i) {
+        if (pairs[i].m < 0 || pairs[i].match_off < 0) return GMS_ERR_BAD_ARG;
+        if (pairs[i].m > gms_max_matches()) return GMS_ERR_CAPACITY;
+        max_m = std::max(max_m, pairs[i].m);
+    }
+    if (max_m > 0 && (!matches || !out)) return GMS_ERR_BAD_ARG;
+
+    std::lock_guard<std::mutex> lock(c->mu);
+    GMS_HIP(hipSetDevice(c->device));
+    c->lane[0].stream = c->own_stream;
+    // everything earlier on the context's streams and workspaces is complete before buffers are regrown and reused
+    GMS_HIP(hipStreamSynchronize(c->stream));
+    GMS_HIP(hipStreamSynchronize(c->lane[0].stream));
+    GMS_HIP(hipStreamSynchronize(c->lane[1].stream));
+
+    // ---- chunks: runs of consecutive pairs of at most kChunkMatches matches (a pair larger than that is a chunk of its own)
+    const size_t kChunkMatches = (size_t)2 << 20;  // 32 MB of match records per chunk and direction
+    const int kChunkPairs = 8192;
+    struct Chunk { int first, count; size_t matches; };
+    std::vector<Chunk> chunks;
+    for (int i = 0; i < n_pairs;) {
+        Chunk ch{i, 0, 0};
+        while (i < n_pairs && ch.count < kChunkPairs && (ch.count == 0 || ch.matches + (size_t)pairs[i].m <= kChunkMatches)) {
+            ch.matches += (size_t)pairs[i].m;
+            ++ch.count;
+            ++i;
+        }
+        chunks.push_back(ch);
+    }
+    size_t cap_m = 0, cap_p = 0;
+    for (const Chunk& ch : chunks) {
+        cap_m = std::max(cap_m, ch.matches);
+        cap_p = std::max(cap_p, (size_t)ch.count);
+    }
+    const size_t in_pairs_bytes = align16(cap_p * sizeof(gms_pair));
+    const size_t in_bytes = in_pairs_bytes + cap_m * sizeof(gms_dmatch);
+    const size_t out_res_bytes = cap_p * sizeof(gms_pair_result);
+    const size_t out_bytes = out_res_bytes + cap_m * sizeof(gms_dmatch);
+    for (Lane& L : c->lane) {
+        GMS_HIP(L.hin.reserve(in_bytes));
+        GMS_HIP(L.hout.reserve(out_bytes));
+        GMS_HIP(L.din.reserve(in_bytes));
+        GMS_HIP(L.dout.reserve(out_bytes));
+    }
+    {   // the workspaces for the largest chunk, once, so that no launch below has to grow them mid-pipeline
+        WsNeed w;
+        GMS_TRY(plan_workspace(c, (int)cap_p, max_m, with_rotation != 0, with_scale != 0, true, &w));
+        GMS_TRY(grow_workspace(c, w, c->lane[0].stream));
+    }
+
+    // ---- the frame table: (pt.x, pt.y) of every keypoint through pinned memory in pieces, then normalizePoints on the GPU
+    const size_t small_bytes = align16((size_t)(n_frames + 1) * 8) + (size_t)n_frames * 8;
+    GMS_HIP(c->tab_kp.reserve((size_t)total_kp * 8));
+    GMS_HIP(c->tab_pts.reserve((size_t)total_kp * 8));
+    GMS_HIP(c->tab_small.reserve(small_bytes));
+    {
+        hipStream_t st = c->lane[0].stream;
+        GMS_HIP(hipMemcpyAsync(c->tab_small.p, frame_off, (size_t)(n_frames + 1) * 8, hipMemcpyHostToDevice, st));
+        GMS_HIP(hipMemcpyAsync((char*)c->tab_small.p + align16((size_t)(n_frames + 1) * 8), wh, (size_t)n_frames * 8,
+                               hipMemcpyHostToDevice, st));
+        GMS_HIP(hipStreamSynchronize(st));  // (frame_off / wh are the caller's pageable memory)
+        const size_t piece = std::min(c->lane[0].hin.cap, c->lane[1].hin.cap) / 8;  // keypoints per piece
+        int k = 0;
+        for (size_t done = 0; done < (size_t)total_kp; done += piece, ++k) {
+            Lane& L = c->lane[k & 1];
+            const size_t n = std::min(piece, (size_t)total_kp - done);
+            GMS_HIP(hipStreamSynchronize(L.stream));  // the piece this buffer carried two rounds ago has left it
+            pack_xy(kp + done, n, (float*)L.hin.p);
+            GMS_HIP(hipMemcpyAsync((char*)c->tab_kp.p + done * 8, L.hin.p, n * 8, hipMemcpyHostToDevice, L.stream));
+        }
+        GMS_HIP(hipStreamSynchronize(c->lane[0].stream));
+        GMS_HIP(hipStreamSynchronize(c->lane[1].stream));
+        if (total_kp)
+            GMS_HIP(gms::launch_normalize(c->tab_kp.p, 8, (const int64_t*)c->tab_small.p,
+                                          (const int32_t*)((char*)c->tab_small.p + align16((size_t)(n_frames + 1) * 8)),
+                                          n_frames, total_kp, (float*)c->tab_pts.p, st));
+        GMS_HIP(hipStreamSynchronize(st));
+    }
+    const int64_t* d_foff = (const int64_t*)c->tab_small.p;
+
+    // ---- the pipeline: chunk k rides lane k & 1 (upload -> filter -> download, stream-ordered); the host stages chunk k + 1
+    //      into the other lane's pinned block meanwhile, and hands chunk k - 1's survivors to the caller's arrays
+    auto drain = [&](const Chunk& ch, Lane& L) -> int {
+        GMS_HIP(hipStreamSynchronize(L.stream));
+        const gms_pair_result* res = (const gms_pair_result*)L.hout.p;
+        const gms_dmatch* o = (const gms_dmatch*)((const char*)L.hout.p + out_res_bytes);
+        size_t local = 0;
+        for (int i = 0; i < ch.count; ++i) {
+            const gms_pair& pr = pairs[ch.first + i];
+            results[ch.first + i] = res[i];
+            if (res[i].status == GMS_OK && res[i].n_inliers > 0)
+                std::memcpy(out + pr.match_off, o + local, (size_t)res[i].n_inliers * sizeof(gms_dmatch));
+            local += (size_t)pr.m;
+        }
+        return GMS_OK;
+    };
+    for (size_t k = 0; k < chunks.size(); ++k) {
+        const Chunk& ch = chunks[k];
+        Lane& L = c->lane[k & 1];
+        if (k >= 2) GMS_TRY(drain(chunks[k - 2], L));
+        gms_pair* hp = (gms_pair*)L.hin.p;
+        gms_dmatch* hm = (gms_dmatch*)((char*)L.hin.p + in_pairs_bytes);
+        size_t local = 0;
+        int chunk_max_m = 0;
+        for (int i = 0; i < ch.count; ++i) {
+            const gms_pair& pr = pairs[ch.first + i];
+            hp[i] = gms_pair{pr.frame_a, pr.frame_b, pr.m, 0, (int64_t)local};
+            if (pr.m) std::memcpy(hm + local, matches + pr.match_off, (size_t)pr.m * sizeof(gms_dmatch));
+            local += (size_t)pr.m;
+            chunk_max_m = std::max(chunk_max_m, pr.m);
+        }
+        GMS_HIP(hipMemcpyAsync(L.din.p, L.hin.p, in_pairs_bytes + local * sizeof(gms_dmatch), hipMemcpyHostToDevice, L.stream));
+        GMS_TRY(filter_launch(c, L.stream, (const float*)c->tab_pts.p, d_foff, n_frames, (const gms_pair*)L.din.p, ch.count,
+                              chunk_max_m, (const gms_dmatch*)((const char*)L.din.p + in_pairs_bytes), with_rotation, with_scale,
+                              threshold_factor, (gms_dmatch*)((char*)L.dout.p + out_res_bytes), (gms_pair_result*)L.dout.p, nullptr));
+        GMS_HIP(hipMemcpyAsync(L.hout.p, L.dout.p, out_res_bytes + local * sizeof(gms_dmatch), hipMemcpyDeviceToHost, L.stream));
+    }
+    for (size_t k = chunks.size() >= 2 ? chunks.size() - 2 : 0; k < chunks.size(); ++k) GMS_TRY(drain(chunks[k], c->lane[k & 1]));
+    return GMS_OK;
 }
 
 int gms_selftest_threshold(gms_ctx* c, const int32_t* T, const int32_t* n, const int32_t* score, double factor,

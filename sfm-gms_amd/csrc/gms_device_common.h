@@ -1,0 +1,78 @@
+// gms_device_common.h -- device helpers shared by every kernel file of the GMS filter (one definition each:
+// the hashed table's slot/bucket arithmetic, verifyCellPairs' threshold test, the rotation patterns, small
+// LDS/DPP idioms). Internal; included by the .hip files only.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "gms_kernels.h"
+
+namespace gms {
+
+constexpr uint32_t kEmpty = 0xFFFFFFFFu;
+
+// code word of the hashed kernels (one dword per match)
+constexpr uint32_t kRMask = 0x7FFu;        // bits 0..10   right cell of the current scale (< 1600)
+constexpr int kFShift = 11;                // bits 11..21  half-cell ("fine") index hy * 40 + hx of the left point,
+constexpr uint32_t kFMask = 0x7FFu;        //              or kFineInvalid when the point is never binned
+constexpr int kAccShift = 24;              // bits 24..31  inlier-under-rotation bits (OR over the 4 grid types)
+constexpr uint32_t kFineInvalid = kFineN;  // entries [1600, 1664) of the fine tables are "nothing here"
+constexpr int kFineStride = 1664;
+constexpr uint32_t kNoMatch = 0xFFFFFF00u; // fres value that equals no right cell
+
+// table slot: [right cell : 11 | count : 21]; a left cell's region holds only its own right cells and is
+// organised in 4-slot buckets so that one 16-byte read sees a whole bucket
+constexpr int kSlotRShift = 21;
+constexpr uint32_t kSlotCountMask = (1u << kSlotRShift) - 1u;
+
+// Data buckets (of 4 slots) of a left cell holding n matches: slots >= distinct right cells + 1, so an
+// empty slot always exists and ends every probe chain. sh = 0, 1, 2 gives about 2, 1.5, 1.25 slots per match;
+// 2048 buckets already exceed the 1600 right cells any region can hold.
+__device__ __forceinline__ uint32_t region_buckets(uint32_t n, int sh)
+{
+    return n ? min((n + (n >> sh) + 3u) >> 2, 2048u) : 0u;
+}
+
+// bucket of right cell r in a region of nb <= 2048 buckets: Fibonacci hash on 12 bits, all 24-bit multiplies
+__device__ __forceinline__ uint32_t bucket_of(uint32_t r, uint32_t nb)
+{
+    return __umul24(__umul24(r, 2531u) & 0xFFFu, nb) >> 12;
+}
+
+__device__ __forceinline__ uint32_t* lds_at(uint32_t* base, uint32_t byte_off)
+{
+    return reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(base) + byte_off);
+}
+
+// verifyCellPairs' test "thresh = sqrt(T / n) * factor; reject iff thresh > score" (divsd, sqrtsd, mulsd, comisd at
+// DLL@0x180049171). In exact arithmetic (factor > 0) it is T * factor^2 > score^2 * n. b = score^2 * n is exact in
+// fp64 (< 2^53) and a = fl(fl(T * factor) * factor) is within 2^-51 of exact, while the reference's three roundings
+// move thresh by less than 2^-50 relative: when a and b differ by more than 2^-40 relative, the reference's answer is
+// the sign of a - b. Only near-ties (exact ties, in practice) run the divide and the square root.
+__device__ __forceinline__ bool threshold_rejects(uint32_t T, uint32_t n, uint32_t score, double factor, bool fast_ok)
+{
+    const double dT = (double)T, dN = (double)n, dS = (double)score;
+    if (fast_ok) {
+        const double a = dT * factor * factor, b = dS * dS * dN;
+        if (fabs(a - b) > fmax(a, b) * 0x1p-40) return a > b;
+    }
+    return sqrt(dT / dN) * factor > dS;
+}
+// factor ranges where factor^2 neither overflows nor loses precision to underflow
+__device__ __forceinline__ bool threshold_fast_ok(double factor) { return factor > 1e-100 && factor < 1e100; }
+
+// mRotationPatterns without a table: the eight outer positions of the 3 x 3 block form a ring
+// (0,1,2,5,8,7,6,3 clockwise); pattern rot sends the position with ring index u to the one with ring index
+// (u - rot) mod 8, the centre stays (checked against the DLL's table in tests/test_oracle_pins.py). A per-lane
+// rotation would otherwise index constant memory per lane, which the compiler serialises over the distinct values.
+__device__ __forceinline__ int rotated_position(int rot, int u) { return (int)((0x36785210u >> (((u - rot) & 7) << 2)) & 15u); }
+__device__ __forceinline__ int position_dx(int q) { return (int)((0x24924u >> (q << 1)) & 3u) - 1; }  // q % 3 - 1
+__device__ __forceinline__ int position_dy(int q) { return (int)((0x2a540u >> (q << 1)) & 3u) - 1; }  // q / 3 - 1
+
+// lane ^ 1 exchange on the VALU (DPP quad_perm [1,0,3,2]), no LDS round trip
+__device__ __forceinline__ uint32_t dpp_xor1(uint32_t x)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1, 0xF, 0xF, false);
+}
+
+}  // namespace gms

@@ -22,7 +22,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#include "gms_kernels.h"
+#include "gms_device_common.h"
 
 namespace gms {
 namespace {
@@ -49,27 +49,6 @@ __device__ __forceinline__ void band_rows(int band, int& lo, int& hi)  // own ro
 {
     lo = band * 7;
     hi = band == 2 ? kLeftH : lo + 7;
-}
-
-__device__ __forceinline__ uint32_t* lds_at(uint32_t* base, uint32_t byte_off)
-{
-    return reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(base) + byte_off);
-}
-
-// the general fp64 form of verifyCellPairs' test (see threshold_rejects in gms_kernels.hip)
-__device__ __forceinline__ bool band_threshold_rejects(uint32_t T, uint32_t n, uint32_t score, double factor)
-{
-    const double dT = (double)T, dN = (double)n, dS = (double)score;
-    if (factor > 1e-100 && factor < 1e100) {
-        const double a = dT * factor * factor, b = dS * dS * dN;
-        if (fabs(a - b) > fmax(a, b) * 0x1p-40) return a > b;
-    }
-    return sqrt(dT / dN) * factor > dS;
-}
-
-__device__ __forceinline__ uint32_t dpp_xor1(uint32_t x)
-{
-    return (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0xB1, 0xF, 0xF, true);  // quad_perm [1,0,3,2]
 }
 
 // Streams a band's list of (code word, match index) entries through the workgroup, 4 per thread per step, the next step's
@@ -327,7 +306,7 @@ band_filter_kernel(FilterParams p, const uint2* lists, const uint32_t* list_len,
                 T += ni;
                 np += 1;
                 if (live && half == 0 && ni != 0) {
-                    const uint32_t pass = band_threshold_rejects(T, np, score, p.threshold_factor) ? 0u : 1u;
+                    const uint32_t pass = threshold_rejects(T, np, score, p.threshold_factor, threshold_fast_ok(p.threshold_factor)) ? 0u : 1u;
                     smem[hdr_off >> 2] = (ej << 1) | pass;  // cellPairs[i] (both lanes of the cell have read the header above)
                 }
             }
@@ -715,7 +694,7 @@ tile_filter_kernel(FilterParams p, TileGeom gm, const uint2* lists, const uint32
             T += ni;
             np += 1;
             uint32_t pass = 0;
-            if (live && ni != 0 && (ROT || half == 0)) pass = band_threshold_rejects(T, np, score, p.threshold_factor) ? 0u : 1u;
+            if (live && ni != 0 && (ROT || half == 0)) pass = threshold_rejects(T, np, score, p.threshold_factor, threshold_fast_ok(p.threshold_factor)) ? 0u : 1u;
             uint32_t bits = pass;
             bool writer = live && ni != 0 && half == 0;
             if (ROT) {
@@ -816,6 +795,17 @@ tile_apply_kernel(FilterParams p, int scale, const uint8_t* rotmask, uint8_t* be
 }
 
 // ---- launch helpers ----------------------------------------------------------------------------------------------------
+hipError_t init_band_kernels()  // once per context: see init_filter_kernels
+{
+    const void* fns[] = {reinterpret_cast<const void*>(band_filter_kernel), reinterpret_cast<const void*>(tile_filter_kernel<true>),
+                         reinterpret_cast<const void*>(tile_filter_kernel<false>)};
+    for (const void* fn : fns) {
+        const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
 size_t band_ws_bytes_per_pair(int mcap, bool need_mask)
 {
     return (size_t)mcap * 24 + (size_t)kFineN * 4 + 16 + (need_mask ? (size_t)mcap : 0);
@@ -834,13 +824,6 @@ hipError_t launch_filter_band(const FilterParams& p, int mcap, void* ws, const u
     uint8_t* mask_ws = reinterpret_cast<uint8_t*>(flags + n);
     hipError_t e = hipMemsetAsync(nfine, 0, ((size_t)n * kFineN + (size_t)n * 4) * 4, stream);
     if (e != hipSuccess) return e;
-    static bool attr_set = false;
-    if (!attr_set) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(band_filter_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)kLdsBytes);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
     hipLaunchKernelGGL(band_codes_kernel, dim3((unsigned)((mcap + 4095) / 4096), (unsigned)n), dim3(1024), 0, stream, p, lists,
                        list_len, nfine, flags, mask_ws, mcap);
     // few pairs: one workgroup per (band, grid type) -- 12 per pair -- so that a single large pair spreads over more CUs (the
@@ -928,16 +911,6 @@ hipError_t launch_filter_tiles(const FilterParams& p, int mcap, void* ws, const 
     if (p.mask == nullptr) {
         e = hipMemsetAsync(bestmask, 0, (size_t)n * mcap, stream);
         if (e != hipSuccess) return e;
-    }
-    static bool attr_set = false;
-    if (!attr_set) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(tile_filter_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)kLdsBytes);
-        if (e != hipSuccess) return e;
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(tile_filter_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)kLdsBytes);
-        if (e != hipSuccess) return e;
-        attr_set = true;
     }
     const bool rot = p.with_rotation != 0;
     for (int s = 0; s < n_scales; ++s) {

@@ -13,7 +13,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#include "gms_kernels.h"
+#include "gms_device_common.h"
 
 namespace gms {
 namespace {
@@ -23,21 +23,8 @@ __constant__ int8_t c_rot_big[8][9] = {  // mRotationPatterns - 1 (DLL .rdata 0x
     {7, 6, 3, 8, 4, 0, 5, 2, 1}, {8, 7, 6, 5, 4, 3, 2, 1, 0}, {5, 8, 7, 2, 4, 6, 1, 0, 3},
     {2, 5, 8, 1, 4, 7, 0, 3, 6}, {1, 2, 5, 0, 4, 8, 3, 6, 7}};
 
-constexpr uint32_t kEmpty = 0xFFFFFFFFu;
-constexpr uint32_t kRMask = 0x7FFu;
-constexpr int kFShift = 11;
-constexpr uint32_t kFMask = 0x7FFu;
-constexpr int kAccShift = 24;
-constexpr uint32_t kFineInvalid = kFineN;
-constexpr int kFineStride = 1664;
-constexpr uint32_t kNoMatch = 0xFFFFFF00u;
-constexpr int kSlotRShift = 21;
-constexpr uint32_t kSlotCountMask = (1u << kSlotRShift) - 1u;
 constexpr int kDescShift = 12;                 // desc = (header bucket << 12) | data buckets (<= 2048)
 constexpr uint32_t kDescNbMask = (1u << kDescShift) - 1u;
-
-__device__ __forceinline__ uint32_t region_buckets(uint32_t n) { return n ? min((2u * n + 3u) >> 2, 2048u) : 0u; }
-__device__ __forceinline__ uint32_t bucket_of(uint32_t r, uint32_t nb) { return __umul24(__umul24(r, 2531u) & 0xFFFu, nb) >> 12; }
 
 // table reads: agent scope, i.e. from L2, where the atomics land
 __device__ __forceinline__ uint32_t tload(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -191,7 +178,7 @@ filter_kernel_big(FilterParams p, uint32_t* ws, size_t ws_stride, int mcap, uint
                     const int hx = hx0 + dx, hy = hy0 + dy;
                     if (hx >= 0 && hy >= 0) n += nfine[hy * kFineW + hx];
                 }
-            const uint32_t nb = region_buckets(n);
+            const uint32_t nb = region_buckets(n, 0);
             uint32_t d = 0;
             if (nb) d = (atomicAdd(&misc[12 + g], nb + 1u) << kDescShift) | nb;
             nleft4[item] = n;
@@ -398,21 +385,21 @@ size_t big_lds_bytes(int mcap)
     return ((size_t)kFineStride + 8 * kLeftN + 4 * kFineStride + (mcap >> 5) + (mcap >> 6) + 1 + 64) * 4;
 }
 
+hipError_t init_big_kernels()  // once per context: see init_filter_kernels
+{
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(filter_kernel_big<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(filter_kernel_big<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes);
+    return e;
+}
+
 hipError_t launch_filter_big(const FilterParams& p, int mcap, int n_workgroups, uint32_t* ws, hipStream_t stream)
 {
     if (p.n_pairs <= 0) return hipSuccess;
     const size_t lds = big_lds_bytes(mcap);
     const uint32_t T = big_table_slots(mcap);
     const size_t stride = big_ws_stride_dwords(mcap);
-    static bool attr_set[2] = {false, false};
     const bool rot = p.with_rotation != 0;
-    if (!attr_set[rot]) {
-        const void* fn = rot ? reinterpret_cast<const void*>(filter_kernel_big<true>)
-                             : reinterpret_cast<const void*>(filter_kernel_big<false>);
-        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes);
-        if (e != hipSuccess) return e;
-        attr_set[rot] = true;
-    }
     if (rot)
         hipLaunchKernelGGL(filter_kernel_big<true>, dim3((unsigned)n_workgroups), dim3(kThreads), lds, stream, p, ws, stride, mcap, T);
     else

@@ -23,10 +23,8 @@ struct FilterParams {
     int n_frames;
     const gms_pair* pairs;
     int n_pairs;
-    int prefetch_stride;        // workgroup b touches the match array of pair b + stride (0 = off)
-    int stagger_cycles;         // first-round workgroups start spread over this many shader cycles (0 = off)
+    int stagger_ticks;          // first-round workgroups start spread over this many 100 MHz wall-clock ticks (0 = off)
     int stagger_blocks;         // how many leading workgroups count as the first round
-    int stagger_mode;           // 0: delay grows with the workgroup index; 1: scattered (diagnostics)
     const gms_dmatch* matches;
     gms_dmatch* out;
     gms_pair_result* results;
@@ -44,18 +42,18 @@ struct FilterParams {
 #endif
 };
 
+hipError_t init_filter_kernels();        // once per context, before the first launch: dynamic-LDS limits of every kernel
+hipError_t init_band_kernels();
+hipError_t init_big_kernels();
 int        filter_pick_kpt(int max_m);   // matches per thread (template variant) for max_m, 0 = too large
 uint32_t   filter_table_slots(int kpt);
 int        filter_region_shift(int kpt);
 size_t     filter_lds_bytes(int kpt, uint32_t table_slots);
-hipError_t launch_normalize(const gms_keypoint* d_kp, const int64_t* d_frame_off, const int32_t* d_wh,
+// kp_stride_bytes: 28 = cv::KeyPoint records, 8 = packed (pt.x, pt.y) pairs
+hipError_t launch_normalize(const void* d_kp, int kp_stride_bytes, const int64_t* d_frame_off, const int32_t* d_wh,
                             int n_frames, int64_t total_kp, float* d_pts, hipStream_t stream);
 hipError_t launch_filter(const FilterParams& p, int kpt, int n_pairs, hipStream_t stream);
 hipError_t launch_filter_scales(const FilterParams& p, int kpt, int n_pairs, hipStream_t stream);
-// two-workgroups-per-CU variant (gms_kernel_occ2.hip), m <= 10 240
-int        occ2_pick_kpt(int max_m);
-uint32_t   occ2_table_slots(int kpt);
-hipError_t launch_filter_occ2(const FilterParams& p, int kpt, int n_pairs, hipStream_t stream);
 // large pairs (gms_kernel_big.hip): code words and table in a per-workgroup HBM slab
 constexpr int kBigMaxMatches = 262144;
 int        big_mcap(int max_m);

@@ -43,11 +43,9 @@
 
 #include <type_traits>
 
-#include "gms_kernels.h"
+#include "gms_device_common.h"
 
 namespace gms {
-
-constexpr uint32_t kEmpty = 0xFFFFFFFFu;
 
 // Diagnostic build only (-DGMS_PHASE_TIMING, libgms_hip_diag.so): thread 0 of each workgroup sums the
 // shader-clock cycles between phase boundaries into p.diag[block][phase]. No stamp exists in the product build.
@@ -60,34 +58,6 @@ constexpr uint32_t kEmpty = 0xFFFFFFFFu;
 #define GMS_STAMP(k)
 #define GMS_STAMP_FLUSH
 #endif
-
-// code word (one dword per match, kept in a register for the whole pair)
-constexpr uint32_t kRMask = 0x7FFu;        // bits 0..10   right cell of the current scale (< 1600)
-constexpr int kFShift = 11;                // bits 11..21  half-cell ("fine") index hy * 40 + hx of the left point,
-constexpr uint32_t kFMask = 0x7FFu;        //              or kFineInvalid when the point is never binned
-constexpr int kAccShift = 24;              // bits 24..31  inlier-under-rotation bits (OR over the 4 grid types)
-constexpr uint32_t kFineInvalid = kFineN;  // entries [1600, 1664) of the fine tables are "nothing here"
-constexpr int kFineStride = 1664;
-constexpr uint32_t kNoMatch = 0xFFFFFF00u; // fres value that equals no right cell
-
-// table slot: [right cell : 11 | count : 21]; a left cell's region holds only its own right cells and is
-// organised in 4-slot buckets so that one ds_read_b128 sees a whole bucket
-constexpr int kSlotRShift = 21;
-constexpr uint32_t kSlotCountMask = (1u << kSlotRShift) - 1u;
-
-// Data buckets (of 4 slots) of a left cell holding n matches: slots >= distinct right cells + 1, so an
-// empty slot always exists and ends every probe chain. sh = 0, 1, 2 gives about 2, 1.5, 1.25 slots per match;
-// 2048 buckets already exceed the 1600 right cells any region can hold.
-__device__ __forceinline__ uint32_t region_buckets(uint32_t n, int sh)
-{
-    return n ? min((n + (n >> sh) + 3u) >> 2, 2048u) : 0u;
-}
-
-// bucket of right cell r in a region of nb <= 2048 buckets: Fibonacci hash on 12 bits, all 24-bit multiplies
-__device__ __forceinline__ uint32_t bucket_of(uint32_t r, uint32_t nb)
-{
-    return __umul24(__umul24(r, 2531u) & 0xFFFu, nb) >> 12;
-}
 
 // byte offset (0, 4, 8, 12) of the slot of bucket v whose key is r (kr = r << 21), or -1
 __device__ __forceinline__ int bucket_find(const uint4& v, uint32_t kr)
@@ -116,11 +86,6 @@ __device__ __forceinline__ uint32_t bucket_count(const uint4& v, uint32_t kr)
     c = ((v.y ^ kr) <= kSlotCountMask) ? v.y : c;
     c = ((v.x ^ kr) <= kSlotCountMask) ? v.x : c;
     return c & kSlotCountMask;
-}
-
-__device__ __forceinline__ uint32_t* lds_at(uint32_t* base, uint32_t byte_off)
-{
-    return reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(base) + byte_off);
 }
 
 // A region is one header bucket followed by nb data buckets; d = (header bucket << 16) | nb.
@@ -178,44 +143,13 @@ __device__ __forceinline__ uint32_t region_lookup_general(const uint32_t* tab, u
     return 0;
 }
 
-// verifyCellPairs' test "thresh = sqrt(T / n) * factor; reject iff thresh > score" (divsd, sqrtsd, mulsd, comisd at
-// DLL@0x180049171). In exact arithmetic (factor > 0) it is T * factor^2 > score^2 * n. b = score^2 * n is exact in
-// fp64 (< 2^53) and a = fl(fl(T * factor) * factor) is within 2^-51 of exact, while the reference's three roundings
-// move thresh by less than 2^-50 relative: when a and b differ by more than 2^-40 relative, the reference's answer is
-// the sign of a - b. Only near-ties (exact ties, in practice) run the divide and the square root.
-__device__ __forceinline__ bool threshold_rejects(uint32_t T, uint32_t n, uint32_t score, double factor, bool fast_ok)
-{
-    const double dT = (double)T, dN = (double)n, dS = (double)score;
-    if (fast_ok) {
-        const double a = dT * factor * factor, b = dS * dS * dN;
-        if (fabs(a - b) > fmax(a, b) * 0x1p-40) return a > b;
-    }
-    return sqrt(dT / dN) * factor > dS;
-}
-// factor ranges where factor^2 neither overflows nor loses precision to underflow
-__device__ __forceinline__ bool threshold_fast_ok(double factor) { return factor > 1e-100 && factor < 1e100; }
-
-// mRotationPatterns without a table: the eight outer positions of the 3 x 3 block form a ring
-// (0,1,2,5,8,7,6,3 clockwise); pattern rot sends the position with ring index u to the one with ring index
-// (u - rot) mod 8, the centre stays (checked against the DLL's table in tests/test_oracle_pins.py). A per-lane
-// rotation would otherwise index constant memory per lane, which the compiler serialises over the distinct values.
-__device__ __forceinline__ int rotated_position(int rot, int u) { return (int)((0x36785210u >> (((u - rot) & 7) << 2)) & 15u); }
-__device__ __forceinline__ int position_dx(int q) { return (int)((0x24924u >> (q << 1)) & 3u) - 1; }  // q % 3 - 1
-__device__ __forceinline__ int position_dy(int q) { return (int)((0x2a540u >> (q << 1)) & 3u) - 1; }  // q / 3 - 1
-
-// lane ^ 1 exchange on the VALU (DPP quad_perm [1,0,3,2]), no LDS round trip
-__device__ __forceinline__ uint32_t dpp_xor1(uint32_t x)
-{
-    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1, 0xF, 0xF, false);
-}
-
 // ------------------------------------------------------------------------------------------------
 // normalizePoints (DLL@0x180048420): one thread per keypoint; frame found by binary search.
 // A -0.0 result is stored as +0.0 (adding +0.0f): every later use is floor(n * W), which is 0 for
 // both, and it lets the filter test "finite, non-negative" on the bit pattern alone.
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
-normalize_kernel(const gms_keypoint* __restrict__ kp, const int64_t* __restrict__ frame_off,
+normalize_kernel(const char* __restrict__ kp, int kp_stride, const int64_t* __restrict__ frame_off,
                  const int32_t* __restrict__ wh, int n_frames, int64_t total, float2* __restrict__ pts)
 {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -227,7 +161,7 @@ normalize_kernel(const gms_keypoint* __restrict__ kp, const int64_t* __restrict_
             if (frame_off[mid] <= i) lo = mid; else hi = mid - 1;
         }
         float w = (float)wh[2 * lo], h = (float)wh[2 * lo + 1];
-        const float* p = reinterpret_cast<const float*>(kp + i);
+        const float* p = reinterpret_cast<const float*>(kp + i * kp_stride);  // pt.x at +0, pt.y at +4 (DLL@0x1800485d4)
         float2 o;
         o.x = p[0] / w + 0.0f;  // IEEE fp32 divide (divss)
         o.y = p[1] / h + 0.0f;
@@ -237,16 +171,16 @@ normalize_kernel(const gms_keypoint* __restrict__ kp, const int64_t* __restrict_
 
 // Every pair of a batch costs about the same, so the workgroups of one dispatch round would all read their
 // match arrays at the same moment (an HBM burst, then a long quiet stretch) and stay in lockstep round after
-// round. The first round's workgroups start spread over p.stagger_cycles; the spread then persists.
+// round. The first round's workgroups start spread over p.stagger_ticks (ticks of the 100 MHz wall clock, so the
+// spread does not depend on the shader clock the chip happens to hold); the spread then persists.
 __device__ __forceinline__ void first_round_stagger(const FilterParams& p)
 {
-    if (p.stagger_cycles > 0 && blockIdx.x < (unsigned)p.stagger_blocks) {
+    if (p.stagger_ticks > 0 && blockIdx.x < (unsigned)p.stagger_blocks) {
         // in workgroup order: workgroups are handed to the XCDs round-robin and in order, so CUs should come free in
         // that same order or the next workgroup in line waits for "its" XCD while others sit idle
-        const unsigned slot = p.stagger_mode ? ((blockIdx.x * 37u) & 63u) * (unsigned)(p.stagger_blocks >> 6) : blockIdx.x;
-        const long long until = (long long)__builtin_readcyclecounter() +
-                                (long long)slot * (long long)p.stagger_cycles / (long long)p.stagger_blocks;
-        while ((long long)__builtin_readcyclecounter() < until) __builtin_amdgcn_s_sleep(32);
+        const long long until = (long long)wall_clock64() +
+                                (long long)blockIdx.x * (long long)p.stagger_ticks / (long long)p.stagger_blocks;
+        while ((long long)wall_clock64() < until) __builtin_amdgcn_s_sleep(32);
     }
 }
 
@@ -392,19 +326,6 @@ __device__ __forceinline__ void hash_pair(const FilterParams& p, uint32_t* smem,
             code[k] = ((live && ok) ? r : 0u) | (f << kFShift);
         }
         if (any_bad) misc[8] = 1;  // benign race: every writer stores 1
-    }
-    // Touch the match array of the pair that a workgroup of the next dispatch round will filter (same XCD
-    // under round-robin placement; speed only): one dword per 128-byte line, results unused. Its HBM reads
-    // then overlap this pair's LDS work instead of arriving as one burst in front of it.
-    {
-        const int nxt = pair_idx + p.prefetch_stride;
-        if (p.prefetch_stride > 0 && nxt < p.n_pairs) {
-            const gms_pair np = p.pairs[nxt];
-            const volatile char* base = reinterpret_cast<const volatile char*>(p.matches + np.match_off);
-            const int lines = (np.m > 0 && np.m <= kMcap) ? (np.m * 16 + 127) >> 7 : 0;
-            for (int ln = tid; ln < lines; ln += NT)
-                (void)*reinterpret_cast<const volatile uint32_t*>(base + (size_t)ln * 128);
-        }
     }
     GMS_STAMP(13);    // bin: codes + half-cell histogram
     __syncthreads();  // nfine complete
@@ -1820,30 +1741,20 @@ int filter_pick_kpt(int max_m)
     return 0;
 }
 
-hipError_t launch_normalize(const gms_keypoint* d_kp, const int64_t* d_frame_off, const int32_t* d_wh,
+hipError_t launch_normalize(const void* d_kp, int kp_stride_bytes, const int64_t* d_frame_off, const int32_t* d_wh,
                             int n_frames, int64_t total_kp, float* d_pts, hipStream_t stream)
 {
     if (total_kp <= 0) return hipSuccess;
     int64_t blocks = (total_kp + 255) / 256;
     if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(normalize_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, d_kp, d_frame_off,
-                       d_wh, n_frames, total_kp, reinterpret_cast<float2*>(d_pts));
+    hipLaunchKernelGGL(normalize_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, reinterpret_cast<const char*>(d_kp),
+                       kp_stride_bytes, d_frame_off, d_wh, n_frames, total_kp, reinterpret_cast<float2*>(d_pts));
     return hipGetLastError();
 }
 
 template <int KPT, bool ROT, int NT>
 static hipError_t launch_filter_t(const FilterParams& p, int n_pairs, size_t lds_bytes, hipStream_t stream)
 {
-    static bool attr_set = false;  // per instantiation; the largest request this variant can make
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(filter_kernel<KPT, ROT, NT>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes);
-        if (e != hipSuccess) return e;
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(filter_kernel_dense<KPT, ROT, NT>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
     if (p.dense) {
         const size_t lds = lds_bytes > kDenseLdsBytes ? lds_bytes : (size_t)kDenseLdsBytes;
         hipLaunchKernelGGL((filter_kernel_dense<KPT, ROT, NT>), dim3((unsigned)n_pairs), dim3(NT), lds, stream, p);
@@ -1851,6 +1762,32 @@ static hipError_t launch_filter_t(const FilterParams& p, int n_pairs, size_t lds
         hipLaunchKernelGGL((filter_kernel<KPT, ROT, NT>), dim3((unsigned)n_pairs), dim3(NT), lds_bytes, stream, p);
     }
     return hipGetLastError();
+}
+
+template <int KPT, bool ROT, int NT>
+static hipError_t allow_full_lds_t()
+{
+    const void* fns[] = {reinterpret_cast<const void*>(filter_kernel<KPT, ROT, NT>),
+                         reinterpret_cast<const void*>(filter_kernel_dense<KPT, ROT, NT>),
+                         reinterpret_cast<const void*>(filter_kernel_dense_scales<KPT, ROT, NT>)};
+    for (const void* fn : fns) {
+        const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
+// Once per context (device), before the first launch: every kernel here may ask for the CU's whole LDS. Done up front so
+// that a launch is nothing but a launch (stream capture of gms_filter_device sees no attribute call).
+hipError_t init_filter_kernels()
+{
+    hipError_t e = allow_full_lds_t<4, false, 1024>();
+    if (e == hipSuccess) e = allow_full_lds_t<4, true, 1024>();
+    if (e == hipSuccess) e = allow_full_lds_t<10, false, 1024>();
+    if (e == hipSuccess) e = allow_full_lds_t<10, true, 1024>();
+    if (e == hipSuccess) e = allow_full_lds_t<16, false, 1024>();
+    if (e == hipSuccess) e = allow_full_lds_t<16, true, 1024>();
+    return e;
 }
 
 // kpt = matches per thread of the 1024-thread workgroup. (A 512-thread build with twice the matches per thread and
@@ -1872,13 +1809,6 @@ hipError_t launch_filter(const FilterParams& p, int kpt, int n_pairs, hipStream_
 template <int KPT, bool ROT, int NT>
 static hipError_t launch_dense_scales_t(const FilterParams& p, int n_pairs, hipStream_t stream)
 {
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(filter_kernel_dense_scales<KPT, ROT, NT>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
     hipLaunchKernelGGL((filter_kernel_dense_scales<KPT, ROT, NT>), dim3((unsigned)n_pairs), dim3(NT), kDenseLdsBytes, stream, p);
     return hipGetLastError();
 }

@@ -14,6 +14,7 @@ assert KEYPOINT_DTYPE.itemsize == 28 and DMATCH_DTYPE.itemsize == 16
 assert PAIR_DTYPE.itemsize == 24 and RESULT_DTYPE.itemsize == 16
 
 GMS_OK, GMS_ERR_BAD_ARG, GMS_ERR_DOMAIN, GMS_ERR_HIP, GMS_ERR_NO_DEVICE, GMS_ERR_CAPACITY = 0, -1, -2, -3, -4, -5
+GMS_ERR_NOT_RESERVED = -6
 
 
 class GmsError(RuntimeError):

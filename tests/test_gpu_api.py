@@ -1,0 +1,290 @@
+"""-m gpu: the contract of the C ABI beyond "one call, right answer" -- reserved launches neither allocate nor synchronise
+(they can be captured into a graph), a context survives stream changes and concurrent host threads, the host-pointer
+batch entry, sliced large batches, the one-shot call's output tail, and BASELINE config 3's table at its stated size."""
+import importlib
+import os
+import subprocess
+import sys
+import threading
+
+import numpy as np
+import pytest
+
+import cases
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _oracle_batch(oracle, frames, sizes, foff, pairs, matches, rot, scale, threads=8):
+    kp_all = np.concatenate(frames)
+    wh = np.asarray(sizes, dtype=np.int32).reshape(-1)
+    failed, out, res, mask = oracle.batch(kp_all, foff, wh, pairs, matches, rot, scale, 6.0, threads)
+    return failed, out, res, mask
+
+
+def _same(pairs, out, res, wout, wres):
+    assert res.tobytes() == wres.tobytes()
+    for i in range(len(pairs)):
+        o, k = int(pairs["match_off"][i]), int(res["n_inliers"][i])
+        assert out[o:o + k].tobytes() == wout[o:o + k].tobytes(), i
+
+
+def _sequence(pkg, synth, n_frames, n_kp, n_pairs, seed, size, ragged=True):
+    from test_gpu_parity import _sequence_batch
+    return _sequence_batch(pkg, synth, n_frames, n_kp, n_pairs, seed, ragged=ragged, size=size)
+
+
+# ---- gms_ctx_reserve: a reserved launch is nothing but launches -> it can be captured and replayed ----------------
+@pytest.mark.parametrize("rot,scale,n_kp", [(False, False, 3000), (True, True, 3000), (False, False, 20000), (True, True, 20000)])
+def test_reserved_launch_is_capturable(pkg, oracle, synth, rot, scale, n_kp):
+    import torch
+    batch = importlib.import_module("sfm-gms_amd.batch")
+    size = (1280, 720)
+    frames, pairs, matches = _sequence(pkg, synth, 6, n_kp, 12, 91, size)
+    with pkg.GmsContext(0) as ctx:
+        table = batch.FrameTable(ctx, frames, [size] * len(frames))
+        dev = table.device
+        d_pairs = batch._to_dev(pairs, dev)
+        d_matches = batch._to_dev(matches, dev)
+        d_out = torch.zeros(len(matches) * 16, dtype=torch.uint8, device=dev)
+        d_res = torch.zeros(len(pairs) * 16, dtype=torch.uint8, device=dev)
+        max_m = int(pairs["m"].max())
+        s = torch.cuda.Stream(device=dev)
+        ctx.set_stream(s.cuda_stream)
+
+        def launch():
+            ctx.filter_device(table.d_pts.data_ptr(), table.d_frame_off.data_ptr(), table.n_frames, d_pairs.data_ptr(),
+                              len(pairs), max_m, d_matches.data_ptr(), d_out.data_ptr(), d_res.data_ptr(), None, rot, scale, 6.0)
+
+        needs_ws = scale or n_kp > 16384
+        if needs_ws:
+            # not reserved: growing a workspace inside a capture is refused, loudly, and the capture survives it
+            g0 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g0, stream=s):
+                with pytest.raises(pkg.GmsError) as e:
+                    launch()
+                assert e.value.code == -6
+        ctx.reserve(len(pairs), max_m, rot, scale)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s):   # any allocation or synchronisation inside would fail the capture
+            launch()
+        d_out.zero_()
+        d_res.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        out = d_out.cpu().numpy().view(pkg.DMATCH_DTYPE)
+        res = d_res.cpu().numpy().view(pkg.RESULT_DTYPE)
+        ctx.set_stream(None)
+    failed, wout, wres, _ = _oracle_batch(oracle, frames, [size] * len(frames), table.frame_off_host, pairs, matches, rot, scale)
+    assert failed == 0
+    _same(pairs, out, res, wout, wres)
+
+
+# ---- one context, two streams, workspaces in use on both ------------------------------------------------------------------
+def test_stream_switch_with_work_in_flight(pkg, oracle, synth):
+    """Launches that share the context's workspaces (scale hypotheses: one record per pair) alternate between two streams
+    without any host synchronisation in between; each must see its own records."""
+    import torch
+    batch = importlib.import_module("sfm-gms_amd.batch")
+    size = (1280, 720)
+    sets = [_sequence(pkg, synth, 5, 4000, 48, 200 + i, size) for i in range(2)]
+    with pkg.GmsContext(0) as ctx:
+        tabs, bufs = [], []
+        for frames, pairs, matches in sets:
+            t = batch.FrameTable(ctx, frames, [size] * len(frames))
+            dev = t.device
+            tabs.append(t)
+            bufs.append((batch._to_dev(pairs, dev), batch._to_dev(matches, dev),
+                         torch.zeros(len(matches) * 16, dtype=torch.uint8, device=dev),
+                         torch.zeros(len(pairs) * 16, dtype=torch.uint8, device=dev)))
+        streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+        torch.cuda.synchronize()
+        for rep in range(6):
+            i = rep & 1
+            ctx.set_stream(streams[i].cuda_stream)
+            pairs = sets[i][1]
+            dp, dm, do, dr = bufs[i]
+            ctx.filter_device(tabs[i].d_pts.data_ptr(), tabs[i].d_frame_off.data_ptr(), tabs[i].n_frames, dp.data_ptr(),
+                              len(pairs), int(pairs["m"].max()), dm.data_ptr(), do.data_ptr(), dr.data_ptr(), None, True, True, 6.0)
+        torch.cuda.synchronize()
+        ctx.set_stream(None)
+        for i, (frames, pairs, matches) in enumerate(sets):
+            out = bufs[i][2].cpu().numpy().view(pkg.DMATCH_DTYPE)
+            res = bufs[i][3].cpu().numpy().view(pkg.RESULT_DTYPE)
+            failed, wout, wres, _ = _oracle_batch(oracle, frames, [size] * len(frames), tabs[i].frame_off_host, pairs, matches, True, True)
+            assert failed == 0
+            _same(pairs, out, res, wout, wres)
+
+
+def test_one_context_many_host_threads(ctx, oracle):
+    """INTEGRATION.md calls a context thread-safe: one-shot calls from several threads, all flag combinations."""
+    work = [(cases.random_pair(300 + i, n=2500 + 700 * i, inlier_frac=0.5), i & 1 == 1, i & 2 == 2) for i in range(8)]
+    want = [oracle.match(c["size1"], c["size2"], c["kp1"], c["kp2"], c["matches"], r, s, 6.0)[1] for c, r, s in work]
+    got, errs = [None] * len(work), []
+
+    def run(i):
+        try:
+            for _ in range(5):
+                c, r, s = work[i]
+                got[i] = ctx.match(c["size1"], c["size2"], c["kp1"], c["kp2"], c["matches"], r, s, 6.0)
+                assert got[i].tobytes() == want[i].tobytes()
+        except Exception as e:  # noqa: BLE001
+            errs.append((i, repr(e)))
+
+    threads = [threading.Thread(target=run, args=(i,)) for i in range(len(work))]
+    [t.start() for t in threads]
+    [t.join() for t in threads]
+    assert not errs, errs
+
+
+# ---- the one-shot call leaves the caller's array alone beyond *n_out ---------------------------------------------------
+def test_one_shot_output_tail_is_untouched(pkg, oracle):
+    import ctypes as C
+    lib = pkg.load_library()
+    sentinel = np.zeros(1, dtype=pkg.DMATCH_DTYPE)
+    sentinel["queryIdx"], sentinel["trainIdx"], sentinel["imgIdx"], sentinel["distance"] = -7, -8, -9, -1.5
+    for n, rot in ((1500, False), (1500, True), (12000, False)):
+        # a larger call first, so that the library's own buffers hold survivors of another call
+        big = cases.random_pair(400, n=n + 500, inlier_frac=0.9)
+        pkg.matchGMS(big["size1"], big["size2"], big["kp1"], big["kp2"], big["matches"])
+        c = cases.random_pair(401 + n, n=n, inlier_frac=0.3)
+        out = np.repeat(sentinel, n)
+        n_out = C.c_int(-1)
+        rc = lib.gms_match(c["kp1"].ctypes.data, n, *c["size1"], c["kp2"].ctypes.data, n, *c["size2"], c["matches"].ctypes.data, n,
+                           int(rot), 0, 6.0, out.ctypes.data, C.byref(n_out))
+        assert rc == 0
+        want = oracle.match(c["size1"], c["size2"], c["kp1"], c["kp2"], c["matches"], rot, False, 6.0)[1]
+        assert n_out.value == len(want) and out[:n_out.value].tobytes() == want.tobytes()
+        assert out[n_out.value:].tobytes() == np.repeat(sentinel, n - n_out.value).tobytes()
+    # an error leaves everything alone and reports zero survivors
+    bad = cases.domain_error_cases()["train_oob"]
+    n = len(bad["matches"])
+    out = np.repeat(sentinel, n)
+    n_out = C.c_int(-1)
+    rc = lib.gms_match(bad["kp1"].ctypes.data, len(bad["kp1"]), *bad["size1"], bad["kp2"].ctypes.data, len(bad["kp2"]), *bad["size2"],
+                       bad["matches"].ctypes.data, n, 0, 0, 6.0, out.ctypes.data, C.byref(n_out))
+    assert rc == -2 and n_out.value == 0 and out.tobytes() == np.repeat(sentinel, n).tobytes()
+
+
+# ---- gms_filter_host_batch ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("rot,scale", [(False, False), (True, True)])
+def test_host_batch_matches_the_oracle(ctx, pkg, oracle, synth, rot, scale):
+    size = (1280, 720)
+    frames, pairs, matches = _sequence(pkg, synth, 8, 5000, 900, 55, size)   # ~2.2 M matches: two chunks at least
+    pairs["m"][17] = 0
+    out, res = ctx.filter_host_batch(frames, [size] * len(frames), pairs, matches, rot, scale, 6.0)
+    counts = np.array([len(f) for f in frames])
+    foff = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+    failed, wout, wres, _ = _oracle_batch(oracle, frames, [size] * len(frames), foff, pairs, matches, rot, scale)
+    assert failed == 0
+    _same(pairs, out, res, wout, wres)
+
+
+def test_host_batch_mixed_sizes_and_a_bad_pair(ctx, pkg, oracle, synth):
+    """Small and large pairs in one list (every chunk picks its own kernel family), pairs out of order in the match array,
+    one pair outside the parity domain."""
+    size = (1920, 1080)
+    frames = synth.make_sequence(77, 4, size=size, n_kp=30000)
+    rng = np.random.default_rng(9)
+    ms = [30000, 100, 9000, 0, 30000, 2000, 17000, 5]
+    blocks = [synth.sequence_matches(7000 + i, 30000, 30000, 0.5)[:m] for i, m in enumerate(ms)]
+    order = rng.permutation(len(ms))
+    offs, off = {}, 0
+    for i in order:   # blocks laid out in a shuffled order
+        offs[i] = off
+        off += ms[i]
+    matches = np.zeros(off, dtype=pkg.DMATCH_DTYPE)
+    pairs = np.zeros(len(ms), dtype=pkg.PAIR_DTYPE)
+    for i, m in enumerate(ms):
+        matches[offs[i]:offs[i] + m] = blocks[i]
+        pairs[i] = (i % 3, 3, m, 0, offs[i])
+    matches["trainIdx"][offs[5] + 3] = 10 ** 6
+    out, res = ctx.filter_host_batch(frames, [size] * 4, pairs, matches, False, False, 6.0)
+    foff = np.arange(5, dtype=np.int64) * 30000
+    failed, wout, wres, _ = _oracle_batch(oracle, frames, [size] * 4, foff, pairs, matches, False, False)
+    assert failed == 1 and res["status"].tolist() == [0, 0, 0, 0, 0, -2, 0, 0]
+    _same(pairs, out, res, wout, wres)
+
+
+# ---- large batches filtered in slices of the workspace budget (GMS_BAND_WS_BYTES is read once per process) ----------------
+_SLICE_WORKER = r'''
+import importlib, sys
+import numpy as np
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests"); sys.path.insert(0, sys.argv[1] + "/oracle")
+import gms_oracle
+pkg = importlib.import_module("sfm-gms_amd"); synth = importlib.import_module("sfm-gms_amd.synth")
+batch = importlib.import_module("sfm-gms_amd.batch")
+from test_gpu_parity import _sequence_batch
+size = (1920, 1080)
+for rot, scale in ((False, False), (True, True)):
+    frames, pairs, matches = _sequence_batch(pkg, synth, 4, 20000, 11, 5 + rot, ragged=True, size=size)
+    pairs["m"][[0, 4, 8]] = 20000                       # full-size pairs on both sides of the slice borders
+    matches = np.concatenate([matches, matches[:40000]])
+    matches["trainIdx"][int(pairs["match_off"][3]) + 1] = 1 << 30   # a domain error next to a border
+    with pkg.GmsContext(0) as ctx:
+        table = batch.FrameTable(ctx, frames, [size] * 4)
+        out, res, mask = batch.filter_pairs(ctx, table, pairs, matches, rot, scale, 6.0)
+    kp_all = np.concatenate(frames); wh = np.array([size] * 4, dtype=np.int32).reshape(-1)
+    failed, wout, wres, wmask = gms_oracle.batch(kp_all, table.frame_off_host, wh, pairs, matches, rot, scale, 6.0, 8)
+    assert failed == 1 and res.tobytes() == wres.tobytes(), (res, wres)
+    for i in range(len(pairs)):
+        o, k = int(pairs["match_off"][i]), int(res["n_inliers"][i])
+        assert out[o:o + k].tobytes() == wout[o:o + k].tobytes(), i
+        if res["status"][i] == 0:
+            assert np.array_equal(mask[o:o + int(pairs["m"][i])], wmask[o:o + int(pairs["m"][i])]), i
+print("slices ok")
+'''
+
+
+def test_large_batch_in_forced_slices(tmp_path):
+    script = tmp_path / "slices.py"
+    script.write_text(_SLICE_WORKER)
+    # 2 MB of workspace: 3 pairs per slice under the default flags (four slices of 11 pairs), 1 with rotation + scale
+    res = subprocess.run([sys.executable, str(script), ROOT], capture_output=True, text=True, timeout=900,
+                         env=dict(os.environ, GMS_BAND_WS_BYTES=str(2 << 20)))
+    assert res.returncode == 0 and "slices ok" in res.stdout, res.stderr[-3000:]
+
+
+# ---- BASELINE config 3 at its stated size: the 1000-frame table (80 MB, beyond the L2s), chunks of the real pair list -----
+def test_config3_thousand_frame_table_two_chunks(ctx, pkg, oracle, synth):
+    import torch
+    batch = importlib.import_module("sfm-gms_amd.batch")
+    d = importlib.import_module("sfm-gms_amd.dist")
+    size, n_frames, n_kp, per_chunk = (1920, 1080), 1000, 10000, 1024
+    frames = synth.make_sequence(1000, n_frames, size=size, n_kp=n_kp)
+    table = batch.FrameTable(ctx, frames, [size] * n_frames)
+    assert table.d_pts.numel() * 4 == 80_000_000
+    dev = table.device
+    kp_all = np.concatenate(frames)
+    wh = np.array([size] * n_frames, dtype=np.int32).reshape(-1)
+    # rank 5 of 8: its block of the global list, first two chunks; plus the very last pairs of the list
+    plan = d.RankPlan(n_frames, n_kp, per_chunk, 2, 5, 8)
+    firsts = plan.starts + [plan.total_pairs - per_chunk]
+    for first in firsts:
+        pairs = d.pair_table(n_frames, first, first + per_chunk, n_kp)
+        d_matches = d.synth_matches_device(first, per_chunk, n_kp, 0.5, dev)
+        d_pairs = batch._to_dev(pairs, dev)
+        d_out = torch.zeros((per_chunk * n_kp, 4), dtype=torch.int32, device=dev)
+        d_res = torch.zeros((per_chunk, 4), dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
+        ctx.filter_device(table.d_pts.data_ptr(), table.d_frame_off.data_ptr(), n_frames, d_pairs.data_ptr(), per_chunk, n_kp,
+                          d_matches.data_ptr(), d_out.data_ptr(), d_res.data_ptr(), None, False, False, 6.0)
+        ctx.synchronize()
+        res = d_res.cpu().numpy().view(pkg.RESULT_DTYPE).reshape(-1)
+        assert (res["status"] == 0).all() and (res["n_inliers"] > 2000).all()
+        # every 97th pair of the chunk (and the global parity sample, where the chunk holds one) against the oracle
+        idx = sorted(set(range(0, per_chunk, 97)) | {j for _, j in d.parity_sample(first, per_chunk) for j in [j - first]})
+        sel = pairs[idx].copy()
+        sel["match_off"] = np.arange(len(idx), dtype=np.int64) * n_kp
+        m = np.concatenate([d.synth_matches_host(first + j, n_kp, 0.5) for j in idx])   # the host form of the same matches
+        got_m = np.concatenate([d_matches[j * n_kp:(j + 1) * n_kp].cpu().numpy() for j in idx])
+        assert got_m.view(np.uint8).tobytes() == m.tobytes()
+        failed, wout, wres, _ = oracle.batch(kp_all, table.frame_off_host, wh, sel, m, False, False, 6.0, 8)
+        assert failed == 0
+        for t, j in enumerate(idx):
+            assert res[j].tobytes() == wres[t].tobytes()
+            k = int(res["n_inliers"][j])
+            got = d_out[j * n_kp:j * n_kp + k].cpu().numpy().view(np.uint8).reshape(-1).view(pkg.DMATCH_DTYPE)
+            assert got.tobytes() == wout[t * n_kp:t * n_kp + k].tobytes()
+        del d_matches, d_out, d_res, d_pairs

@@ -95,23 +95,39 @@ def test_synthetic_recipe_is_deterministic(synth):
 
 
 _GLOO_WORKER = r'''
+# The rank-side driver logic of bench.py (sfm-gms_amd/dist.py: RankPlan, synth_matches_device, parity_sample and the gloo
+# rendezvous), on CPU tensors: everything except the filter launch itself.
 import importlib, os, sys, json
 sys.path.insert(0, sys.argv[1])
-import torch, torch.distributed as dist
+import numpy as np
+pkg = importlib.import_module("sfm-gms_amd")
 d = importlib.import_module("sfm-gms_amd.dist")
 rank, local_rank, world = d.env_world()
-dist.init_process_group("gloo")
-n_total = 1001
-lo, hi = d.rank_pair_indices(n_total, rank, world)
-rows = d.sequence_pair_table(40, lo, hi, match_stride=500)
-assert len(rows) == hi - lo and all(0 <= a < b < 40 for a, b, _, _ in rows)
-assert [r[3] for r in rows] == [i * 500 for i in range(hi - lo)]
-dist.barrier()
+dist = d.init_rendezvous(world)
+assert dist is not None and dist.get_backend() == "gloo"
+n_frames, n_kp, per_step, n_chunks = 40, 300, 64, 5
+plan = d.RankPlan(n_frames, n_kp, per_step, n_chunks, rank, world)
+assert plan.total_pairs == 780 and (plan.lo, plan.hi) == pkg.shard_range(780, rank, world)
+seen = []
+for c in range(n_chunks):
+    t = plan.chunk_pairs(c)
+    k0 = plan.starts[c]
+    assert plan.lo <= k0 and k0 + plan.chunk <= plan.hi          # a chunk never leaves the rank's block
+    assert [(int(a), int(b)) for a, b in zip(t["frame_a"], t["frame_b"])] == [pkg.pair_from_index(k0 + j, n_frames) for j in range(plan.chunk)]
+    assert (t["match_off"] == np.arange(plan.chunk) * n_kp).all() and (t["m"] == n_kp).all()
+    m = d.synth_matches_device(k0, plan.chunk, n_kp, 0.5, "cpu").numpy().view(np.uint8).reshape(-1).view(pkg.DMATCH_DTYPE)
+    for k, j in plan.chunk_sample(c):
+        assert k % d.PARITY_EVERY == 0 and k == k0 + j
+        seen.append(k)
+    j = plan.chunk // 2                                           # any pair: device form == host form, whatever the rank
+    assert m[j * n_kp:(j + 1) * n_kp].tobytes() == d.synth_matches_host(k0 + j, n_kp, 0.5).tobytes()
+d.barrier(dist)
 slow = d.max_over_ranks(1.0 + rank, dist)
-counts = d.gather_counts(hi - lo, dist)
+tot = d.sum_over_ranks([plan.hi - plan.lo, len(set(seen))], dist)
+counts = d.gather_counts(plan.hi - plan.lo, dist)
 if rank == 0:
-    print(json.dumps({"max": slow, "counts": counts, "first": rows[0][:2]}))
-dist.barrier()
+    print(json.dumps({"max": slow, "counts": counts, "sum": tot, "starts": plan.starts}))
+d.barrier(dist)
 dist.destroy_process_group()
 '''
 
@@ -127,4 +143,43 @@ def test_two_rank_driver_logic_under_gloo(tmp_path):
     import json
     line = [ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1]
     got = json.loads(line)
-    assert got["max"] == 2.0 and got["counts"] == [501, 500] and sum(got["counts"]) == 1001
+    assert got["max"] == 2.0 and got["counts"] == [390, 390] and got["sum"][0] == 780
+    assert got["starts"] == [0, 64, 128, 192, 256]   # rank 0 walks its block front to back
+    assert got["sum"][1] == 1                         # pair 0 is the only multiple of 997 below 780 (rank 0 filtered it)
+
+
+def test_bench_imports_the_driver_module_the_gloo_test_covers():
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    for name in ("RankPlan", "synth_matches_device", "init_rendezvous", "max_over_ranks", "sum_over_ranks", "barrier"):
+        assert ("distmod." + name in src) or ("self.dist." + name in src) or ("wl.dist." + name in src), name
+    assert '"nccl"' not in src and "init_process_group" not in src  # the rendezvous is dist.py's (gloo)
+
+
+def test_bench_refuses_a_world_size_that_contradicts_gpus():
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], capture_output=True, text=True,
+                         timeout=120, env=env)
+    assert res.returncode != 0 and "--gpus 4" in res.stderr
+
+
+def test_vectorised_pair_indexing_and_match_synthesis(pkg):
+    import importlib
+    d = importlib.import_module("sfm-gms_amd.dist")
+    for n in (2, 3, 17, 1000):
+        total = pkg.all_pairs_count(n)
+        k = np.unique(np.concatenate([np.arange(min(total, 400)), np.arange(max(0, total - 400), total),
+                                      np.linspace(0, total - 1, 300).astype(np.int64)]))
+        a, b = d.pairs_from_indices(k, n)
+        assert [pkg.pair_from_index(int(x), n) for x in k] == list(zip(a.tolist(), b.tolist()))
+    with pytest.raises(IndexError):
+        d.pairs_from_indices([3], 3)
+    m = d.synth_matches_host(499499, 10000, 0.5)
+    assert (m["queryIdx"] == np.arange(10000)).all() and m["trainIdx"].min() >= 0 and m["trainIdx"].max() < 10000
+    assert 0.47 < (m["trainIdx"] == m["queryIdx"]).mean() < 0.53 and 0 <= m["distance"].min() and m["distance"].max() < 256
+    dev = d.synth_matches_device(499498, 2, 10000, 0.5, "cpu").numpy().view(np.uint8).reshape(-1).view(pkg.DMATCH_DTYPE)
+    assert dev[10000:].tobytes() == m.tobytes()
+    assert d.parity_sample(0, 2000) == [0, 997, 1994] and d.parity_sample(998, 996) == [] and d.parity_sample(998, 997) == [1994]
+    starts, chunk = d.chunk_starts(100, 1100, 300, 5)
+    assert chunk == 300 and starts == [100, 400, 700, 100, 400]
+    starts, chunk = d.chunk_starts(0, 50, 300, 2)
+    assert chunk == 50 and starts == [0, 0]

@@ -8,11 +8,11 @@ for i, flags in enumerate(sys.argv[1:]):
     fl = [f for f in flags.split() if f != "none"]
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-w", "-mllvm", "-disable-machine-licm",
                            "-I" + os.path.join(ROOT, "include"), "-I" + csrc, "-shared", "-o", out,
-                           os.path.join(csrc, "gms_kernels.hip"), os.path.join(csrc, "gms_kernel_occ2.hip"),
+                           os.path.join(csrc, "gms_kernels.hip"),
                            os.path.join(csrc, "gms_kernel_big.hip"), os.path.join(csrc, "gms_kernel_band.hip"), os.path.join(csrc, "gms_capi.cpp")] + fl)
     code = f"""
 import importlib, sys, json
-sys.path.insert(0, {ROOT!r}); sys.argv = ['bench.py'] + {os.environ.get('BENCH_ARGS', '--steps 10 --warmup 2 --no-extra --cpu-pairs 64').split()!r}
+sys.path.insert(0, {ROOT!r}); sys.argv = ['bench.py'] + {os.environ.get('BENCH_ARGS', '--steps 10 --warmup 2 --no-extra --no-cpu').split()!r}
 capi = importlib.import_module('sfm-gms_amd.capi'); capi.library_path = lambda: {out!r}
 import bench; bench.main()
 """
