@@ -218,9 +218,10 @@ batch = importlib.import_module("sfm-gms_amd.batch")
 from test_gpu_parity import _sequence_batch
 size = (1920, 1080)
 for rot, scale in ((False, False), (True, True)):
-    frames, pairs, matches = _sequence_batch(pkg, synth, 4, 20000, 11, 5 + rot, ragged=True, size=size)
-    pairs["m"][[0, 4, 8]] = 20000                       # full-size pairs on both sides of the slice borders
-    matches = np.concatenate([matches, matches[:40000]])
+    frames, pairs, matches = _sequence_batch(pkg, synth, 4, 20000, 11, 5 + rot, ragged=False, size=size)
+    # ragged sizes, full-size pairs on both sides of the slice borders (ranges stay disjoint: only m shrinks)
+    pairs["m"] = [20000, 16385, 49, 17000, 20000, 18000, 16500, 20000, 20000, 500, 19999]
+    matches = matches.copy()
     matches["trainIdx"][int(pairs["match_off"][3]) + 1] = 1 << 30   # a domain error next to a border
     with pkg.GmsContext(0) as ctx:
         table = batch.FrameTable(ctx, frames, [size] * 4)
@@ -274,7 +275,7 @@ def test_config3_thousand_frame_table_two_chunks(ctx, pkg, oracle, synth):
         res = d_res.cpu().numpy().view(pkg.RESULT_DTYPE).reshape(-1)
         assert (res["status"] == 0).all() and (res["n_inliers"] > 2000).all()
         # every 97th pair of the chunk (and the global parity sample, where the chunk holds one) against the oracle
-        idx = sorted(set(range(0, per_chunk, 97)) | {j for _, j in d.parity_sample(first, per_chunk) for j in [j - first]})
+        idx = sorted(set(range(0, per_chunk, 97)) | {k - first for k in d.parity_sample(first, per_chunk)})
         sel = pairs[idx].copy()
         sel["match_off"] = np.arange(len(idx), dtype=np.int64) * n_kp
         m = np.concatenate([d.synth_matches_host(first + j, n_kp, 0.5) for j in idx])   # the host form of the same matches
