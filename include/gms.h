@@ -150,6 +150,28 @@ int gms_filter_host_batch(gms_ctx* ctx, const gms_keypoint* kp, const int64_t* f
                           int with_rotation, int with_scale, double threshold_factor,
                           gms_dmatch* out, gms_pair_result* results);
 
+/* ---- brute-force descriptor matcher: the producer of the match array ------------------------------------
+ * Replaces, for a batch of pairs on the resident frame table, what the reference runs in front of matchGMS
+ * (FeatureMatchUtil.cpp:66-68; DisparityUtil.cpp:104-109,143):
+ *     BFMatcher::create(normType)->match(descriptors1, descriptors2, matches)          (no cross-check)
+ * Descriptor i of a frame belongs to keypoint i (same d_frame_off as the keypoint table). Pair p gets
+ * one match per query row -- {queryIdx = i, trainIdx = first minimum over the train rows, imgIdx = 0, distance} for
+ * i < min(d_pairs[p].m, n(frame_a)) -- written at d_matches[match_off + i]: the array gms_filter_device reads next.
+ *   GMS_DESC_HAMMING256    rows of 32 bytes (ORB), NORM_HAMMING, distance = popcount as float; needs no prepared block
+ *   GMS_DESC_L2_F32X128    rows of 128 floats (SIFT), NORM_L2, distance = sqrtf(sum of squared differences in fp32).
+ *                          gms_bf_prepare_device builds the per-frame tables (gms_bf_prepared_bytes bytes, caller-allocated)
+ *                          once per frame table. Frames whose values are all integers 0..255 (what SIFT emits) run on the
+ *                          matrix cores with exact arithmetic; any other frame is matched by the reference's fp32 loop.
+ * Stream-ordered on the context's stream, no allocation, no synchronisation. A frame may hold at most 2^22 rows. */
+#define GMS_DESC_HAMMING256  0
+#define GMS_DESC_L2_F32X128  1
+int64_t gms_bf_prepared_bytes(int desc_kind, int64_t total_desc, int n_frames);
+int gms_bf_prepare_device(gms_ctx* ctx, int desc_kind, const void* d_desc, const int64_t* d_frame_off, int n_frames,
+                          int64_t total_desc, void* d_prepared);
+int gms_bfmatch_device(gms_ctx* ctx, int desc_kind, const void* d_desc, const void* d_prepared, int64_t total_desc,
+                       const int64_t* d_frame_off, int n_frames, const gms_pair* d_pairs, int n_pairs, int max_query,
+                       gms_dmatch* d_matches);
+
 /* ---- introspection --------------------------------------------------------------------------- */
 int         gms_max_matches(void);        /* largest m per pair this build accepts                 */
 int         gms_last_hip_error(void);     /* last hipError_t seen by this thread's calls           */

@@ -54,8 +54,29 @@ def load():
     lib.gms_ref_verify_cells.restype = i32
     lib.gms_ref_scale_ratio.argtypes = [i32]
     lib.gms_ref_scale_ratio.restype = dbl
+    lib.bf_ref_hamming256.argtypes = [vp, i32, vp, i32, vp]
+    lib.bf_ref_hamming256.restype = i32
+    lib.bf_ref_l2.argtypes = [vp, i32, vp, i32, i32, vp]
+    lib.bf_ref_l2.restype = i32
     _lib = lib
     return lib
+
+
+def bf_match(query, train, hamming):
+    """The reference's BFMatcher::match restated (oracle/bf_ref.c): uint8 [n, 32] rows under NORM_HAMMING, or float32
+    [n, dim] rows under NORM_L2; one DMatch per query row, first minimum."""
+    lib = load()
+    out = np.zeros(max(len(query), 1), dtype=DMATCH_DTYPE)
+    if hamming:
+        q = np.ascontiguousarray(query, dtype=np.uint8).reshape(-1, 32)
+        t = np.ascontiguousarray(train, dtype=np.uint8).reshape(-1, 32)
+        rc = lib.bf_ref_hamming256(q.ctypes.data, len(q), t.ctypes.data, len(t), out.ctypes.data)
+    else:
+        q = np.ascontiguousarray(query, dtype=np.float32)
+        t = np.ascontiguousarray(train, dtype=np.float32)
+        rc = lib.bf_ref_l2(q.ctypes.data, len(q), t.ctypes.data, len(t), q.shape[1], out.ctypes.data)
+    assert rc == 0
+    return out[: len(q)]
 
 
 def match(size1, size2, kp1, kp2, matches, with_rotation=False, with_scale=False, threshold_factor=6.0):

@@ -124,6 +124,20 @@ class GmsContext:
                                            float(thresholdFactor), d_out, d_results, d_mask or None),
                self._lib, "gms_filter_device")
 
+    # -- brute-force descriptor matcher on the resident frame table (FeatureMatchUtil.cpp:66-68) -----------------------
+    def bf_prepared_bytes(self, desc_kind, total_desc, n_frames):
+        return int(self._lib.gms_bf_prepared_bytes(int(desc_kind), int(total_desc), int(n_frames)))
+
+    def bf_prepare_device(self, desc_kind, d_desc, d_frame_off, n_frames, total_desc, d_prepared):
+        _check(self._lib.gms_bf_prepare_device(self._h, int(desc_kind), d_desc, d_frame_off, int(n_frames), int(total_desc),
+                                               d_prepared or None), self._lib, "gms_bf_prepare_device")
+
+    def bfmatch_device(self, desc_kind, d_desc, d_prepared, total_desc, d_frame_off, n_frames, d_pairs, n_pairs, max_query,
+                       d_matches):
+        _check(self._lib.gms_bfmatch_device(self._h, int(desc_kind), d_desc, d_prepared or None, int(total_desc), d_frame_off,
+                                            int(n_frames), d_pairs, int(n_pairs), int(max_query), d_matches),
+               self._lib, "gms_bfmatch_device")
+
     def selftest_threshold(self, T, n, score, factor):
         T = np.ascontiguousarray(T, dtype=np.int32)
         n = np.ascontiguousarray(n, dtype=np.int32)

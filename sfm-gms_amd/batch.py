@@ -41,6 +41,46 @@ class FrameTable:
         ctx.synchronize()
 
 
+class DescriptorTable:
+    """Descriptors of all frames of a sequence, resident on the GPU beside a FrameTable (descriptor i of a frame belongs to
+    keypoint i). kind = GMS_DESC_HAMMING256: uint8 [n, 32] rows (ORB); GMS_DESC_L2_F32X128: float32 [n, 128] rows (SIFT), for
+    which the per-frame tables of the matcher are prepared once here (gms_bf_prepare_device)."""
+
+    def __init__(self, ctx, frames, descriptors_per_frame, kind):
+        self.ctx, self.kind, self.frames = ctx, int(kind), frames
+        dt, width = (np.uint8, 32) if self.kind == 0 else (np.float32, 128)
+        rows = [np.ascontiguousarray(d, dtype=dt).reshape(-1, width) for d in descriptors_per_frame]
+        assert [len(r) for r in rows] == list(np.diff(frames.frame_off_host)), "one descriptor per keypoint"
+        self.host = np.concatenate(rows) if frames.total else np.zeros((0, width), dtype=dt)
+        self.d_desc = torch.from_numpy(self.host.view(np.uint8).reshape(-1)).to(frames.device) if frames.total else \
+            torch.zeros(16, dtype=torch.uint8, device=frames.device)
+        nbytes = ctx.bf_prepared_bytes(self.kind, frames.total, frames.n_frames)
+        self.d_prep = torch.zeros(max(nbytes, 16), dtype=torch.uint8, device=frames.device)
+        torch.cuda.synchronize(frames.device)
+        ctx.bf_prepare_device(self.kind, self.d_desc.data_ptr(), frames.d_frame_off.data_ptr(), frames.n_frames, frames.total,
+                              self.d_prep.data_ptr())
+        ctx.synchronize()
+
+    def match_device(self, d_pairs, n_pairs, max_query, d_matches):
+        """gms_bfmatch_device: one match per query row of every pair, written at the pair's match_off (stream-ordered)."""
+        f = self.frames
+        self.ctx.bfmatch_device(self.kind, self.d_desc.data_ptr(), self.d_prep.data_ptr(), f.total, f.d_frame_off.data_ptr(),
+                                f.n_frames, d_pairs, n_pairs, max_query, d_matches)
+
+
+def match_pairs(ctx, descs, pairs):
+    """Brute-force matches of `pairs` (PAIR_DTYPE; m = keypoints of frame_a) as a host DMATCH_DTYPE array laid out by match_off."""
+    dev = descs.frames.device
+    pairs = np.ascontiguousarray(pairs, dtype=PAIR_DTYPE)
+    total = int((pairs["match_off"] + pairs["m"]).max()) if len(pairs) else 0
+    d_pairs = _to_dev(pairs, dev)
+    d_matches = torch.zeros(max(total, 1) * 16, dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize(dev)
+    descs.match_device(d_pairs.data_ptr(), len(pairs), int(pairs["m"].max()) if len(pairs) else 0, d_matches.data_ptr())
+    ctx.synchronize()
+    return d_matches.cpu().numpy().view(DMATCH_DTYPE)[:total]
+
+
 def filter_pairs(ctx, frames, pairs, matches, withRotation=False, withScale=False, thresholdFactor=6.0,
                  want_mask=True):
     """Run the filter over `pairs` (PAIR_DTYPE array) whose matches live in `matches` (DMATCH_DTYPE array,

@@ -672,6 +672,42 @@ int gms_filter_host_batch(gms_ctx* c, const gms_keypoint* kp, const int64_t* fra
     return GMS_OK;
 }
 
+int64_t gms_bf_prepared_bytes(int desc_kind, int64_t total_desc, int n_frames)
+{
+    return (int64_t)gms::bf_prepared_bytes(desc_kind, total_desc, n_frames);
+}
+
+int gms_bf_prepare_device(gms_ctx* c, int desc_kind, const void* d_desc, const int64_t* d_frame_off, int n_frames,
+                          int64_t total_desc, void* d_prepared)
+{
+    if (!c || n_frames < 0 || total_desc < 0) return GMS_ERR_BAD_ARG;
+    if (desc_kind == GMS_DESC_HAMMING256) return GMS_OK;  // nothing to prepare
+    if (desc_kind != GMS_DESC_L2_F32X128) return GMS_ERR_BAD_ARG;
+    if (total_desc == 0 || n_frames == 0) return GMS_OK;
+    if (!d_desc || !d_frame_off || !d_prepared) return GMS_ERR_BAD_ARG;
+    std::lock_guard<std::mutex> lock(c->mu);
+    GMS_HIP(hipSetDevice(c->device));
+    GMS_HIP(gms::launch_bf_prepare(d_desc, d_frame_off, n_frames, total_desc, d_prepared, c->stream));
+    return GMS_OK;
+}
+
+int gms_bfmatch_device(gms_ctx* c, int desc_kind, const void* d_desc, const void* d_prepared, int64_t total_desc,
+                       const int64_t* d_frame_off, int n_frames, const gms_pair* d_pairs, int n_pairs, int max_query,
+                       gms_dmatch* d_matches)
+{
+    if (!c || n_frames < 0 || n_pairs < 0 || max_query < 0 || total_desc < 0) return GMS_ERR_BAD_ARG;
+    if (desc_kind != GMS_DESC_HAMMING256 && desc_kind != GMS_DESC_L2_F32X128) return GMS_ERR_BAD_ARG;
+    if (n_pairs == 0 || max_query == 0) return GMS_OK;
+    if (!d_desc || !d_frame_off || !d_pairs || !d_matches) return GMS_ERR_BAD_ARG;
+    if (desc_kind == GMS_DESC_L2_F32X128 && !d_prepared) return GMS_ERR_BAD_ARG;
+    if (max_query > (1 << 22)) return GMS_ERR_CAPACITY;
+    std::lock_guard<std::mutex> lock(c->mu);
+    GMS_HIP(hipSetDevice(c->device));
+    GMS_HIP(gms::launch_bf_match(desc_kind, d_desc, d_prepared, total_desc, d_frame_off, n_frames, d_pairs, n_pairs, max_query,
+                                 d_matches, c->stream));
+    return GMS_OK;
+}
+
 int gms_selftest_threshold(gms_ctx* c, const int32_t* T, const int32_t* n, const int32_t* score, double factor,
                            int count, uint8_t* out)
 {

@@ -66,6 +66,11 @@ hipError_t launch_filter_band(const FilterParams& p, int mcap, void* ws, const u
 // large pairs with rotation / scale hypotheses (gms_kernel_band.hip): tiled 16-bit matrix, three launches per scale
 size_t     tile_ws_bytes_per_pair(const FilterParams& p, int mcap, bool need_mask);
 hipError_t launch_filter_tiles(const FilterParams& p, int mcap, void* ws, const uint32_t** flags_out, hipStream_t stream);
+// brute-force descriptor matcher (bf_kernels.hip)
+size_t     bf_prepared_bytes(int kind, int64_t total, int n_frames);
+hipError_t launch_bf_prepare(const void* d_desc, const int64_t* d_frame_off, int n_frames, int64_t total, void* d_prep, hipStream_t stream);
+hipError_t launch_bf_match(int kind, const void* d_desc, const void* d_prep, int64_t total, const int64_t* d_frame_off, int n_frames,
+                           const gms_pair* d_pairs, int n_pairs, int max_query, gms_dmatch* d_matches, hipStream_t stream);
 hipError_t launch_threshold(const int32_t* d_T, const int32_t* d_n, const int32_t* d_score, double factor,
                             int count, uint8_t* d_out, hipStream_t stream);
 

@@ -100,3 +100,32 @@ def sequence_matches(case_id, n_kp_a, n_kp_b, inlier_frac=0.5):
     q = np.arange(n_kp_a)
     t = np.where(rng.uniform(size=n_kp_a) < inlier_frac, np.minimum(q, n_kp_b - 1), rng.integers(0, n_kp_b, n_kp_a))
     return make_matches(q, t, rng)
+
+
+def sequence_descriptors(case_id, n_frames, n_kp, kind="orb", flip_bits=20, noise=6.0, outlier_frac=0.0):
+    """Descriptors for a make_sequence() sequence: scene point i has one base descriptor, frame f observes it with noise, so
+    the brute-force match of keypoint i of frame a in frame b is (mostly) keypoint i.
+    kind "orb": uint8 [n_kp, 32] rows, `flip_bits` random bits flipped per observation (NORM_HAMMING).
+    kind "sift": float32 [n_kp, 128] rows holding integers 0..255, as cv::SIFT emits them (NORM_L2).
+    outlier_frac: share of a frame's keypoints that show something else (a random descriptor): their nearest neighbour in
+    another frame is arbitrary, which is what the putative matches of real image pairs look like."""
+    rng = rng_for(case_id ^ 0xD35C)
+    out = []
+    if kind == "orb":
+        base = rng.integers(0, 256, (n_kp, 32), dtype=np.uint8)
+        for _ in range(n_frames):
+            d = base.copy()
+            pos = rng.integers(0, 256, (n_kp, flip_bits))
+            rows = np.repeat(np.arange(n_kp), flip_bits)
+            np.bitwise_xor.at(d, (rows, (pos >> 3).ravel()), (1 << (pos & 7)).astype(np.uint8).ravel())
+            other = rng.uniform(size=n_kp) < outlier_frac
+            d[other] = rng.integers(0, 256, (int(other.sum()), 32), dtype=np.uint8)
+            out.append(d)
+    else:
+        base = rng.gamma(1.2, 22.0, (n_kp, 128))
+        for _ in range(n_frames):
+            d = np.clip(np.rint(base + rng.normal(0, noise, (n_kp, 128))), 0, 255)
+            other = rng.uniform(size=n_kp) < outlier_frac
+            d[other] = np.clip(np.rint(rng.gamma(1.2, 22.0, (int(other.sum()), 128))), 0, 255)
+            out.append(d.astype(np.float32))
+    return out

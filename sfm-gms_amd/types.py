@@ -21,3 +21,6 @@ class GmsError(RuntimeError):
     def __init__(self, code, what=""):
         self.code = int(code)
         super().__init__(f"gms error {code}: {what}")
+
+# descriptor kinds of the brute-force matcher (include/gms.h)
+GMS_DESC_HAMMING256, GMS_DESC_L2_F32X128 = 0, 1
