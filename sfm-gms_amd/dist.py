@@ -136,6 +136,35 @@ def synth_matches_device(first, count, n_kp, inlier_frac, device, seed=MATCH_SEE
     return out
 
 
+def synth_descriptors_device(n_frames, n_kp, kind, outlier_frac, device, seed=MATCH_SEED):
+    """Descriptors of every keypoint of a synth.make_sequence()-style sequence, generated on `device`: scene point i has a base
+    descriptor, frame f observes it with noise, and with probability outlier_frac shows something else entirely (so that
+    brute-force matching yields true correspondences i -> i mixed with arbitrary ones, like real putative matches).
+    kind "orb": uint8 [n_frames * n_kp, 32] (about 32 of the 256 bits flipped per observation);
+    kind "sift": float32 [n_frames * n_kp, 128] holding integers 0..255, as cv::SIFT emits them."""
+    import torch
+    words = 8 if kind == "orb" else 128
+    thresh = min(int(outlier_frac * 4294967296.0), _M32)
+    out = []
+    point = torch.arange(n_kp, dtype=torch.int64, device=device)
+    w = torch.arange(words, dtype=torch.int64, device=device)
+    base = _mix_t(_mix_t(point[:, None] * 131 + seed) + w[None, :] * 0x9E3779B1)
+    for f in range(n_frames):
+        key = _mix_t(_mix_t(point[:, None] + (f + 1) * 0x10001 + seed) + w[None, :] * 0x85EBCA6B)
+        other = (_mix_t(point * 7919 + f * 104729 + seed) < thresh)[:, None]
+        if kind == "orb":
+            noise = key & _mix_t(key + 1) & _mix_t(key + 2)              # each bit set with probability 1/8
+            d = torch.where(other, _mix_t(key + 3), base ^ noise)
+            out.append(d.to(torch.int32))                                # the low 32 bits, reinterpreted
+        else:
+            b = (base & 0xFF) * (_mix_t(base + 5) & 0xFF) >> 9           # skewed towards small values, 0..127
+            n = (key & 7) - (_mix_t(key + 1) & 7)                        # -7..7
+            d = torch.where(other, (_mix_t(key + 3) & 0xFF) * (_mix_t(key + 4) & 0xFF) >> 9, torch.clamp(b + n, 0, 255))
+            out.append(d.to(torch.float32))
+    t = torch.cat(out)
+    return t.view(torch.uint8).reshape(-1, 32) if kind == "orb" else t
+
+
 # ---- rendezvous ---------------------------------------------------------------------------------------------------------
 def init_rendezvous(world_size):
     """torch.distributed over gloo (CPU tensors) when world_size > 1, else None. MASTER_ADDR/PORT, RANK, WORLD_SIZE come

@@ -19,7 +19,10 @@ d = importlib.import_module("sfm-gms_amd.dist")
 
 kind = sys.argv[1] if len(sys.argv) > 1 else "orb"
 n_pairs = int(sys.argv[2]) if len(sys.argv) > 2 else 256
-n_frames, n_kp, size = 32, 10000, (1920, 1080)
+n_kp, size = 10000, (1920, 1080)
+n_frames = 32
+while n_frames * (n_frames - 1) // 2 < n_pairs:
+    n_frames += 8
 ctx = pkg.GmsContext(0)
 frames = synth.make_sequence(1000, n_frames, size=size, n_kp=n_kp)
 descs = synth.sequence_descriptors(1000, n_frames, n_kp, kind, outlier_frac=0.5)
