@@ -172,6 +172,33 @@ int gms_bfmatch_device(gms_ctx* ctx, int desc_kind, const void* d_desc, const vo
                        const int64_t* d_frame_off, int n_frames, const gms_pair* d_pairs, int n_pairs, int max_query,
                        gms_dmatch* d_matches);
 
+/* ---- consumers of the filtered matches --------------------------------------------------------------------
+ * Both read the survivors of ONE pair where gms_filter_device left them (d_matches = d_out + match_off, *d_n_matches =
+ * d_results[i].n_inliers, max_matches >= that count, e.g. the pair's m) and the two frames' ORIGINAL keypoints (pixel
+ * coordinates, cv::KeyPoint records). Stream-ordered, no allocation, no synchronisation.
+ *
+ * gms_disparity_device: DisparityUtil.cpp:179-201. d_disparity (w*h bytes, row-major) receives the disparity map (255 = no
+ * match; a later match overwrites an earlier one on the same pixel); with a ground-truth image d_gt (w*h bytes, may be NULL)
+ * d_stats receives count / sum of squares / maximum of |map - gt / disp_ratio| over the matched pixels, from which
+ * rms = sqrt(sum_sq / count) (DisparityUtil.cpp:201). d_work: w*h uint32 of scratch. status: GMS_ERR_DOMAIN when a match
+ * indexes outside the keypoints or lands outside the image (undefined behaviour in the reference). */
+typedef struct gms_disparity_stats {
+    int64_t count;    /* matched pixels (map != 255) */
+    int64_t sum_sq;   /* sum of a^2, a = |map - gt / disp_ratio| */
+    int32_t max_abs;  /* max a */
+    int32_t status;   /* GMS_OK or GMS_ERR_DOMAIN */
+} gms_disparity_stats;
+int gms_disparity_device(gms_ctx* ctx, const gms_keypoint* d_kp1, int n1, const gms_keypoint* d_kp2, int n2,
+                         const gms_dmatch* d_matches, const int32_t* d_n_matches, int max_matches, int width, int height,
+                         const uint8_t* d_gt, int disp_ratio, uint8_t* d_disparity, uint32_t* d_work,
+                         gms_disparity_stats* d_stats);
+/* gms_gather_points_device: SfMUtil.cpp:25-35. coords1[i] = keypoints1[queryIdx].pt, coords2[i] = keypoints2[trainIdx].pt
+ * (two floats each) for i < *d_n_matches: the arrays findEssentialMat / recoverPose / undistortPoints take (SfMUtil.cpp:39,
+ * 45,78-79). *d_status: GMS_OK or GMS_ERR_DOMAIN. */
+int gms_gather_points_device(gms_ctx* ctx, const gms_keypoint* d_kp1, int n1, const gms_keypoint* d_kp2, int n2,
+                             const gms_dmatch* d_matches, const int32_t* d_n_matches, int max_matches,
+                             float* d_coords1, float* d_coords2, int32_t* d_status);
+
 /* ---- introspection --------------------------------------------------------------------------- */
 int         gms_max_matches(void);        /* largest m per pair this build accepts                 */
 int         gms_last_hip_error(void);     /* last hipError_t seen by this thread's calls           */

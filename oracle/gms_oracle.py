@@ -54,6 +54,10 @@ def load():
     lib.gms_ref_verify_cells.restype = i32
     lib.gms_ref_scale_ratio.argtypes = [i32]
     lib.gms_ref_scale_ratio.restype = dbl
+    lib.disp_ref_map_and_rms.argtypes = [vp, i32, vp, i32, vp, i32, i32, i32, vp, i32, vp, vp, vp, vp, vp]
+    lib.disp_ref_map_and_rms.restype = i32
+    lib.sfm_ref_gather.argtypes = [vp, i32, vp, i32, vp, i32, vp, vp]
+    lib.sfm_ref_gather.restype = i32
     lib.bf_ref_hamming256.argtypes = [vp, i32, vp, i32, vp]
     lib.bf_ref_hamming256.restype = i32
     lib.bf_ref_l2.argtypes = [vp, i32, vp, i32, i32, vp]
@@ -142,3 +146,31 @@ def verify_cells(motion, nleft, wr, hr, rotation_type, factor=6.0):
                                   float(factor), out.ctypes.data)
     assert rc == 0
     return out
+
+
+def disparity(kp1, kp2, matches, width, height, gt, disp_ratio):
+    """DisparityUtil.cpp:179-201 restated (oracle/consumer_ref.c): (rc, map [h, w] uint8, count, sum_sq, max_abs, rms)."""
+    lib = load()
+    kp1 = np.ascontiguousarray(kp1, dtype=KEYPOINT_DTYPE)
+    kp2 = np.ascontiguousarray(kp2, dtype=KEYPOINT_DTYPE)
+    mt = np.ascontiguousarray(matches, dtype=DMATCH_DTYPE)
+    out = np.zeros((height, width), dtype=np.uint8)
+    cnt, ssq, mx, rms = C.c_int64(0), C.c_int64(0), C.c_int32(0), C.c_double(0)
+    g = None if gt is None else np.ascontiguousarray(gt, dtype=np.uint8)
+    rc = lib.disp_ref_map_and_rms(kp1.ctypes.data, len(kp1), kp2.ctypes.data, len(kp2), mt.ctypes.data, len(mt), int(width),
+                                  int(height), None if g is None else g.ctypes.data, int(disp_ratio), out.ctypes.data,
+                                  C.byref(cnt), C.byref(ssq), C.byref(mx), C.byref(rms))
+    return rc, out, cnt.value, ssq.value, mx.value, rms.value
+
+
+def gather(kp1, kp2, matches):
+    """SfMUtil.cpp:25-35 restated: (rc, coords1 [m, 2], coords2 [m, 2]) float32."""
+    lib = load()
+    kp1 = np.ascontiguousarray(kp1, dtype=KEYPOINT_DTYPE)
+    kp2 = np.ascontiguousarray(kp2, dtype=KEYPOINT_DTYPE)
+    mt = np.ascontiguousarray(matches, dtype=DMATCH_DTYPE)
+    c1 = np.zeros((max(len(mt), 1), 2), dtype=np.float32)
+    c2 = np.zeros((max(len(mt), 1), 2), dtype=np.float32)
+    rc = lib.sfm_ref_gather(kp1.ctypes.data, len(kp1), kp2.ctypes.data, len(kp2), mt.ctypes.data, len(mt), c1.ctypes.data,
+                            c2.ctypes.data)
+    return rc, c1[: len(mt)], c2[: len(mt)]

@@ -138,6 +138,18 @@ class GmsContext:
                                             int(n_frames), d_pairs, int(n_pairs), int(max_query), d_matches),
                self._lib, "gms_bfmatch_device")
 
+    # -- consumers of the filtered matches (DisparityUtil.cpp:179-201, SfMUtil.cpp:25-35) -------------------------------
+    def disparity_device(self, d_kp1, n1, d_kp2, n2, d_matches, d_n_matches, max_matches, width, height, d_gt, disp_ratio,
+                         d_disparity, d_work, d_stats):
+        _check(self._lib.gms_disparity_device(self._h, d_kp1, int(n1), d_kp2, int(n2), d_matches, d_n_matches, int(max_matches),
+                                              int(width), int(height), d_gt or None, int(disp_ratio), d_disparity, d_work,
+                                              d_stats), self._lib, "gms_disparity_device")
+
+    def gather_points_device(self, d_kp1, n1, d_kp2, n2, d_matches, d_n_matches, max_matches, d_coords1, d_coords2, d_status):
+        _check(self._lib.gms_gather_points_device(self._h, d_kp1, int(n1), d_kp2, int(n2), d_matches, d_n_matches,
+                                                  int(max_matches), d_coords1, d_coords2, d_status),
+               self._lib, "gms_gather_points_device")
+
     def selftest_threshold(self, T, n, score, factor):
         T = np.ascontiguousarray(T, dtype=np.int32)
         n = np.ascontiguousarray(n, dtype=np.int32)

@@ -708,6 +708,34 @@ int gms_bfmatch_device(gms_ctx* c, int desc_kind, const void* d_desc, const void
     return GMS_OK;
 }
 
+int gms_disparity_device(gms_ctx* c, const gms_keypoint* d_kp1, int n1, const gms_keypoint* d_kp2, int n2,
+                         const gms_dmatch* d_matches, const int32_t* d_n_matches, int max_matches, int width, int height,
+                         const uint8_t* d_gt, int disp_ratio, uint8_t* d_disparity, uint32_t* d_work, gms_disparity_stats* d_stats)
+{
+    if (!c || n1 < 0 || n2 < 0 || max_matches < 0 || width <= 0 || height <= 0) return GMS_ERR_BAD_ARG;
+    if (!d_n_matches || !d_disparity || !d_work || !d_stats || (d_gt && disp_ratio == 0)) return GMS_ERR_BAD_ARG;
+    if (max_matches > 0 && (!d_kp1 || !d_kp2 || !d_matches)) return GMS_ERR_BAD_ARG;
+    if (max_matches >= (1 << 24)) return GMS_ERR_CAPACITY;  // the scatter key keeps the match index in 24 bits
+    std::lock_guard<std::mutex> lock(c->mu);
+    GMS_HIP(hipSetDevice(c->device));
+    GMS_HIP(gms::launch_disparity(d_kp1, n1, d_kp2, n2, d_matches, d_n_matches, max_matches, width, height, d_gt, disp_ratio,
+                                  d_disparity, d_work, d_stats, c->stream));
+    return GMS_OK;
+}
+
+int gms_gather_points_device(gms_ctx* c, const gms_keypoint* d_kp1, int n1, const gms_keypoint* d_kp2, int n2,
+                             const gms_dmatch* d_matches, const int32_t* d_n_matches, int max_matches,
+                             float* d_coords1, float* d_coords2, int32_t* d_status)
+{
+    if (!c || n1 < 0 || n2 < 0 || max_matches < 0 || !d_n_matches || !d_status) return GMS_ERR_BAD_ARG;
+    if (max_matches > 0 && (!d_kp1 || !d_kp2 || !d_matches || !d_coords1 || !d_coords2)) return GMS_ERR_BAD_ARG;
+    std::lock_guard<std::mutex> lock(c->mu);
+    GMS_HIP(hipSetDevice(c->device));
+    GMS_HIP(gms::launch_gather_points(d_kp1, n1, d_kp2, n2, d_matches, d_n_matches, max_matches, d_coords1, d_coords2, d_status,
+                                      c->stream));
+    return GMS_OK;
+}
+
 int gms_selftest_threshold(gms_ctx* c, const int32_t* T, const int32_t* n, const int32_t* score, double factor,
                            int count, uint8_t* out)
 {

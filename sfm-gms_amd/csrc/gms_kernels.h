@@ -71,6 +71,13 @@ size_t     bf_prepared_bytes(int kind, int64_t total, int n_frames);
 hipError_t launch_bf_prepare(const void* d_desc, const int64_t* d_frame_off, int n_frames, int64_t total, void* d_prep, hipStream_t stream);
 hipError_t launch_bf_match(int kind, const void* d_desc, const void* d_prep, int64_t total, const int64_t* d_frame_off, int n_frames,
                            const gms_pair* d_pairs, int n_pairs, int max_query, gms_dmatch* d_matches, hipStream_t stream);
+// consumers of the filtered matches (consumer_kernels.hip)
+hipError_t launch_disparity(const gms_keypoint* d_kp1, int n1, const gms_keypoint* d_kp2, int n2, const gms_dmatch* d_matches,
+                            const int32_t* d_n_matches, int max_matches, int w, int h, const uint8_t* d_gt, int disp_ratio,
+                            uint8_t* d_disparity, uint32_t* d_work, gms_disparity_stats* d_stats, hipStream_t stream);
+hipError_t launch_gather_points(const gms_keypoint* d_kp1, int n1, const gms_keypoint* d_kp2, int n2, const gms_dmatch* d_matches,
+                                const int32_t* d_n_matches, int max_matches, float* d_coords1, float* d_coords2, int32_t* d_status,
+                                hipStream_t stream);
 hipError_t launch_threshold(const int32_t* d_T, const int32_t* d_n, const int32_t* d_score, double factor,
                             int count, uint8_t* d_out, hipStream_t stream);
 

@@ -24,3 +24,7 @@ class GmsError(RuntimeError):
 
 # descriptor kinds of the brute-force matcher (include/gms.h)
 GMS_DESC_HAMMING256, GMS_DESC_L2_F32X128 = 0, 1
+
+# gms_disparity_stats (include/gms.h)
+DISPARITY_STATS_DTYPE = np.dtype([("count", "<i8"), ("sum_sq", "<i8"), ("max_abs", "<i4"), ("status", "<i4")])
+assert DISPARITY_STATS_DTYPE.itemsize == 24

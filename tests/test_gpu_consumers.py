@@ -1,0 +1,116 @@
+"""-m gpu: the consumers of the filtered matches (gms_disparity_device, gms_gather_points_device) against the restated
+reference loops, on the survivors exactly as gms_filter_device leaves them in HBM. Integer / verbatim-copy work: bit-exact."""
+import importlib
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _dense_case(synth, w=450, h=375, seed=3):
+    """DisparityUtil.cpp:123-133: one keypoint per pixel, column-major like the reference's loops (i over cols, j over rows)."""
+    xs, ys = np.meshgrid(np.arange(w), np.arange(h), indexing="ij")
+    xy1 = np.stack([xs.ravel(), ys.ravel()], axis=1).astype(np.float32)
+    rng = np.random.default_rng(seed)
+    disp = 12.0 + 6.0 * np.sin(xy1[:, 1] / 40.0)
+    tx = np.clip(np.rint(xy1[:, 0] - disp), 0, w - 1).astype(np.int64)
+    train = (tx * h + ys.ravel()).astype(np.int64)
+    bad = rng.uniform(size=len(train)) < 0.3
+    train[bad] = rng.integers(0, len(train), int(bad.sum()))
+    gt = np.clip(np.rint((12.0 + 6.0 * np.sin(np.arange(h)[:, None] / 40.0)) * 4.0 + rng.integers(-3, 4, (h, w))), 0, 255).astype(np.uint8)
+    return dict(size=(w, h), kp1=synth.make_keypoints(xy1), kp2=synth.make_keypoints(xy1.copy()),
+                matches=synth.make_matches(np.arange(len(xy1)), train, rng), gt=gt)
+
+
+def _run(ctx, pkg, oracle, c, filtered=True):
+    import torch
+    batch = importlib.import_module("sfm-gms_amd.batch")
+    types = importlib.import_module("sfm-gms_amd.types")
+    w, h = c["size"]
+    table = batch.FrameTable(ctx, [c["kp1"], c["kp2"]], [c["size"], c["size"]])
+    dev = table.device
+    n1, n2, m = len(c["kp1"]), len(c["kp2"]), len(c["matches"])
+    pairs = np.zeros(1, dtype=pkg.PAIR_DTYPE)
+    pairs[0] = (0, 1, m, 0, 0)
+    d_pairs = batch._to_dev(pairs, dev)
+    d_matches = batch._to_dev(c["matches"], dev)
+    d_out = torch.zeros(max(m, 1) * 16, dtype=torch.uint8, device=dev)
+    d_res = torch.zeros(16, dtype=torch.uint8, device=dev)
+    if filtered:
+        ctx.filter_device(table.d_pts.data_ptr(), table.d_frame_off.data_ptr(), 2, d_pairs.data_ptr(), 1, m, d_matches.data_ptr(),
+                          d_out.data_ptr(), d_res.data_ptr(), None, False, False, 6.0)
+        src, d_n = d_out, d_res          # n_inliers is the first int of the result record
+    else:
+        src = d_matches
+        d_n = torch.tensor([m], dtype=torch.int32, device=dev)
+    kp_bytes = types.KEYPOINT_DTYPE.itemsize
+    d_kp1 = table.d_kp.data_ptr()
+    d_kp2 = table.d_kp.data_ptr() + n1 * kp_bytes
+    d_gt = torch.from_numpy(c["gt"]).to(dev) if c.get("gt") is not None else None
+    d_disp = torch.zeros(w * h, dtype=torch.uint8, device=dev)
+    d_work = torch.zeros(w * h, dtype=torch.int32, device=dev)
+    d_stats = torch.zeros(24, dtype=torch.uint8, device=dev)
+    d_c1 = torch.zeros(max(m, 1) * 2, dtype=torch.float32, device=dev)
+    d_c2 = torch.zeros(max(m, 1) * 2, dtype=torch.float32, device=dev)
+    d_st = torch.full((1,), 77, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    ctx.disparity_device(d_kp1, n1, d_kp2, n2, src.data_ptr(), d_n.data_ptr(), m, w, h, d_gt.data_ptr() if d_gt is not None else None,
+                         c.get("ratio", 4), d_disp.data_ptr(), d_work.data_ptr(), d_stats.data_ptr())
+    ctx.gather_points_device(d_kp1, n1, d_kp2, n2, src.data_ptr(), d_n.data_ptr(), m, d_c1.data_ptr(), d_c2.data_ptr(), d_st.data_ptr())
+    ctx.synchronize()
+    n = int(d_n.cpu().numpy().view(np.int32)[0])
+    kept = src.cpu().numpy().view(pkg.DMATCH_DTYPE)[:n]
+    stats = d_stats.cpu().numpy().view(types.DISPARITY_STATS_DTYPE)[0]
+    return kept, d_disp.cpu().numpy().reshape(h, w), stats, d_c1.cpu().numpy().reshape(-1, 2)[:n], d_c2.cpu().numpy().reshape(-1, 2)[:n], int(d_st.item())
+
+
+def test_dense_disparity_450x375_after_the_filter(ctx, pkg, oracle, synth):
+    c = _dense_case(synth)
+    kept, disp, stats, c1, c2, st = _run(ctx, pkg, oracle, c)
+    rc, want_kept, _, _ = oracle.match(c["size"], c["size"], c["kp1"], c["kp2"], c["matches"], False, False, 6.0)
+    assert rc == 0 and kept.tobytes() == want_kept.tobytes() and len(kept) > 50000
+    rc, wdisp, cnt, ssq, mx, rms = oracle.disparity(c["kp1"], c["kp2"], kept, *c["size"], c["gt"], 4)
+    assert rc == 0 and np.array_equal(disp, wdisp)
+    assert (int(stats["count"]), int(stats["sum_sq"]), int(stats["max_abs"]), int(stats["status"])) == (cnt, ssq, mx, 0)
+    assert np.sqrt(float(stats["sum_sq"]) / float(stats["count"])) == rms      # DisparityUtil.cpp:201
+    rc, w1, w2 = oracle.gather(c["kp1"], c["kp2"], kept)
+    assert rc == 0 and st == 0 and c1.tobytes() == w1.tobytes() and c2.tobytes() == w2.tobytes()
+
+
+def test_sparse_matches_sharing_pixels_last_match_wins(ctx, pkg, oracle, synth):
+    rng = np.random.default_rng(8)
+    w, h, n = 64, 48, 6000       # 6000 keypoints on 3072 pixels: most pixels receive several matches
+    xy1 = np.stack([rng.uniform(0, w, n), rng.uniform(0, h, n)], axis=1).astype(np.float32)
+    xy2 = np.stack([rng.uniform(0, 600, n), rng.uniform(0, h, n)], axis=1).astype(np.float32)   # differences beyond 255 wrap
+    xy1 = np.minimum(xy1, np.array([w - 0.01, h - 0.01], dtype=np.float32))
+    c = dict(size=(w, h), kp1=synth.make_keypoints(xy1), kp2=synth.make_keypoints(xy2),
+             matches=synth.make_matches(rng.integers(0, n, 9000), rng.integers(0, n, 9000), rng),
+             gt=rng.integers(0, 256, (h, w)).astype(np.uint8), ratio=3)
+    kept, disp, stats, c1, c2, st = _run(ctx, pkg, oracle, c, filtered=False)
+    rc, wdisp, cnt, ssq, mx, rms = oracle.disparity(c["kp1"], c["kp2"], c["matches"], w, h, c["gt"], 3)
+    assert rc == 0 and np.array_equal(disp, wdisp) and (int(stats["count"]), int(stats["sum_sq"]), int(stats["max_abs"])) == (cnt, ssq, mx)
+    rc, w1, w2 = oracle.gather(c["kp1"], c["kp2"], c["matches"])
+    assert c1.tobytes() == w1.tobytes() and c2.tobytes() == w2.tobytes() and st == 0
+
+
+def test_no_ground_truth_no_matches_and_domain_errors(ctx, pkg, oracle, synth):
+    rng = np.random.default_rng(9)
+    w, h = 32, 32
+    xy = rng.uniform(0, 31.9, (50, 2)).astype(np.float32)
+    base = dict(size=(w, h), kp1=synth.make_keypoints(xy), kp2=synth.make_keypoints(xy.copy()),
+                matches=synth.make_matches(np.arange(50), np.arange(50), rng), gt=None)
+    kept, disp, stats, c1, c2, st = _run(ctx, pkg, oracle, base, filtered=False)
+    rc, wdisp, *_ = oracle.disparity(base["kp1"], base["kp2"], base["matches"], w, h, None, 1)
+    assert np.array_equal(disp, wdisp) and int(stats["count"]) == 0 and int(stats["status"]) == 0
+    empty = dict(base, matches=base["matches"][:0])
+    kept, disp, stats, c1, c2, st = _run(ctx, pkg, oracle, empty, filtered=False)
+    assert (disp == 255).all() and len(c1) == 0 and st == 0
+    bad = base["matches"].copy()
+    bad["trainIdx"][7] = 50
+    kept, disp, stats, c1, c2, st = _run(ctx, pkg, oracle, dict(base, matches=bad), filtered=False)
+    assert int(stats["status"]) == -2 and st == -2
+    far = xy.copy()
+    far[3, 0] = 40.0             # lands outside the 32-pixel-wide map
+    kept, disp, stats, c1, c2, st = _run(ctx, pkg, oracle, dict(base, kp1=synth.make_keypoints(far)), filtered=False)
+    assert int(stats["status"]) == -2 and st == 0
