@@ -118,7 +118,12 @@ int  gms_ctx_reserve(gms_ctx* ctx, int n_pairs, int max_m, int with_rotation, in
  *
  * gms_normalize_device: GMSMatcher::normalizePoints (DLL@0x180048420) for every keypoint of every
  * frame: d_pts[2*i] = kp[i].x / (float)w[frame], d_pts[2*i+1] = kp[i].y / (float)h[frame]
- * (IEEE fp32 divide). d_frame_off has n_frames+1 entries (keypoint offsets), d_wh 2*n_frames ints. */
+ * (IEEE fp32 divide). d_frame_off has n_frames+1 entries (keypoint offsets), d_wh 2*n_frames ints.
+ * d_pts is the frame table the filter works from and needs gms_frame_table_bytes(total_kp) bytes (16 per keypoint + 16):
+ * the normalised points (8 bytes each), then two 32-bit cell-code words per keypoint -- everything about a keypoint that does
+ * not depend on the pair it is matched in (its cells on the left grid's four half-cell shifted types and on the right grids of
+ * setScale) is worked out once per frame here, not once per pair. Opaque beyond the points; always pass it back whole. */
+int64_t gms_frame_table_bytes(int64_t total_kp);
 int gms_normalize_device(gms_ctx* ctx, const gms_keypoint* d_kp, const int64_t* d_frame_off,
                          const int32_t* d_wh, int n_frames, int64_t total_kp, float* d_pts);
 

@@ -113,6 +113,9 @@ class GmsContext:
         _check(self._lib.gms_ctx_reserve(self._h, int(n_pairs), int(max_m), int(bool(withRotation)), int(bool(withScale))),
                self._lib, "gms_ctx_reserve")
 
+    def frame_table_bytes(self, total_kp):
+        return int(self._lib.gms_frame_table_bytes(int(total_kp)))
+
     def normalize_device(self, d_kp, d_frame_off, d_wh, n_frames, total_kp, d_pts):
         _check(self._lib.gms_normalize_device(self._h, d_kp, d_frame_off, d_wh, int(n_frames), int(total_kp), d_pts),
                self._lib, "gms_normalize_device")

@@ -34,7 +34,8 @@ class FrameTable:
         self.d_kp = _to_dev(kp_all, self.device)
         self.d_frame_off = torch.from_numpy(self.frame_off_host).to(self.device)
         self.d_wh = torch.from_numpy(wh.reshape(-1).copy()).to(self.device)
-        self.d_pts = torch.empty(max(2 * self.total, 2), dtype=torch.float32, device=self.device)
+        # the frame table: normalised points, then the per-keypoint cell codes (gms_frame_table_bytes)
+        self.d_pts = torch.zeros(ctx.frame_table_bytes(self.total) // 4, dtype=torch.float32, device=self.device)
         torch.cuda.synchronize(self.device)
         ctx.normalize_device(self.d_kp.data_ptr(), self.d_frame_off.data_ptr(), self.d_wh.data_ptr(),
                              self.n_frames, self.total, self.d_pts.data_ptr())

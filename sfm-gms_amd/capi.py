@@ -7,7 +7,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # Every symbol include/gms.h declares; tests check the built library exports all of them.
 EXPORTED_SYMBOLS = [
     "gms_match", "gms_match_ctx", "gms_ctx_create", "gms_ctx_destroy", "gms_ctx_set_stream",
-    "gms_ctx_synchronize", "gms_ctx_reserve", "gms_normalize_device", "gms_filter_device",
+    "gms_ctx_synchronize", "gms_ctx_reserve", "gms_frame_table_bytes", "gms_normalize_device", "gms_filter_device",
     "gms_filter_host_batch", "gms_bf_prepared_bytes", "gms_bf_prepare_device", "gms_bfmatch_device", "gms_disparity_device",
     "gms_gather_points_device", "gms_max_matches",
     "gms_last_hip_error", "gms_error_string", "gms_version", "gms_selftest_threshold",
@@ -65,5 +65,7 @@ def load_library():
         if name not in ("gms_error_string", "gms_version"):
             getattr(lib, name).restype = i32
     lib.gms_bf_prepared_bytes.restype = i64
+    lib.gms_frame_table_bytes.argtypes = [i64]
+    lib.gms_frame_table_bytes.restype = i64
     _lib = lib
     return lib

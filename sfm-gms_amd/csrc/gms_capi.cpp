@@ -424,6 +424,8 @@ int gms_ctx_reserve(gms_ctx* c, int n_pairs, int max_m, int with_rotation, int w
     return grow_workspace(c, w, c->stream);
 }
 
+int64_t gms_frame_table_bytes(int64_t total_kp) { return total_kp < 0 ? 0 : total_kp * 16 + 16; }
+
 int gms_normalize_device(gms_ctx* c, const gms_keypoint* d_kp, const int64_t* d_frame_off,
                          const int32_t* d_wh, int n_frames, int64_t total_kp, float* d_pts)
 {
@@ -480,10 +482,10 @@ int gms_match_ctx(gms_ctx* c, const gms_keypoint* kp1, int n1, int w1, int h1,
     GMS_HIP(L.hout.reserve(out_bytes));
     // (a DevBuf that grows frees its old block: earlier work of this lane is complete -- every host-pointer call ends
     // synchronised -- unless the caller switched streams in between, which the synchronize below covers)
-    if (in_bytes > L.din.cap || out_bytes > L.dout.cap || nkp * 8 > c->tab_pts.cap) GMS_HIP(hipDeviceSynchronize());
+    if (in_bytes > L.din.cap || out_bytes > L.dout.cap || nkp * 16 + 16 > c->tab_pts.cap) GMS_HIP(hipDeviceSynchronize());
     GMS_HIP(L.din.reserve(in_bytes));
     GMS_HIP(L.dout.reserve(out_bytes));
-    GMS_HIP(c->tab_pts.reserve(nkp * 8));
+    GMS_HIP(c->tab_pts.reserve(nkp * 16 + 16));
     char* hin = (char*)L.hin.p;
     const CallHeader hdr = {{0, n1, (int64_t)n1 + n2}, {w1, h1, w2, h2}, {0, 1, m, 0, 0}};
     std::memcpy(hin, &hdr, sizeof hdr);
@@ -604,7 +606,7 @@ int gms_filter_host_batch(gms_ctx* c, const gms_keypoint* kp, const int64_t* fra
     // ---- the frame table: (pt.x, pt.y) of every keypoint through pinned memory in pieces, then normalizePoints on the GPU
     const size_t small_bytes = align16((size_t)(n_frames + 1) * 8) + (size_t)n_frames * 8;
     GMS_HIP(c->tab_kp.reserve((size_t)total_kp * 8));
-    GMS_HIP(c->tab_pts.reserve((size_t)total_kp * 8));
+    GMS_HIP(c->tab_pts.reserve((size_t)total_kp * 16 + 16));
     GMS_HIP(c->tab_small.reserve(small_bytes));
     {
         hipStream_t st = c->lane[0].stream;

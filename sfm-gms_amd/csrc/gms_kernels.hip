@@ -148,10 +148,50 @@ __device__ __forceinline__ uint32_t region_lookup_general(const uint32_t* tab, u
 // A -0.0 result is stored as +0.0 (adding +0.0f): every later use is floor(n * W), which is 0 for
 // both, and it lets the filter test "finite, non-negative" on the bit pattern alone.
 // ------------------------------------------------------------------------------------------------
+// dense code word
+                                                     // bits 0..4   q = (hx & 1) + 20 * (hy & 1)
+constexpr uint32_t kDNever = 1u << 5;                // bit 5       not binned under any grid type
+constexpr uint32_t kDEdgeX = 1u << 6;                // bit 6       hx == 39: x >= 20 under the x-shifted grid types
+constexpr uint32_t kDEdgeY = 1u << 7;                // bit 7       hy == 39
+constexpr int kDEShift = 8;                          // bits 8..16  E(r) = 403 - r, the byte's offset in its row
+constexpr uint32_t kDEMask = 0x1FFu;
+constexpr int kDAccShift = 17;                       // bits 17..24 inlier-under-rotation bits (one bit without rotation)
+constexpr int kDTagShift = 20;                       // arg-max key in a row header: grid type << 20 | (count - 1) << 11 | E(j)
+constexpr int kDCellShift = 18;                      // without rotation only, bits 18..26: the left cell under grid type 1
+                                                     // (with rotation it has a register of its own, as a row offset)
+
+// Besides the normalised point, everything about a keypoint that does not depend on the pair it is matched in is worked out
+// here, once per frame (a frame of a sequence is filtered against hundreds of others): two code words per keypoint.
+//   lcode  the keypoint as a LEFT point: the dense code word's left part (see kDNever .. kDCellShift below) -- half-cell parities
+//          q, the "x / y >= 20 under the shifted grid" edge bits, the cell under grid type 1 -- or kDNever when it is never binned;
+//   rcode  the keypoint as a RIGHT point: E(r) = 403 - r of scale 0 (0 = outside the 20 x 20 grid), its cell coordinates on the
+//          40 x 40 and 28 x 28 grids (fl(40 n) = 2 fl(20 n) and fl(20 n) = 2 fl(10 n) exactly, likewise 28 / 14: the five right
+//          grids of setScale are these two families; a coordinate at or above the field's grid size = outside that family's grids).
+// Bit 31 of either: the point is outside the parity domain (negative, non-finite or >= 2^20 after normalisation).
+constexpr uint32_t kCodeBad = 1u << 31;
+__device__ __forceinline__ void keypoint_codes(float2 n, uint32_t& lcode, uint32_t& rcode)
+{
+    const bool bad = max(__float_as_uint(n.x), __float_as_uint(n.y)) >= 0x49800000u;
+    const float x = bad ? 0.0f : n.x, y = bad ? 0.0f : n.y;
+    const float fx = 20.0f * x, fy = 20.0f * y;                                  // mulss, rounded to fp32 (DLL@0x180047bc0)
+    const uint32_t hx = (uint32_t)(int)(fx + fx), hy = (uint32_t)(int)(fy + fy);  // floor(2 f): carries all four grid types
+    const uint32_t q = (hx & 1u) + 20u * (hy & 1u);
+    const uint32_t edge = (hx == 39u ? kDEdgeX : 0u) | (hy == 39u ? kDEdgeY : 0u);
+    const uint32_t l1 = (hy >> 1) * (uint32_t)kLeftW + (hx >> 1);
+    lcode = (max(hx, hy) < 40u ? (q | edge | (l1 << kDCellShift)) : kDNever) | (bad ? kCodeBad : 0u);
+    const uint32_t r0x = (uint32_t)(int)fx, r0y = (uint32_t)(int)fy;              // getGridIndexRight, 20 x 20 (DLL@0x180047d60)
+    const uint32_t e0 = (r0x < 20u && r0y < 20u) ? 403u - (r0y * 20u + r0x) : 0u;
+    const uint32_t r4x = min((uint32_t)(int)(40.0f * x), 63u), r4y = min((uint32_t)(int)(40.0f * y), 63u);
+    const uint32_t r3x = min((uint32_t)(int)(28.0f * x), 31u), r3y = min((uint32_t)(int)(28.0f * y), 31u);
+    rcode = e0 | (r4x << 9) | (r4y << 15) | (r3x << 21) | (r3y << 26) | (bad ? kCodeBad : 0u);
+}
+
 __global__ void __launch_bounds__(256)
 normalize_kernel(const char* __restrict__ kp, int kp_stride, const int64_t* __restrict__ frame_off,
                  const int32_t* __restrict__ wh, int n_frames, int64_t total, float2* __restrict__ pts)
 {
+    uint32_t* __restrict__ lcode = reinterpret_cast<uint32_t*>(pts + total);
+    uint32_t* __restrict__ rcode = lcode + total;
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (; i < total; i += stride) {
@@ -166,6 +206,10 @@ normalize_kernel(const char* __restrict__ kp, int kp_stride, const int64_t* __re
         o.x = p[0] / w + 0.0f;  // IEEE fp32 divide (divss)
         o.y = p[1] / h + 0.0f;
         pts[i] = o;
+        uint32_t lc, rc;
+        keypoint_codes(o, lc, rc);
+        lcode[i] = lc;
+        rcode[i] = rc;
     }
 }
 
@@ -774,18 +818,6 @@ constexpr uint32_t kDenseLdsBytes = kDenseTrashOff + 4u * 16u;  // 163 792
 static_assert(kDenseLdsBytes <= kLdsBytes, "dense layout exceeds the LDS");
 static_assert(kDenseBytes % 16 == 0 && kDenseRow % 4 == 0, "rows are dword aligned, the matrix is cleared in uint4s");
 
-// dense code word
-                                                     // bits 0..4   q = (hx & 1) + 20 * (hy & 1)
-constexpr uint32_t kDNever = 1u << 5;                // bit 5       not binned under any grid type
-constexpr uint32_t kDEdgeX = 1u << 6;                // bit 6       hx == 39: x >= 20 under the x-shifted grid types
-constexpr uint32_t kDEdgeY = 1u << 7;                // bit 7       hy == 39
-constexpr int kDEShift = 8;                          // bits 8..16  E(r) = 403 - r, the byte's offset in its row
-constexpr uint32_t kDEMask = 0x1FFu;
-constexpr int kDAccShift = 17;                       // bits 17..24 inlier-under-rotation bits (one bit without rotation)
-constexpr int kDTagShift = 20;                       // arg-max key in a row header: grid type << 20 | (count - 1) << 11 | E(j)
-constexpr int kDCellShift = 18;                      // without rotation only, bits 18..26: the left cell under grid type 1
-                                                     // (with rotation it has a register of its own, as a row offset)
-
 // The threshold test of the byte-matrix path: T <= 9 * 255, score <= 9 * 255, n <= 9. For an integer factor up to 1023
 // (the reference's default is 6) T * factor^2 and score^2 * n are exact 32-bit integers; when they differ, they differ by
 // at least 1 in about 2^32, far more than the reference's three fp64 roundings can move thresh, so their order is the
@@ -819,6 +851,23 @@ __device__ __forceinline__ uint32_t dense_nleft(const uint8_t* nfine8, int x, in
     return n;
 }
 
+// The same for dense_pair's histogram, which is laid out by cell: one dword per cell of grid type 1, its four half cells in the
+// four bytes (byte index (hx & 1) + 2 (hy & 1)) -- the index a left code word yields without arithmetic.
+__device__ __forceinline__ uint32_t dense_nleft_cm(const uint8_t* nfine8, int x, int y, int gx, int gy)
+{
+    const int hx0 = 2 * x - gx, hy0 = 2 * y - gy;
+    uint32_t n = 0;
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 2; ++dx) {
+            const int hx = max(hx0 + dx, 0), hy = max(hy0 + dy, 0);
+            const uint32_t v = nfine8[(((hy >> 1) * kLeftW + (hx >> 1)) << 2) + (hx & 1) + ((hy & 1) << 1)];
+            n += (hx0 + dx >= 0 && hy0 + dy >= 0) ? v : 0u;
+        }
+    return n;
+}
+
 // false (workgroup-uniform, nothing written to global memory): the pair has to take the general path
 template <int KPT, bool ROT, int NT>
 __device__ __forceinline__ bool dense_pair(const FilterParams& p, uint32_t* smem, const int pair_idx, const int tid)
@@ -838,13 +887,14 @@ __device__ __forceinline__ bool dense_pair(const FilterParams& p, uint32_t* smem
     const int64_t offA = p.frame_off[pr.frame_a], offB = p.frame_off[pr.frame_b];
     const int nA = (int)(p.frame_off[pr.frame_a + 1] - offA), nB = (int)(p.frame_off[pr.frame_b + 1] - offB);
     if (nA <= 0 || nB <= 0) return false;
-    const bool stage_b = (uint32_t)nB * 8u <= kDenseBytes;  // workgroup-uniform: frame B fits the (still unused) matrix area
-    const float2* __restrict__ ptsA = p.pts + offA;
-    const float2* __restrict__ ptsB = p.pts + offB;
     const gms_dmatch* __restrict__ matches = p.matches + pr.match_off;
+    // the frame table's code words (written by normalize_kernel behind the points): frame A's left codes, frame B's right codes
+    const int64_t total_kp = p.frame_off[p.n_frames];
+    const uint32_t* __restrict__ lcodeA = reinterpret_cast<const uint32_t*>(p.pts + total_kp) + offA;
+    const uint32_t* __restrict__ rcodeB = reinterpret_cast<const uint32_t*>(p.pts + total_kp) + total_kp + offB;
 
     const uint8_t* dense8 = reinterpret_cast<const uint8_t*>(smem);
-    uint32_t* nfine32 = smem + kDenseFineOff / 4;   // 40 x 40 byte counters, four to a dword
+    uint32_t* nfine32 = smem + kDenseFineOff / 4;   // half-cell histogram: one dword per cell of grid type 1, a byte per half cell
     const uint8_t* nfine8 = reinterpret_cast<const uint8_t*>(nfine32);
     uint8_t* nleft8 = reinterpret_cast<uint8_t*>(smem) + kDenseNleftOff;
     uint32_t* misc = smem + kDenseMiscOff / 4;
@@ -858,16 +908,22 @@ __device__ __forceinline__ bool dense_pair(const FilterParams& p, uint32_t* smem
     if (tid < 16) trash[tid] = 0;
     if (tid < kFineN / 4) nfine32[tid] = 0;
 
-    // ---- the pair's DMatch records, whole (they stay in registers until copy-out), and frame B staged in the
-    //      still unused matrix area for the train-side gather
-    // Frame B's points are requested first and the records right behind them (loads return in order): the staged frame is
-    // complete -- and the barrier passed -- while the later records are still on their way, and binning starts on the
-    // first records as they land instead of behind all of them.
-    constexpr int kStageRegs = 10;  // 10 240 keypoints through registers; larger frames finish in a plain loop
-    float2 tb[kStageRegs];
-    if (stage_b) {
+    // ---- both frames' code words staged in the still unused matrix area (coalesced 16-byte loads from 16-byte aligned addresses:
+    //      a frame starts anywhere in the table, so the copy keeps the source's phase and look-ups add it), then the pair's DMatch
+    //      records, whole (they stay in registers until copy-out). Loads return in order: the staged codes are complete -- and the
+    //      barrier passed -- while the later records are still on their way.
+    const uint32_t phA = (uint32_t)(reinterpret_cast<uintptr_t>(lcodeA) >> 2) & 3u, phB = (uint32_t)(reinterpret_cast<uintptr_t>(rcodeB) >> 2) & 3u;
+    const uint32_t qA = (phA + (uint32_t)nA + 3u) >> 2, qB = (phB + (uint32_t)nB + 3u) >> 2;  // uint4s of either copy
+    const bool staged = (qA + qB) * 16u <= kDenseBytes;  // workgroup-uniform: both fit (20 200 keypoints a frame, say)
+    const uint4* __restrict__ srcA = reinterpret_cast<const uint4*>(lcodeA - phA);
+    const uint4* __restrict__ srcB = reinterpret_cast<const uint4*>(rcodeB - phB);
+    constexpr int kStageRegs = 5;  // 20 480 code words through registers; larger frames finish in a plain loop
+    uint4 tb[kStageRegs];
 #pragma unroll
-        for (int i = 0; i < kStageRegs; ++i) tb[i] = ptsB[min(i * NT + tid, nB - 1)];
+    for (int i = 0; i < kStageRegs; ++i) {  // (unconditional: a pair too large to stage just reads a few code words it does not use)
+        const uint32_t j = min((uint32_t)(i * NT + tid), qA + qB - 1u);
+        const uint4* src = j < qA ? srcA + j : srcB + (j - qA);  // one load either way: select the address, not the data
+        tb[i] = *src;
     }
     // Up to 10 matches per thread the whole 16-byte records stay in registers until copy-out (the match array is read
     // once); at 16 per thread that would be 64 registers of a 128-register budget, so there only (queryIdx, trainIdx)
@@ -882,26 +938,26 @@ __device__ __forceinline__ bool dense_pair(const FilterParams& p, uint32_t* smem
     }
     auto query_of = [&](int k) -> uint32_t { return kKeepRec ? rec[k].x : qt[k].x; };
     auto train_of = [&](int k) -> uint32_t { return kKeepRec ? rec[k].y : qt[k].y; };
-    // motion.setTo(0) for the part of the matrix area that frame B does not occupy: now, while the loads are in flight
-    const uint32_t staged16 = stage_b ? ((uint32_t)nB * 8u + 15u) >> 4 : 0u;  // uint4s holding the staged frame
+    // motion.setTo(0) for the part of the matrix area that the staged codes do not occupy: now, while the loads are in flight
+    const uint32_t staged16 = staged ? qA + qB : 0u;
     {
         const uint4 z4 = make_uint4(0, 0, 0, 0);
         uint4* d4 = reinterpret_cast<uint4*>(smem);
         for (uint32_t i = staged16 + tid; i < kDenseBytes / 16; i += NT) d4[i] = z4;
     }
-    float2* lds_b = reinterpret_cast<float2*>(smem);
-    if (stage_b) {
+    if (staged) {
+        uint4* d4 = reinterpret_cast<uint4*>(smem);
 #pragma unroll
         for (int i = 0; i < kStageRegs; ++i)
-            if (i * NT + tid < nB) lds_b[i * NT + tid] = tb[i];
-        for (int j = kStageRegs * NT + tid; j < nB; j += NT) lds_b[j] = ptsB[j];
+            if ((uint32_t)(i * NT + tid) < qA + qB) d4[i * NT + tid] = tb[i];
+        for (uint32_t j = kStageRegs * NT + tid; j < qA + qB; j += NT) d4[j] = *(j < qA ? srcA + j : srcB + (j - qA));
     }
+    const uint32_t* ldsA = smem + phA;            // left code of frame A's keypoint q at ldsA[q]
+    const uint32_t* ldsB = smem + 4u * qA + phB;  // right code of frame B's keypoint t at ldsB[t]
     __syncthreads();
-    // the left-side gathers below are global loads and return behind the records whatever their issue time: wait for the
-    // records once, so that the gathers go out together instead of one round trip per record
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #ifdef GMS_PHASE_TIMING
-    GMS_STAMP(4);  // bin: records landed, frame B staged
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    GMS_STAMP(4);  // bin: records landed, codes staged
     ph_[15] = wall_clock64();
 #endif
 
@@ -914,15 +970,17 @@ __device__ __forceinline__ bool dense_pair(const FilterParams& p, uint32_t* smem
         return __umul24(cw & q_mask, kDenseRow) + row1[k];
     };
     {
-        float2 a[KPT], b[KPT];
+        uint32_t ca[KPT], cb[KPT];
+        if (staged) {
 #pragma unroll
-        for (int k = 0; k < KPT; ++k) a[k] = ptsA[min(query_of(k), (uint32_t)(nA - 1))];
-        if (stage_b) {
+            for (int k = 0; k < KPT; ++k) ca[k] = ldsA[min(query_of(k), (uint32_t)(nA - 1))];
 #pragma unroll
-            for (int k = 0; k < KPT; ++k) b[k] = lds_b[min(train_of(k), (uint32_t)(nB - 1))];
-        } else {  // a frame above 20 200 keypoints: the train-side gather goes to global memory like the query side
+            for (int k = 0; k < KPT; ++k) cb[k] = ldsB[min(train_of(k), (uint32_t)(nB - 1))];
+        } else {  // frames too large to stage: both gathers go to global memory
 #pragma unroll
-            for (int k = 0; k < KPT; ++k) b[k] = ptsB[min(train_of(k), (uint32_t)(nB - 1))];
+            for (int k = 0; k < KPT; ++k) ca[k] = lcodeA[min(query_of(k), (uint32_t)(nA - 1))];
+#pragma unroll
+            for (int k = 0; k < KPT; ++k) cb[k] = rcodeB[min(train_of(k), (uint32_t)(nB - 1))];
         }
 #ifdef GMS_PHASE_TIMING
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -932,29 +990,18 @@ __device__ __forceinline__ bool dense_pair(const FilterParams& p, uint32_t* smem
 #pragma unroll
         for (int k = 0; k < KPT; ++k) {
             const bool live = k * NT + tid < m;
-            // parity domain: coordinates finite, non-negative, < 2^20 (one unsigned compare on the bit patterns)
-            const uint32_t worst = max(max(__float_as_uint(a[k].x), __float_as_uint(a[k].y)),
-                                       max(__float_as_uint(b[k].x), __float_as_uint(b[k].y)));
-            const float fx = 20.0f * a[k].x, fy = 20.0f * a[k].y;   // mulss, rounded to fp32
-            const uint32_t hx = (uint32_t)(int)(fx + fx), hy = (uint32_t)(int)(fy + fy);  // floor(2f), 2f exact
-            // getGridIndexRight: x + y * 20, no bounds test in the reference. Both terms are below 2^25 inside the parity
-            // domain; clamped to 4096 the 24-bit multiply-add is exact whenever the true value is below 400 and stays
-            // above it otherwise (full-rate instructions instead of a 32-bit multiply)
-            const uint32_t rx = (uint32_t)(int)(20.0f * b[k].x), ry = (uint32_t)(int)(20.0f * b[k].y);
-            const uint32_t r = __umul24(min(ry, 4096u), (uint32_t)kDenseRightW) + min(rx, 4096u);
-            // '&', not '&&': no short-circuit branches
-            const bool ok = ((int)(query_of(k) < (uint32_t)nA) & (int)(train_of(k) < (uint32_t)nB) & (int)(worst < 0x49800000u) & (int)(r < (uint32_t)kDenseRightN)) != 0;
-            const bool binned = live & ok & (max(hx, hy) < 40u);
-            const uint32_t f = binned ? __umul24(hy, (uint32_t)kFineW) + hx : 0u;
-            const uint32_t old = atomicAdd(binned ? &nfine32[f >> 2] : &trash[lane & 7], 1u << ((f << 3) & 31u));
-            spill |= binned & (((old >> ((f << 3) & 31u)) & 255u) == 255u);  // the byte wrapped: > 255 in one half cell
+            const uint32_t e0 = cb[k] & kDEMask;  // E(r) of getGridIndexRight on the 20 x 20 grid, 0 = outside it (no bounds test in the reference)
+            // parity domain: indices in range, both points inside it, the right cell inside its grid ('&', not '&&': no branches)
+            const bool ok = ((int)(query_of(k) < (uint32_t)nA) & (int)(train_of(k) < (uint32_t)nB) & (int)(((ca[k] | cb[k]) & kCodeBad) == 0u) & (int)(e0 != 0u)) != 0;
+            const bool binned = live & ok & ((ca[k] & kDNever) == 0u);
+            // half-cell histogram: dword = the cell under grid type 1, byte = (hx & 1) + 2 (hy & 1); q = (hx & 1) + 20 (hy & 1)
+            const uint32_t cell = (ca[k] >> kDCellShift) & 0x1FFu, sh = ((ca[k] & 1u) << 3) | ((ca[k] & 4u) << 2);
+            const uint32_t old = atomicAdd(binned ? &nfine32[cell] : &trash[lane & 7], 1u << sh);
+            spill |= binned & (((old >> sh) & 255u) == 255u);  // the byte wrapped: > 255 in one half cell
             any_bad |= live & !ok;
-            const uint32_t q = (hx & 1u) + __umul24(hy & 1u, 20u);
-            const uint32_t edge = ((hx + 25u) & kDEdgeX) | ((hy + 89u) & kDEdgeY);  // hx == 39 -> bit 6, hy == 39 -> bit 7 (hx, hy < 40)
-            const uint32_t l1 = __umul24(hy >> 1, (uint32_t)kLeftW) + (hx >> 1);
-            const uint32_t cw = q | edge | (((uint32_t)(kDenseRightN + 3) - r) << kDEShift) | (kPackCell ? l1 << kDCellShift : 0u);
+            const uint32_t cw = (ca[k] & (0xFFu | (kPackCell ? 0x1FFu << kDCellShift : 0u))) | (e0 << kDEShift);
             code[k] = binned ? cw : kDNever;
-            if (!kPackCell) row1[k] = binned ? __umul24(l1, kDenseRow) : 0u;
+            if (!kPackCell) row1[k] = binned ? __umul24(cell, kDenseRow) : 0u;
         }
         if (any_bad) misc[8] = 1;   // benign races: every writer stores 1
         if (spill) misc[13] = 1;  // (its own flag: misc[11] is written again while slower waves may still be reading this one)
@@ -1004,7 +1051,7 @@ __device__ __forceinline__ bool dense_pair(const FilterParams& p, uint32_t* smem
         if (!CROWDED && tid < kLeftN) {
             // nLeft of this grid type, once per cell (read by verify, behind the next barrier); above 255 a row's entries
             // are no longer guaranteed to fit their bytes
-            const uint32_t n = dense_nleft(nfine8, tid % kLeftW, tid / kLeftW, gx, gy);
+            const uint32_t n = dense_nleft_cm(nfine8, tid % kLeftW, tid / kLeftW, gx, gy);
             if (n > 255u) misc[11] = 1;
             nleft8[tid] = (uint8_t)n;
         }

@@ -255,7 +255,7 @@ def test_config3_thousand_frame_table_two_chunks(ctx, pkg, oracle, synth):
     size, n_frames, n_kp, per_chunk = (1920, 1080), 1000, 10000, 1024
     frames = synth.make_sequence(1000, n_frames, size=size, n_kp=n_kp)
     table = batch.FrameTable(ctx, frames, [size] * n_frames)
-    assert table.d_pts.numel() * 4 == 80_000_000
+    assert table.d_pts.numel() * 4 == 160_000_016 and table.total * 8 == 80_000_000   # points: 80 MB, beyond the L2s
     dev = table.device
     kp_all = np.concatenate(frames)
     wh = np.array([size] * n_frames, dtype=np.int32).reshape(-1)
