@@ -1171,7 +1171,9 @@ __device__ __forceinline__ bool dense_pair(const FilterParams& p, uint32_t* smem
                     cr[k] = smem[row >> 2];
                     if (g < 3) {
                         const uint32_t at = row + ((cw >> kDEShift) & kDEMask);
-                        atomicSub(lds_at(smem, at & ~3u), 1u << ((at << 3) & 31u));
+                        // every reader of the entry is past the barrier: all its matches store the same zero (a plain byte store,
+                        // no read-modify-write in the LDS)
+                        reinterpret_cast<uint8_t*>(smem)[at] = 0;
                     }
                 }
             }

@@ -31,20 +31,19 @@ def main():
     diag_path = os.path.join(ROOT, "sfm-gms_amd", "csrc", "libgms_hip_diag.so")
     capi.library_path = lambda: diag_path
     pkg = importlib.import_module("sfm-gms_amd")
-    synth = importlib.import_module("sfm-gms_amd.synth")
     lib = pkg.load_library()
     dev = torch.device("cuda", 0)
     ctx = pkg.GmsContext(0)
     stream = torch.cuda.Stream(device=dev)
     ctx.set_stream(stream.cuda_stream)
-    args = argparse.Namespace(pairs=a.pairs, frames=64, features=a.features, inlier_frac=0.5)
-    wl = bench.build_workload(args, 0, 1, dev, pkg, synth, ctx)
+    args = argparse.Namespace(pairs=a.pairs, frames=200, features=a.features, inlier_frac=0.5, warmup=1, steps=1, max_resident=2)
+    wl = bench.Workload(args, 0, 1, dev, pkg, ctx)
     dbuf = torch.zeros(a.pairs * 16, dtype=torch.int64, device=dev)
     lib.gms_diag_set_buffer.argtypes = [C.c_void_p]
     lib.gms_diag_set_buffer(dbuf.data_ptr())
     for _ in range(3):
         with torch.cuda.stream(stream):
-            bench.launch(ctx, wl, bool(a.rot), bool(a.scale))
+            wl.launch(ctx, 0, bool(a.rot), bool(a.scale))
     torch.cuda.synchronize()
     raw = dbuf.cpu().numpy().reshape(-1, 16)
     if a.starts:
