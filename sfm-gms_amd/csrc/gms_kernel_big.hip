@@ -100,9 +100,11 @@ filter_kernel_big(FilterParams p, uint32_t* ws, size_t ws_stride, int mcap, uint
     uint32_t* nleft4 = nfine + kFineStride;        // [4][400]
     uint32_t* desc4 = nleft4 + 4 * kLeftN;         // [4][400]
     uint32_t* fdesc4 = desc4 + 4 * kLeftN;         // [4][1664]
-    uint32_t* bestmask = fdesc4 + 4 * kFineStride; // mcap / 32
-    uint32_t* chunk_base = bestmask + (mcap >> 5); // mcap / 64 + 1
-    uint32_t* misc = chunk_base + (mcap >> 6) + 1; // [0..7] counts, [8] error, [9] carry, [12..15] allocators, [16..31] scan
+    uint32_t* misc = fdesc4 + 4 * kFineStride;     // [0..7] counts, [8] error, [9] carry, [10] capacity, [12..15] allocators, [16..31] scan
+    // the winner's bit mask and the copy-out scan: in LDS up to kBigLdsMaskMatches matches, behind the table in the slab beyond
+    // (only this workgroup touches them, always across a workgroup barrier)
+    uint32_t* bestmask = mcap <= kBigLdsMaskMatches ? misc + 64 : tab + T;  // mcap / 32
+    uint32_t* chunk_base = bestmask + (mcap >> 5);                          // mcap / 64 + 1
 
     for (int pi = blockIdx.x; pi < p.n_pairs; pi += gridDim.x) {
         if (p.pair_flags && !(p.pair_flags[pi] & 2u)) continue;  // the band kernels (gms_kernel_band.hip) did this pair
@@ -180,6 +182,7 @@ filter_kernel_big(FilterParams p, uint32_t* ws, size_t ws_stride, int mcap, uint
                 }
             const uint32_t nb = region_buckets(n, 0);
             uint32_t d = 0;
+            if (n > kSlotCountMask) misc[10] = 1;  // a table slot counts in 21 bits: more than 2 097 151 matches in ONE left cell
             if (nb) d = (atomicAdd(&misc[12 + g], nb + 1u) << kDescShift) | nb;
             nleft4[item] = n;
             desc4[item] = d;
@@ -324,7 +327,8 @@ filter_kernel_big(FilterParams p, uint32_t* ws, size_t ws_stride, int mcap, uint
         }
 
         // ---- copy-out ------------------------------------------------------------------------------------------
-        const bool failed = misc[8] != 0;
+        const bool too_many = misc[10] != 0;
+        const bool failed = misc[8] != 0 || too_many;
         const int n_chunks = (mm + 63) >> 6;
         {
             uint32_t* wave_tot = misc + 16;
@@ -367,7 +371,7 @@ filter_kernel_big(FilterParams p, uint32_t* ws, size_t ws_stride, int mcap, uint
             r.n_inliers = failed ? 0 : (int)total;
             r.best_scale = failed ? -1 : best_scale;
             r.best_rot = failed ? -1 : best_rot;
-            r.status = failed ? GMS_ERR_DOMAIN : GMS_OK;
+            r.status = too_many ? GMS_ERR_CAPACITY : failed ? GMS_ERR_DOMAIN : GMS_OK;
             p.results[pi] = r;
         }
     }
@@ -376,13 +380,26 @@ filter_kernel_big(FilterParams p, uint32_t* ws, size_t ws_stride, int mcap, uint
 // ------------------------------------------------------------------------------------------------------------
 int big_mcap(int max_m) { return (max_m + 63) & ~63; }
 
-uint32_t big_table_slots(int mcap) { return ((uint32_t)mcap * 2u + 7u * kLeftN + 3u) & ~3u; }
+// a left cell's region never has more than 2048 data buckets + its header (1600 right cells at most), so the table of one grid
+// type never needs more than 400 * 2049 buckets however many matches the pair has -- and the descriptor's 20-bit bucket index holds
+uint32_t big_table_slots(int mcap)
+{
+    const uint64_t want = ((uint64_t)mcap * 2u + 7u * kLeftN + 3u) & ~(uint64_t)3;
+    const uint64_t most = (uint64_t)kLeftN * 2049u * 4u;
+    return (uint32_t)(want < most ? want : most);
+}
 
-size_t big_ws_stride_dwords(int mcap) { return (size_t)mcap + big_table_slots(mcap); }
+static size_t big_mask_dwords(int mcap) { return (size_t)(mcap >> 5) + (size_t)(mcap >> 6) + 1; }
+
+size_t big_ws_stride_dwords(int mcap)
+{
+    const size_t d = (size_t)mcap + big_table_slots(mcap) + (mcap > kBigLdsMaskMatches ? big_mask_dwords(mcap) : 0);
+    return (d + 3) & ~(size_t)3;
+}
 
 size_t big_lds_bytes(int mcap)
 {
-    return ((size_t)kFineStride + 8 * kLeftN + 4 * kFineStride + (mcap >> 5) + (mcap >> 6) + 1 + 64) * 4;
+    return ((size_t)kFineStride + 8 * kLeftN + 4 * kFineStride + 64 + (mcap <= kBigLdsMaskMatches ? big_mask_dwords(mcap) : 0)) * 4;
 }
 
 hipError_t init_big_kernels()  // once per context: see init_filter_kernels

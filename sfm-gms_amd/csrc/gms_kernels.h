@@ -55,7 +55,8 @@ hipError_t launch_normalize(const void* d_kp, int kp_stride_bytes, const int64_t
 hipError_t launch_filter(const FilterParams& p, int kpt, int n_pairs, hipStream_t stream);
 hipError_t launch_filter_scales(const FilterParams& p, int kpt, int n_pairs, hipStream_t stream);
 // large pairs (gms_kernel_big.hip): code words and table in a per-workgroup HBM slab
-constexpr int kBigMaxMatches = 262144;
+constexpr int kBigMaxMatches = 1 << 22;       // per pair: 4 194 304 (a 2594 x 1131 one-keypoint-per-pixel frame of DisparityUtil.cpp:299 has 2.93 M)
+constexpr int kBigLdsMaskMatches = 262144;   // up to here the slab kernel keeps the winner's bit mask in LDS
 int        big_mcap(int max_m);
 size_t     big_ws_stride_dwords(int mcap);
 hipError_t launch_filter_big(const FilterParams& p, int mcap, int n_workgroups, uint32_t* ws, hipStream_t stream);

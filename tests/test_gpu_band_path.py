@@ -227,3 +227,61 @@ def test_tiles_workspace_left_by_a_larger_pair(ctx, oracle):
         small = cases.random_pair(132 + n % 5, n=n, inlier_frac=0.3, theta_deg=90.0, scale=0.5)
         _check(ctx, oracle, small, True, True)
         _check(ctx, oracle, small, True, False)
+
+
+# ---- beyond 262 144 matches per pair (the cap of round 1): the reference's third call site, DisparityUtil.cpp:299, runs matchGMS on
+#      one keypoint per pixel of a 2594 x 1131 image pair -----------------------------------------------------------------------------
+def _per_pixel_case(w, h, seed, bad_frac=0.3):
+    """DisparityUtil.cpp:280-299: keypoints pushed column by column (i over cols, j over rows), M = W * H matches."""
+    xs, ys = np.meshgrid(np.arange(w, dtype=np.float32), np.arange(h, dtype=np.float32), indexing="ij")
+    xy1 = np.stack([xs.ravel(), ys.ravel()], axis=1)
+    rng = np.random.default_rng(seed)
+    disp = np.rint(14.0 + 9.0 * np.sin(xy1[:, 1] / 90.0)).astype(np.int64)
+    tx = np.clip(xy1[:, 0].astype(np.int64) - disp, 0, w - 1)
+    train = tx * h + xy1[:, 1].astype(np.int64)
+    bad = rng.uniform(size=len(train)) < bad_frac
+    train[bad] = rng.integers(0, len(train), int(bad.sum()))
+    m = np.zeros(len(train), dtype=cases.types.DMATCH_DTYPE)
+    m["queryIdx"], m["trainIdx"] = np.arange(len(train)), train
+    m["distance"] = (np.arange(len(train)) % 1000).astype(np.float32)
+    kp = cases.synth.make_keypoints(xy1)
+    return dict(size1=(w, h), size2=(w, h), kp1=kp, kp2=kp.copy(), matches=m)
+
+
+def test_portrait_mode_call_site_2594x1131_per_pixel(ctx, oracle):
+    c = _per_pixel_case(2594, 1131, 4)
+    assert len(c["matches"]) == 2933814
+    assert _check(ctx, oracle, c) > 1500000
+
+
+@pytest.mark.parametrize("rot,scale", [(True, False), (True, True)])
+def test_half_a_million_matches_with_hypotheses(ctx, oracle, rot, scale):
+    c = _per_pixel_case(800, 640, 5)
+    assert _check(ctx, oracle, c, rot, scale) > 200000
+
+
+def test_flagged_pair_beyond_the_lds_mask_limit(ctx, oracle):
+    """90 000 of 400 000 matches in one left cell: the slab kernel takes the pair, its winner mask in the slab instead of LDS."""
+    rng = np.random.default_rng(18)
+    w, h = 2000, 1000
+    n_hot, n_rest = 90000, 310000
+    hot1 = np.stack([rng.uniform(1000, 1099, n_hot), rng.uniform(500, 549, n_hot)], axis=1)
+    rest1 = np.stack([rng.uniform(0, w - 1, n_rest), rng.uniform(0, h - 1, n_rest)], axis=1)
+    xy1 = np.concatenate([hot1, rest1]).astype(np.float32)
+    xy2 = np.clip(xy1 + rng.normal(0, 1.5, xy1.shape), 0, [w - 0.01, h - 0.01]).astype(np.float32)
+    n = n_hot + n_rest
+    c = cases._pair(xy1, xy2, np.arange(n), np.arange(n), (w, h), (w, h))
+    c["matches"] = c["matches"][rng.permutation(n)]
+    for rot, scale in ((False, False), (True, True)):
+        assert _check(ctx, oracle, c, rot, scale) > n_hot
+
+
+def test_more_matches_in_one_cell_than_a_slot_counts(ctx, pkg):
+    """2.2 M matches of one left cell: beyond the 21-bit slot counters of the slab kernel -> GMS_ERR_CAPACITY, not a wrong answer."""
+    n = 2200000
+    xy = np.full((4, 2), 10.0, dtype=np.float32)
+    kp = cases.synth.make_keypoints(xy)
+    m = np.zeros(n, dtype=pkg.DMATCH_DTYPE)
+    with pytest.raises(pkg.GmsError) as e:
+        ctx.match((640, 480), (640, 480), kp, kp.copy(), m)
+    assert e.value.code == -5

@@ -108,9 +108,9 @@ def test_large_pairs_in_a_batch(ctx, oracle, pkg, synth):
 
 def test_capacity_error_is_loud(ctx, pkg):
     n = ctx.max_matches + 1
-    c = cases.random_pair(61, n=n, inlier_frac=0.5)
+    c = cases.random_pair(61, n=100, inlier_frac=0.5)
     with pytest.raises(pkg.GmsError) as e:
-        ctx.match(c["size1"], c["size2"], c["kp1"], c["kp2"], c["matches"])
+        ctx.match(c["size1"], c["size2"], c["kp1"], c["kp2"], np.zeros(n, dtype=pkg.DMATCH_DTYPE))
     assert e.value.code == -5
 
 
