@@ -32,6 +32,7 @@ extern "C" {
 #define GMS_ERR_HIP       (-3) /* a HIP runtime call failed (gms_last_hip_error() has the code)  */
 #define GMS_ERR_NO_DEVICE (-4) /* no usable gfx950 device                                        */
 #define GMS_ERR_CAPACITY  (-5) /* m exceeds what this build supports (see gms_max_matches())     */
+#define GMS_ERR_IO        (-7) /* gms_dataset_read / _write: cannot open, short file, or not a GMSFRM01 file             */
 #define GMS_ERR_NOT_RESERVED (-6) /* a workspace would have to grow while the stream is being captured: call
                                      gms_ctx_reserve() for this shape first                          */
 
@@ -168,6 +169,7 @@ int gms_filter_host_batch(gms_ctx* ctx, const gms_keypoint* kp, const int64_t* f
  *                          once per frame table. Frames whose values are all integers 0..255 (what SIFT emits) run on the
  *                          matrix cores with exact arithmetic; any other frame is matched by the reference's fp32 loop.
  * Stream-ordered on the context's stream, no allocation, no synchronisation. A frame may hold at most 2^22 rows. */
+#define GMS_DESC_NONE      (-1)
 #define GMS_DESC_HAMMING256  0
 #define GMS_DESC_L2_F32X128  1
 int64_t gms_bf_prepared_bytes(int desc_kind, int64_t total_desc, int n_frames);
@@ -203,6 +205,27 @@ int gms_disparity_device(gms_ctx* ctx, const gms_keypoint* d_kp1, int n1, const 
 int gms_gather_points_device(gms_ctx* ctx, const gms_keypoint* d_kp1, int n1, const gms_keypoint* d_kp2, int n2,
                              const gms_dmatch* d_matches, const int32_t* d_n_matches, int max_matches,
                              float* d_coords1, float* d_coords2, int32_t* d_status);
+
+/* ---- ingest format -----------------------------------------------------------------------------------------
+ * The reference keeps detector and matcher output in process (std::vector<cv::KeyPoint>, cv::Mat descriptors,
+ * std::vector<cv::DMatch>: FeatureMatchUtil.cpp:9-12,58-68; DisparityUtil.cpp:108,137-143) and has no on-disk form. One
+ * little-endian file ("GMSFRM01", layout in gms_io.cpp) carries a sequence in exactly the arrays the batch API takes --
+ * cv::KeyPoint / cv::DMatch records verbatim -- so that a caller can dump its vectors and any process can filter them.
+ * gms_dataset_read allocates one block (owner) that gms_dataset_free releases; on write, owner is ignored. Host only. */
+typedef struct gms_dataset {
+    int32_t n_frames, desc_kind;        /* desc_kind: GMS_DESC_NONE / _HAMMING256 / _L2_F32X128                    */
+    int64_t n_pairs, total_matches;
+    int32_t* wh;                        /* 2 * n_frames: (width, height)                                           */
+    int64_t* frame_off;                 /* n_frames + 1 keypoint offsets; frame_off[n_frames] = number of keypoints */
+    gms_keypoint* keypoints;
+    void* descriptors;                  /* one row per keypoint (32 B or 128 floats), or NULL                      */
+    gms_pair* pairs;                    /* match_off indexes `matches`                                             */
+    gms_dmatch* matches;
+    void* owner;
+} gms_dataset;
+int  gms_dataset_write(const char* path, const gms_dataset* d);
+int  gms_dataset_read(const char* path, gms_dataset* d);
+void gms_dataset_free(gms_dataset* d);
 
 /* ---- introspection --------------------------------------------------------------------------- */
 int         gms_max_matches(void);        /* largest m per pair this build accepts                 */

@@ -9,7 +9,7 @@ EXPORTED_SYMBOLS = [
     "gms_match", "gms_match_ctx", "gms_ctx_create", "gms_ctx_destroy", "gms_ctx_set_stream",
     "gms_ctx_synchronize", "gms_ctx_reserve", "gms_frame_table_bytes", "gms_normalize_device", "gms_filter_device",
     "gms_filter_host_batch", "gms_bf_prepared_bytes", "gms_bf_prepare_device", "gms_bfmatch_device", "gms_disparity_device",
-    "gms_gather_points_device", "gms_max_matches",
+    "gms_gather_points_device", "gms_dataset_write", "gms_dataset_read", "gms_dataset_free", "gms_max_matches",
     "gms_last_hip_error", "gms_error_string", "gms_version", "gms_selftest_threshold",
 ]
 
@@ -61,10 +61,14 @@ def load_library():
     lib.gms_error_string.restype = C.c_char_p
     lib.gms_version.argtypes = []
     lib.gms_version.restype = C.c_char_p
+    lib.gms_dataset_write.argtypes = [C.c_char_p, vp]
+    lib.gms_dataset_read.argtypes = [C.c_char_p, vp]
+    lib.gms_dataset_free.argtypes = [vp]
     for name in EXPORTED_SYMBOLS:
         if name not in ("gms_error_string", "gms_version"):
             getattr(lib, name).restype = i32
     lib.gms_bf_prepared_bytes.restype = i64
+    lib.gms_dataset_free.restype = None
     lib.gms_frame_table_bytes.argtypes = [i64]
     lib.gms_frame_table_bytes.restype = i64
     _lib = lib

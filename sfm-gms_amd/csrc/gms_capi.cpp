@@ -325,6 +325,7 @@ const char* gms_error_string(int code)
     case GMS_ERR_HIP: return "HIP runtime error";
     case GMS_ERR_NO_DEVICE: return "no usable HIP device";
     case GMS_ERR_CAPACITY: return "too many matches per pair for this build";
+    case GMS_ERR_IO: return "dataset file: cannot open, truncated, or not a GMSFRM01 file";
     case GMS_ERR_NOT_RESERVED: return "workspace not reserved for this shape (stream capture in progress)";
     default: return "unknown error";
     }

@@ -1631,7 +1631,7 @@ __device__ __forceinline__ bool dense_scales_pair(const FilterParams& p, uint32_
                         if ((cw & out_mask) == 0 && (!BANDED || l - cell0 < n_held)) {
                             if (!BANDED || l - own0 < n_own) cr[k] = smem[row >> 2];
                             const uint32_t at = row + ((cw >> kDEShift) & kSEMask);
-                            atomicSub(lds_at(smem, at & ~3u), 1u << ((at << 3) & 31u));
+                            reinterpret_cast<uint8_t*>(smem)[at] = 0;  // (every reader of the entry is past the barrier: see dense_pair)
                         }
                     }
 #pragma unroll

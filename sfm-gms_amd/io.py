@@ -1,0 +1,73 @@
+"""The ingest format (SURVEY.md 8f "f2"; include/gms.h "ingest format"): a sequence's keypoints, descriptors, pairs and putative
+matches in one little-endian file, the records verbatim cv::KeyPoint / cv::DMatch. The reference has no on-disk form
+(FeatureMatchUtil.cpp:9-12,58-68 keep everything in std::vector / cv::Mat); a caller dumps its vectors with gms_dataset_write
+(csrc/gms_io.cpp) or `save` here, and `load` hands back the arrays the batch API takes. numpy only: no GPU involved."""
+import ctypes as C
+
+import numpy as np
+
+from .types import DMATCH_DTYPE, KEYPOINT_DTYPE, PAIR_DTYPE
+
+MAGIC = b"GMSFRM01"
+_HEADER = np.dtype([("magic", "S8"), ("n_frames", "<u4"), ("desc_kind", "<u4"), ("total_kp", "<u8"), ("n_pairs", "<u8"),
+                    ("total_matches", "<u8")])
+_ROW = {-1: (None, 0), 0: (np.uint8, 32), 1: (np.float32, 128)}
+
+
+class Dataset:
+    """frames: list of KEYPOINT_DTYPE arrays; sizes: [(w, h)]; descriptors: list of [n, 32] uint8 / [n, 128] float32 or None;
+    pairs (PAIR_DTYPE) index matches (DMATCH_DTYPE) by match_off."""
+
+    def __init__(self, frames, sizes, descriptors=None, desc_kind=-1, pairs=None, matches=None):
+        self.frames, self.sizes, self.descriptors, self.desc_kind = list(frames), [tuple(s) for s in sizes], descriptors, int(desc_kind)
+        self.pairs = np.zeros(0, dtype=PAIR_DTYPE) if pairs is None else np.ascontiguousarray(pairs, dtype=PAIR_DTYPE)
+        self.matches = np.zeros(0, dtype=DMATCH_DTYPE) if matches is None else np.ascontiguousarray(matches, dtype=DMATCH_DTYPE)
+
+
+def save(path, ds):
+    counts = np.array([len(f) for f in ds.frames], dtype=np.int64)
+    off = np.concatenate([[0], np.cumsum(counts)]).astype("<i8")
+    hdr = np.zeros(1, dtype=_HEADER)
+    hdr["magic"], hdr["n_frames"], hdr["desc_kind"] = MAGIC, len(ds.frames), ds.desc_kind + 1
+    hdr["total_kp"], hdr["n_pairs"], hdr["total_matches"] = int(off[-1]), len(ds.pairs), len(ds.matches)
+    with open(path, "wb") as f:
+        f.write(hdr.tobytes())
+        f.write(np.asarray(ds.sizes, dtype="<i4").reshape(-1).tobytes())
+        if len(ds.frames):
+            f.write(off.tobytes())
+        for fr in ds.frames:
+            f.write(np.ascontiguousarray(fr, dtype=KEYPOINT_DTYPE).tobytes())
+        dt, width = _ROW[ds.desc_kind]
+        if dt is not None:
+            for d in ds.descriptors:
+                f.write(np.ascontiguousarray(d, dtype=dt).reshape(-1, width).tobytes())
+        f.write(ds.pairs.tobytes())
+        f.write(ds.matches.tobytes())
+
+
+def load(path):
+    with open(path, "rb") as f:
+        hdr = np.frombuffer(f.read(_HEADER.itemsize), dtype=_HEADER)
+        if len(hdr) != 1 or hdr["magic"][0] != MAGIC or int(hdr["desc_kind"][0]) > 2:
+            raise ValueError(f"{path}: not a GMSFRM01 file")
+        n, kind = int(hdr["n_frames"][0]), int(hdr["desc_kind"][0]) - 1
+        total, n_pairs, total_m = int(hdr["total_kp"][0]), int(hdr["n_pairs"][0]), int(hdr["total_matches"][0])
+        take = lambda dt, count: np.frombuffer(f.read(np.dtype(dt).itemsize * count), dtype=dt, count=count)
+        wh = take("<i4", 2 * n).reshape(-1, 2)
+        off = take("<i8", n + 1) if n else np.zeros(1, dtype=np.int64)
+        if int(off[-1]) != total or (np.diff(off) < 0).any():
+            raise ValueError(f"{path}: frame offsets do not match the keypoint count")
+        kp = take(KEYPOINT_DTYPE, total)
+        dt, width = _ROW[kind]
+        desc = take(dt, total * width).reshape(-1, width) if dt is not None else None
+        pairs = take(PAIR_DTYPE, n_pairs)
+        matches = take(DMATCH_DTYPE, total_m)
+    frames = [kp[off[i]:off[i + 1]] for i in range(n)]
+    descs = [desc[off[i]:off[i + 1]] for i in range(n)] if desc is not None else None
+    return Dataset(frames, [tuple(x) for x in wh.tolist()], descs, kind, pairs, matches)
+
+
+class _CDataset(C.Structure):
+    _fields_ = [("n_frames", C.c_int32), ("desc_kind", C.c_int32), ("n_pairs", C.c_int64), ("total_matches", C.c_int64),
+                ("wh", C.c_void_p), ("frame_off", C.c_void_p), ("keypoints", C.c_void_p), ("descriptors", C.c_void_p),
+                ("pairs", C.c_void_p), ("matches", C.c_void_p), ("owner", C.c_void_p)]
