@@ -269,9 +269,9 @@ def bf_gms_leg(ctx, wl, pkg, stream, kind, n_frames=64, n_pairs=1024, steps=3):
         if failed or got_m.tobytes() != want_m.tobytes() or res[i].tobytes() != wres[0].tobytes() or got_o.tobytes() != wout[:k].tobytes():
             bad += 1
     evals = float(n_pairs) * n_kp * n_kp
-    if kind == "orb":  # 18 integer VALU operations per distance evaluation (8 xor, 8 popcount-accumulate, pack, min)
-        roof = {"bound": "valu", "achieved": evals * 18 / (match_ms * 1e-3) / 1e12, "peak": 78.6, "unit": "T int32 lane-ops/s",
-                "note": "256 CUs x 4 SIMDs x 32 lanes x 2.4 GHz; HBM traffic of the matcher is 0.8 MB per pair"}
+    if kind == "orb":  # hamming = |a| + |b| - 2 a.b over the 256 bits as 0/1 bytes on v_mfma_i32_32x32x32_i8: 2 x 256 int8 ops per evaluation
+        roof = {"bound": "mfma", "achieved": evals * 512 / (match_ms * 1e-3) / 1e12, "peak": 5000.0, "unit": "TOP/s (int8)",
+                "note": "int8 dense peak = 2 x the bf16 dense peak (MI355X_MICROARCH.md, Matrix cores); HBM traffic of the matcher is 5 MB per pair"}
     else:
         roof = {"bound": "mfma", "achieved": evals * 256 / (match_ms * 1e-3) / 1e12, "peak": 2500.0, "unit": "TFLOP/s",
                 "note": "bf16 dense peak; 2 x 128 flop per distance evaluation"}

@@ -62,14 +62,15 @@ class DescriptorTable:
                               self.d_prep.data_ptr())
         ctx.synchronize()
 
-    def match_device(self, d_pairs, n_pairs, max_query, d_matches):
-        """gms_bfmatch_device: one match per query row of every pair, written at the pair's match_off (stream-ordered)."""
+    def match_device(self, d_pairs, n_pairs, max_query, d_matches, use_prepared=True):
+        """gms_bfmatch_device: one match per query row of every pair, written at the pair's match_off (stream-ordered).
+        use_prepared=False (Hamming only): the vector-ALU kernel on the raw rows instead of the matrix-core one."""
         f = self.frames
-        self.ctx.bfmatch_device(self.kind, self.d_desc.data_ptr(), self.d_prep.data_ptr(), f.total, f.d_frame_off.data_ptr(),
-                                f.n_frames, d_pairs, n_pairs, max_query, d_matches)
+        self.ctx.bfmatch_device(self.kind, self.d_desc.data_ptr(), self.d_prep.data_ptr() if use_prepared else None, f.total,
+                                f.d_frame_off.data_ptr(), f.n_frames, d_pairs, n_pairs, max_query, d_matches)
 
 
-def match_pairs(ctx, descs, pairs):
+def match_pairs(ctx, descs, pairs, use_prepared=True):
     """Brute-force matches of `pairs` (PAIR_DTYPE; m = keypoints of frame_a) as a host DMATCH_DTYPE array laid out by match_off."""
     dev = descs.frames.device
     pairs = np.ascontiguousarray(pairs, dtype=PAIR_DTYPE)
@@ -77,7 +78,7 @@ def match_pairs(ctx, descs, pairs):
     d_pairs = _to_dev(pairs, dev)
     d_matches = torch.zeros(max(total, 1) * 16, dtype=torch.uint8, device=dev)
     torch.cuda.synchronize(dev)
-    descs.match_device(d_pairs.data_ptr(), len(pairs), int(pairs["m"].max()) if len(pairs) else 0, d_matches.data_ptr())
+    descs.match_device(d_pairs.data_ptr(), len(pairs), int(pairs["m"].max()) if len(pairs) else 0, d_matches.data_ptr(), use_prepared)
     ctx.synchronize()
     return d_matches.cpu().numpy().view(DMATCH_DTYPE)[:total]
 

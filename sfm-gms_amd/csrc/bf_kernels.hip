@@ -22,6 +22,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "gms_kernels.h"
 
 namespace gms {
@@ -163,145 +165,249 @@ bf_l2_prepare_kernel(const float4* __restrict__ desc, const int64_t* __restrict_
     }
 }
 
-// ---- NORM_L2 on the matrix cores ----------------------------------------------------------------------------------------------
+// ---- NORM_HAMMING: the per-frame tables of the matrix-core path ------------------------------------------------------------------
+// hamming(a, b) = |a| + |b| - 2 a.b over the 256 bits as 0/1 bytes: each row is expanded to 256 int8 (the A / B operands of
+// v_mfma_i32_32x32x32_i8) and its popcount kept beside it. One thread per (row, 16 bits).
+__global__ void __launch_bounds__(256)
+bf_ham_prepare_kernel(const uint16_t* __restrict__ desc, int64_t total, uint4* __restrict__ rows_i8, int32_t* __restrict__ norms)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;  // 16 pieces of 16 bits per row
+    if (i >= total * 16) return;
+    const uint32_t bits = desc[i];
+    uint32_t w[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t n = (bits >> (4 * k)) & 15u;
+        w[k] = (n & 1u) | ((n & 2u) << 7) | ((n & 4u) << 14) | ((n & 8u) << 21);  // bit j of the nibble -> byte j
+    }
+    rows_i8[i] = make_uint4(w[0], w[1], w[2], w[3]);
+    uint32_t pc = (uint32_t)__builtin_popcount(bits);
+#pragma unroll
+    for (int d = 8; d >= 1; d >>= 1) pc += (uint32_t)__shfl_xor((int)pc, d, 16);
+    if ((threadIdx.x & 15) == 0) norms[i >> 4] = (int32_t)pc;
+}
+
+// ---- both norms on the matrix cores ------------------------------------------------------------------------------------------------
+// One 256-thread workgroup = 256 query rows of one pair (four waves x 64 query columns, the B operands, resident in registers and
+// pre-multiplied by -2) against all train rows of the pair's other frame, streamed through LDS in tiles of 64 rows (the A operands).
+// An accumulator starts from |b|^2 of its row, so after the K loop it holds |b|^2 - 2 a.b: the distance minus the query's own
+// norm. Per tile a lane only keeps the MINIMUM of its 32 values per query column (one v_min3 per two values) and the tile it came
+// from -- tracking the arg-min per value would cost more vector instructions than the tile's MFMAs take. The winning TILE of a
+// query is then searched once more at the end, with the norm's own exact arithmetic, for the first minimal row.
+//   L2:       rows = bf16 x 128 (256 B), v_mfma_f32_32x32x16_bf16, fp32 accumulators; every value an exact integer (see the file header)
+//   Hamming:  rows = int8 x 256 (256 B), v_mfma_i32_32x32x32_i8, int32 accumulators
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) int i32x4;
+typedef __attribute__((ext_vector_type(16))) int i32x16;
 
 constexpr int kL2Dim = 128;
 constexpr int kTileRows = 64;                    // train rows per LDS tile
-constexpr uint32_t kRowPitch = 256u + 16u;       // bf16 row + 16 B: the 32 rows a ds_read_b128 touches fall on different banks
+constexpr uint32_t kRowPitch = 256u + 16u;       // a 256-byte row + 16 B: the 32 rows a ds_read_b128 touches fall on different banks
 constexpr uint32_t kTileBytes = kTileRows * kRowPitch;               // 17 408
 constexpr uint32_t kNormOff = 2u * kTileBytes;                       // two tiles, then two norm tiles
-constexpr uint32_t kL2LdsBytes = kNormOff + 2u * kTileRows * 4u;     // 35 328
+constexpr uint32_t kMfmaLdsBytes = kNormOff + 2u * kTileRows * 4u;   // 35 328
 constexpr int kQueriesPerBlock = 256;            // 4 waves x 64 query columns
 
+template <bool HAM>
 __global__ void __launch_bounds__(256)
-bf_l2_mfma_kernel(const uint4* __restrict__ rows_bf16, const float* __restrict__ norms, const uint32_t* __restrict__ frame_bad,
-                  const int64_t* __restrict__ frame_off, int n_frames, const gms_pair* __restrict__ pairs, int tiles_per_pair,
-                  uint32_t n_tasks, gms_dmatch* __restrict__ matches)
+bf_mfma_kernel(const uint4* __restrict__ rows, const uint32_t* __restrict__ norms, const uint32_t* __restrict__ frame_bad,
+               const void* __restrict__ raw, const int64_t* __restrict__ frame_off, int n_frames, const gms_pair* __restrict__ pairs,
+               int tiles_per_pair, uint32_t n_tasks, gms_dmatch* __restrict__ matches)
 {
-    __shared__ __attribute__((aligned(16))) unsigned char lds[kL2LdsBytes];
+    using Acc = typename std::conditional<HAM, i32x16, f32x16>::type;
+    using Val = typename std::conditional<HAM, int32_t, float>::type;   // an accumulator element / a norm
+    __shared__ __attribute__((aligned(16))) unsigned char lds[kMfmaLdsBytes];
     const uint32_t task = xcd_task(blockIdx.x, n_tasks);
     const int pair_idx = (int)(task / (uint32_t)tiles_per_pair), tile = (int)(task % (uint32_t)tiles_per_pair);
     const gms_pair pr = pairs[pair_idx];
     const FramePair f = frame_pair(pr, frame_off, n_frames);
     const int q0 = tile * kQueriesPerBlock;
-    if (!f.ok || q0 >= f.m) return;                                     // workgroup-uniform
-    if (frame_bad[pr.frame_a] | frame_bad[pr.frame_b]) return;          // the loop kernel owns this pair
+    if (!f.ok || q0 >= f.m) return;                                                  // workgroup-uniform
+    if (!HAM && (frame_bad[pr.frame_a] | frame_bad[pr.frame_b])) return;             // the loop kernel owns this pair
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int col = lane & 31, half = lane >> 5;
+    const Val kBig = HAM ? (Val)0x3FFFFFFF : (Val)3.0e38f;
+    if (f.nB <= 0) {  // nothing to match against: the reference's matcher returns no match for the row
+        const int q = q0 + tid;
+        if (q < f.m) {
+            gms_dmatch m;
+            m.queryIdx = q;
+            m.trainIdx = -1;
+            m.imgIdx = 0;
+            m.distance = 3.402823466e+38f;
+            *reinterpret_cast<uint4*>(&matches[pr.match_off + q]) = *reinterpret_cast<const uint4*>(&m);
+        }
+        return;
+    }
 
     // ---- this wave's 64 query columns as B operands, scaled by -2 (exact), resident for the whole kernel:
-    //      bq[c][s] = -2 * Q[32 c + col][16 s + 8 half .. + 8)
-    bf16x8 bq[2][8];
+    //      bq[c][s] = -2 * Q[32 c + col][bytes 32 s + 16 half .. + 16)
+    uint4 bq[2][8];
     int qrow[2];
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
         qrow[c] = q0 + wave * 64 + c * 32 + col;
-        const uint4* src = rows_bf16 + (size_t)(f.offA + min(qrow[c], f.m - 1)) * 16;
+        const uint4* src = rows + (size_t)(f.offA + min(qrow[c], f.m - 1)) * 16;
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
-            const uint4 raw = src[2 * s + half];
-            const uint32_t w[4] = {raw.x, raw.y, raw.z, raw.w};
+            const uint4 r4 = src[2 * s + half];
+            const uint32_t w[4] = {r4.x, r4.y, r4.z, r4.w};
             uint32_t o[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const float lo = __uint_as_float(w[i] << 16) * -2.0f, hi = __uint_as_float(w[i] & 0xFFFF0000u) * -2.0f;
-                o[i] = (__float_as_uint(lo) >> 16) | (__float_as_uint(hi) & 0xFFFF0000u);
+                if (HAM) {
+                    o[i] = w[i] * 0xFEu;  // bytes 0 / 1 -> 0 / -2 (0xFE): no carries between bytes
+                } else {
+                    const float lo = __uint_as_float(w[i] << 16) * -2.0f, hi = __uint_as_float(w[i] & 0xFFFF0000u) * -2.0f;
+                    o[i] = (__float_as_uint(lo) >> 16) | (__float_as_uint(hi) & 0xFFFF0000u);
+                }
             }
-            bq[c][s] = __builtin_bit_cast(bf16x8, make_uint4(o[0], o[1], o[2], o[3]));
+            bq[c][s] = make_uint4(o[0], o[1], o[2], o[3]);
         }
     }
-    float bestv[2] = {3.402823466e+38f, 3.402823466e+38f};
-    int besti[2] = {-1, -1};
+    Val bestv[2] = {kBig, kBig};
+    int bestt[2] = {0, 0};
 
-    const uint4* __restrict__ trB = rows_bf16 + (size_t)f.offB * 16;
-    const float* __restrict__ nrmB = norms + f.offB;
+    const uint4* __restrict__ trB = rows + (size_t)f.offB * 16;
+    const uint32_t* __restrict__ nrmB = norms + f.offB;
     const int n_tiles = (f.nB + kTileRows - 1) / kTileRows;
-    // stage tile t into buffer t & 1: 64 rows x 256 B = 1024 16-byte pieces, four per thread, rows beyond nB repeat the last row
-    // (their norm is +inf, so they never win)
-    auto stage_load = [&](int t, uint4 (&v)[4], float& nv) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int piece = i * 256 + tid, r = piece >> 4, c16 = piece & 15;
-            v[i] = trB[(size_t)min(t * kTileRows + r, f.nB - 1) * 16 + c16];
-        }
+    // stage tile t into buffer t & 1: 64 rows x 256 B = 1024 16-byte pieces, four per thread; rows beyond nB repeat the last row
+    // with a norm that never wins
+    struct Stage { uint4 v0, v1, v2, v3; uint32_t nv; };  // (named members, returned by value: stays in registers)
+    auto stage_load = [&](int t) -> Stage {
+        Stage st;
+        auto piece = [&](int i) -> uint4 {
+            const int pc = i * 256 + tid, r = pc >> 4, c16 = pc & 15;
+            return trB[(size_t)min(t * kTileRows + r, f.nB - 1) * 16 + c16];
+        };
+        st.v0 = piece(0); st.v1 = piece(1); st.v2 = piece(2); st.v3 = piece(3);
         const int r = t * kTileRows + (tid & 63);
-        nv = (tid < kTileRows) ? (r < f.nB ? nrmB[r] : __builtin_inff()) : 0.0f;
+        const Val big = kBig;
+        st.nv = (tid < kTileRows) ? (r < f.nB ? nrmB[r] : __builtin_bit_cast(uint32_t, big)) : 0u;
+        return st;
     };
-    auto stage_store = [&](int t, const uint4 (&v)[4], float nv) {
+    auto stage_store = [&](int t, const Stage& st) {
         unsigned char* base = lds + (uint32_t)(t & 1) * kTileBytes;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int piece = i * 256 + tid, r = piece >> 4, c16 = piece & 15;
-            *reinterpret_cast<uint4*>(base + (uint32_t)r * kRowPitch + (uint32_t)c16 * 16u) = v[i];
-        }
-        if (tid < kTileRows) reinterpret_cast<float*>(lds + kNormOff)[(t & 1) * kTileRows + tid] = nv;
+        auto put = [&](int i, const uint4& v) {
+            const int pc = i * 256 + tid, r = pc >> 4, c16 = pc & 15;
+            *reinterpret_cast<uint4*>(base + (uint32_t)r * kRowPitch + (uint32_t)c16 * 16u) = v;
+        };
+        put(0, st.v0); put(1, st.v1); put(2, st.v2); put(3, st.v3);
+        if (tid < kTileRows) reinterpret_cast<uint32_t*>(lds + kNormOff)[(t & 1) * kTileRows + tid] = st.nv;
     };
-    uint4 sv[4];
-    float snv;
-    stage_load(0, sv, snv);
-    stage_store(0, sv, snv);
+    Stage sv = stage_load(0);
+    stage_store(0, sv);
     __syncthreads();
     for (int t = 0; t < n_tiles; ++t) {
         const bool more = t + 1 < n_tiles;
-        if (more) stage_load(t + 1, sv, snv);  // in flight during this tile's MFMAs
+        if (more) sv = stage_load(t + 1);  // in flight during this tile's MFMAs
         const unsigned char* tb = lds + (uint32_t)(t & 1) * kTileBytes;
-        const float* nb = reinterpret_cast<const float*>(lds + kNormOff) + (t & 1) * kTileRows;
-        f32x16 acc[2][2];
-        // C-in = |b|^2 of the accumulator's row: rows (reg & 3) + 8 (reg >> 2) + 4 half of the 32-row block
+        const uint32_t* nb = reinterpret_cast<const uint32_t*>(lds + kNormOff) + (t & 1) * kTileRows;
+        Acc acc[2][2];
+        // C-in = the norm of the accumulator's row: rows (reg & 3) + 8 (reg >> 2) + 4 half of the 32-row block
 #pragma unroll
         for (int rb = 0; rb < 2; ++rb) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const float4 n4 = *reinterpret_cast<const float4*>(nb + rb * 32 + 8 * g + 4 * half);
-                acc[rb][0][4 * g + 0] = n4.x; acc[rb][0][4 * g + 1] = n4.y; acc[rb][0][4 * g + 2] = n4.z; acc[rb][0][4 * g + 3] = n4.w;
+                const uint4 n4 = *reinterpret_cast<const uint4*>(nb + rb * 32 + 8 * g + 4 * half);
+                acc[rb][0][4 * g + 0] = __builtin_bit_cast(Val, n4.x); acc[rb][0][4 * g + 1] = __builtin_bit_cast(Val, n4.y);
+                acc[rb][0][4 * g + 2] = __builtin_bit_cast(Val, n4.z); acc[rb][0][4 * g + 3] = __builtin_bit_cast(Val, n4.w);
             }
             acc[rb][1] = acc[rb][0];
         }
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
-            // A operand: train row (32 rb + col), k = 16 s + 8 half .. + 8
-            const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(tb + (uint32_t)col * kRowPitch + (uint32_t)(32 * s + 16 * half));
-            const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(tb + (uint32_t)(32 + col) * kRowPitch + (uint32_t)(32 * s + 16 * half));
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bq[0][s], acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bq[1][s], acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bq[0][s], acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bq[1][s], acc[1][1], 0, 0, 0);
+            // A operand: train row (32 rb + col), bytes 32 s + 16 half .. + 16 (the same bytes of the row as the B operand's: the
+            // dot product pairs equal positions whatever order the instruction visits them in)
+            const uint4 a0 = *reinterpret_cast<const uint4*>(tb + (uint32_t)col * kRowPitch + (uint32_t)(32 * s + 16 * half));
+            const uint4 a1 = *reinterpret_cast<const uint4*>(tb + (uint32_t)(32 + col) * kRowPitch + (uint32_t)(32 * s + 16 * half));
+            if constexpr (HAM) {
+                acc[0][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_bit_cast(i32x4, a0), __builtin_bit_cast(i32x4, bq[0][s]), acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_bit_cast(i32x4, a0), __builtin_bit_cast(i32x4, bq[1][s]), acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_bit_cast(i32x4, a1), __builtin_bit_cast(i32x4, bq[0][s]), acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_bit_cast(i32x4, a1), __builtin_bit_cast(i32x4, bq[1][s]), acc[1][1], 0, 0, 0);
+            } else {
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a0), __builtin_bit_cast(bf16x8, bq[0][s]), acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a0), __builtin_bit_cast(bf16x8, bq[1][s]), acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a1), __builtin_bit_cast(bf16x8, bq[0][s]), acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a1), __builtin_bit_cast(bf16x8, bq[1][s]), acc[1][1], 0, 0, 0);
+            }
         }
-        // acc = |b|^2 - 2 a.b for (train row, query column): first strict minimum, rows ascending
-        const int t0 = t * kTileRows + 4 * half;
+        // the tile's minimum per query column (this lane's 32 of the 64 rows), and the first tile that reached it
 #pragma unroll
-        for (int c = 0; c < 2; ++c)
+        for (int c = 0; c < 2; ++c) {
+            Val mn = acc[0][c][0];
 #pragma unroll
-            for (int rb = 0; rb < 2; ++rb)
+            for (int reg = 1; reg < 16; ++reg) mn = min(mn, acc[0][c][reg]);
 #pragma unroll
-                for (int reg = 0; reg < 16; ++reg) {
-                    const float v = acc[rb][c][reg];
-                    const bool lt = v < bestv[c];
-                    bestv[c] = lt ? v : bestv[c];
-                    besti[c] = lt ? t0 + rb * 32 + (reg & 3) + 8 * (reg >> 2) : besti[c];
-                }
-        if (more) stage_store(t + 1, sv, snv);  // the other buffer: last read one barrier ago
+            for (int reg = 0; reg < 16; ++reg) mn = min(mn, acc[1][c][reg]);
+            const bool lt = mn < bestv[c];
+            bestv[c] = lt ? mn : bestv[c];
+            bestt[c] = lt ? t : bestt[c];
+        }
+        if (more) stage_store(t + 1, sv);  // the other buffer: last read one barrier ago
         __syncthreads();
     }
-    // the two halves of the wave hold disjoint row sets of the same query: lower value, then lower row
-    gms_dmatch* __restrict__ out = matches + pr.match_off;
+    // ---- the two halves of the wave hold disjoint row sets of the same query: lower value, then earlier tile
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
-        const float ov = __shfl_xor(bestv[c], 32);
-        const int oi = __shfl_xor(besti[c], 32);
-        const bool take = ov < bestv[c] || (ov == bestv[c] && (uint32_t)oi < (uint32_t)besti[c]);
-        const float v = take ? ov : bestv[c];
-        const int bi = take ? oi : besti[c];
-        if (half == 0 && qrow[c] < f.m) {
-            const float na = norms[f.offA + qrow[c]];
-            gms_dmatch r;
-            r.queryIdx = qrow[c];
-            r.trainIdx = bi;
-            r.imgIdx = 0;
-            r.distance = bi >= 0 ? sqrtf(fmaxf(v + na, 0.0f)) : 3.402823466e+38f;
-            *reinterpret_cast<uint4*>(&out[qrow[c]]) = *reinterpret_cast<const uint4*>(&r);
+        const Val ov = __builtin_bit_cast(Val, __shfl_xor(__builtin_bit_cast(int, bestv[c]), 32));
+        const int ot = __shfl_xor(bestt[c], 32);
+        const bool take = ov < bestv[c] || (ov == bestv[c] && ot < bestt[c]);
+        bestt[c] = take ? ot : bestt[c];
+    }
+    // ---- every query's winning tile once more, one lane per train row, in the norm's own arithmetic: the first minimal row
+    gms_dmatch* __restrict__ out = matches + pr.match_off;
+    for (int i = 0; i < 64; ++i) {
+        const int q = q0 + wave * 64 + i;
+        if (q >= f.m) break;                                                          // wave-uniform
+        const int tstar = __shfl(i < 32 ? bestt[0] : bestt[1], i & 31);
+        uint32_t key;
+        if constexpr (HAM) {
+            const int r = tstar * kTileRows + lane, rr = min(r, f.nB - 1);
+            const uint4* qa = reinterpret_cast<const uint4*>(reinterpret_cast<const uint32_t*>(raw) + (size_t)(f.offA + q) * 8);
+            const uint4* tb4 = reinterpret_cast<const uint4*>(reinterpret_cast<const uint32_t*>(raw) + (size_t)(f.offB + rr) * 8);
+            const uint4 x0 = qa[0], x1 = qa[1], y0 = tb4[0], y1 = tb4[1];
+            const uint32_t d = (uint32_t)(__builtin_popcount(x0.x ^ y0.x) + __builtin_popcount(x0.y ^ y0.y) + __builtin_popcount(x0.z ^ y0.z) +
+                                          __builtin_popcount(x0.w ^ y0.w) + __builtin_popcount(x1.x ^ y1.x) + __builtin_popcount(x1.y ^ y1.y) +
+                                          __builtin_popcount(x1.z ^ y1.z) + __builtin_popcount(x1.w ^ y1.w));
+            key = r < f.nB ? (d << 6) | (uint32_t)lane : 0xFFFFFFFFu;
+        } else {
+            // The tile's 64 rows are 16 KB of consecutive memory: read them coalesced -- a wave instruction covers four whole rows,
+            // lane = (row of the four, 16-byte piece of the row) -- and add a row's sixteen partial dot products up across its lanes.
+            // bf16 rows hold the integers exactly, so |a|^2 + |b|^2 - 2 a.b (two elements per v_dot2c_f32_bf16) is made of exact
+            // integers below 2^24 in any order.
+            typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+            const int piece = lane & 15, rsub = lane >> 4;
+            const uint4 x = rows[(size_t)(f.offA + q) * 16 + piece];
+            const float na = __uint_as_float(norms[f.offA + q]);
+            key = 0xFFFFFFFFu;
+#pragma unroll 4
+            for (int j = 0; j < 16; ++j) {
+                const int row = tstar * kTileRows + 4 * j + rsub;
+                const int rowc = min(row, f.nB - 1);
+                const uint4 y = rows[(size_t)(f.offB + rowc) * 16 + piece];
+                float dot = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, x.x), __builtin_bit_cast(bf16x2, y.x), 0.0f, false);
+                dot = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, x.y), __builtin_bit_cast(bf16x2, y.y), dot, false);
+                dot = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, x.z), __builtin_bit_cast(bf16x2, y.z), dot, false);
+                dot = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, x.w), __builtin_bit_cast(bf16x2, y.w), dot, false);
+#pragma unroll
+                for (int d = 8; d >= 1; d >>= 1) dot += __shfl_xor(dot, d, 16);
+                const float d2 = (na + __uint_as_float(nrmB[rowc])) - 2.0f * dot;
+                const uint32_t kj = row < f.nB ? ((uint32_t)d2 << 6) | (uint32_t)(4 * j + rsub) : 0xFFFFFFFFu;  // d^2 <= 128 * 255^2 < 2^23
+                key = min(key, kj);
+            }
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) key = min(key, (uint32_t)__shfl_xor((int)key, d));
+        if (lane == 0) {
+            gms_dmatch m;
+            m.queryIdx = q;
+            m.trainIdx = f.nB > 0 ? tstar * kTileRows + (int)(key & 63u) : -1;
+            m.imgIdx = 0;
+            m.distance = f.nB > 0 ? (HAM ? (float)(key >> 6) : sqrtf((float)(key >> 6))) : 3.402823466e+38f;
+            *reinterpret_cast<uint4*>(&out[q]) = *reinterpret_cast<const uint4*>(&m);
         }
     }
 }
@@ -372,17 +478,27 @@ bf_l2_loop_kernel(const float* __restrict__ desc, const uint32_t* __restrict__ f
 }  // namespace
 
 // ---- launch helpers ------------------------------------------------------------------------------------------------------------
-// prepared block of the L2 path: [total][128] bf16 | [total] float norms | [n_frames] u32 "not SIFT-like" flags
+// prepared block:  L2       [total][128] bf16 | [total] float norms | [n_frames] u32 "not SIFT-like" flags
+//                  Hamming  [total][256] int8 | [total] int32 popcounts
 size_t bf_prepared_bytes(int kind, int64_t total, int n_frames)
 {
-    if (kind != GMS_DESC_L2_F32X128 || total < 0 || n_frames < 0) return 0;
-    return ((size_t)total * 256 + (size_t)total * 4 + (size_t)n_frames * 4 + 15) & ~(size_t)15;
+    if (total < 0 || n_frames < 0) return 0;
+    if (kind == GMS_DESC_L2_F32X128) return ((size_t)total * 260 + (size_t)n_frames * 4 + 15) & ~(size_t)15;
+    if (kind == GMS_DESC_HAMMING256) return ((size_t)total * 260 + 15) & ~(size_t)15;
+    return 0;
 }
 
-hipError_t launch_bf_prepare(const void* d_desc, const int64_t* d_frame_off, int n_frames, int64_t total, void* d_prep, hipStream_t stream)
+hipError_t launch_bf_prepare(int kind, const void* d_desc, const int64_t* d_frame_off, int n_frames, int64_t total, void* d_prep,
+                             hipStream_t stream)
 {
     if (total <= 0) return hipSuccess;
     char* base = reinterpret_cast<char*>(d_prep);
+    if (kind == GMS_DESC_HAMMING256) {
+        const int64_t blocks = (total * 16 + 255) / 256;
+        hipLaunchKernelGGL(bf_ham_prepare_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, reinterpret_cast<const uint16_t*>(d_desc), total,
+                           reinterpret_cast<uint4*>(base), reinterpret_cast<int32_t*>(base + (size_t)total * 256));
+        return hipGetLastError();
+    }
     uint32_t* bad = reinterpret_cast<uint32_t*>(base + (size_t)total * 260);
     hipError_t e = hipMemsetAsync(bad, 0, (size_t)n_frames * 4, stream);
     if (e != hipSuccess) return e;
@@ -396,28 +512,33 @@ hipError_t launch_bf_match(int kind, const void* d_desc, const void* d_prep, int
                            const gms_pair* d_pairs, int n_pairs, int max_query, gms_dmatch* d_matches, hipStream_t stream)
 {
     if (n_pairs <= 0 || max_query <= 0) return hipSuccess;
+    const char* base = reinterpret_cast<const char*>(d_prep);
+    const uint32_t* norms = reinterpret_cast<const uint32_t*>(base + (size_t)total * 256);
+    const int tiles = (max_query + kQueriesPerBlock - 1) / kQueriesPerBlock;
+    const uint32_t n = (uint32_t)tiles * (uint32_t)n_pairs;
+    if (kind == GMS_DESC_HAMMING256 && d_prep != nullptr) {
+        hipLaunchKernelGGL(bf_mfma_kernel<true>, dim3(n), dim3(256), 0, stream, reinterpret_cast<const uint4*>(base), norms,
+                           (const uint32_t*)nullptr, d_desc, d_frame_off, n_frames, d_pairs, tiles, n, d_matches);
+        return hipGetLastError();
+    }
     if (kind == GMS_DESC_HAMMING256) {
-        // four query rows per lane when the launch fills the chip anyway, one when it does not
+        // no prepared block: the vector-ALU kernel on the raw rows; four query rows per lane when the launch fills the chip anyway
         const int tiles4 = (max_query + 1023) / 1024, tiles1 = (max_query + 255) / 256;
         if ((int64_t)tiles4 * n_pairs >= 1024) {
-            const uint32_t n = (uint32_t)tiles4 * (uint32_t)n_pairs;
-            hipLaunchKernelGGL(bf_hamming_kernel<4>, dim3(n), dim3(256), 0, stream, reinterpret_cast<const uint32_t*>(d_desc), d_frame_off,
-                               n_frames, d_pairs, tiles4, n, d_matches);
+            const uint32_t n4 = (uint32_t)tiles4 * (uint32_t)n_pairs;
+            hipLaunchKernelGGL(bf_hamming_kernel<4>, dim3(n4), dim3(256), 0, stream, reinterpret_cast<const uint32_t*>(d_desc), d_frame_off,
+                               n_frames, d_pairs, tiles4, n4, d_matches);
         } else {
-            const uint32_t n = (uint32_t)tiles1 * (uint32_t)n_pairs;
-            hipLaunchKernelGGL(bf_hamming_kernel<1>, dim3(n), dim3(256), 0, stream, reinterpret_cast<const uint32_t*>(d_desc), d_frame_off,
-                               n_frames, d_pairs, tiles1, n, d_matches);
+            const uint32_t n1 = (uint32_t)tiles1 * (uint32_t)n_pairs;
+            hipLaunchKernelGGL(bf_hamming_kernel<1>, dim3(n1), dim3(256), 0, stream, reinterpret_cast<const uint32_t*>(d_desc), d_frame_off,
+                               n_frames, d_pairs, tiles1, n1, d_matches);
         }
         return hipGetLastError();
     }
     if (kind == GMS_DESC_L2_F32X128) {
-        const char* base = reinterpret_cast<const char*>(d_prep);
-        const float* norms = reinterpret_cast<const float*>(base + (size_t)total * 256);
         const uint32_t* bad = reinterpret_cast<const uint32_t*>(base + (size_t)total * 260);
-        const int tiles = (max_query + kQueriesPerBlock - 1) / kQueriesPerBlock;
-        const uint32_t n = (uint32_t)tiles * (uint32_t)n_pairs;
-        hipLaunchKernelGGL(bf_l2_mfma_kernel, dim3(n), dim3(256), 0, stream, reinterpret_cast<const uint4*>(base), norms, bad, d_frame_off,
-                           n_frames, d_pairs, tiles, n, d_matches);
+        hipLaunchKernelGGL(bf_mfma_kernel<false>, dim3(n), dim3(256), 0, stream, reinterpret_cast<const uint4*>(base), norms, bad, d_desc,
+                           d_frame_off, n_frames, d_pairs, tiles, n, d_matches);
         // pairs with a frame that is not SIFT-like (every block of the other pairs returns at once)
         hipLaunchKernelGGL(bf_l2_loop_kernel<kL2Dim>, dim3(n), dim3(256), 0, stream, reinterpret_cast<const float*>(d_desc), bad, d_frame_off,
                            n_frames, d_pairs, tiles, d_matches);

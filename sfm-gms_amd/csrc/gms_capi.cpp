@@ -684,13 +684,12 @@ int gms_bf_prepare_device(gms_ctx* c, int desc_kind, const void* d_desc, const i
                           int64_t total_desc, void* d_prepared)
 {
     if (!c || n_frames < 0 || total_desc < 0) return GMS_ERR_BAD_ARG;
-    if (desc_kind == GMS_DESC_HAMMING256) return GMS_OK;  // nothing to prepare
-    if (desc_kind != GMS_DESC_L2_F32X128) return GMS_ERR_BAD_ARG;
+    if (desc_kind != GMS_DESC_HAMMING256 && desc_kind != GMS_DESC_L2_F32X128) return GMS_ERR_BAD_ARG;
     if (total_desc == 0 || n_frames == 0) return GMS_OK;
     if (!d_desc || !d_frame_off || !d_prepared) return GMS_ERR_BAD_ARG;
     std::lock_guard<std::mutex> lock(c->mu);
     GMS_HIP(hipSetDevice(c->device));
-    GMS_HIP(gms::launch_bf_prepare(d_desc, d_frame_off, n_frames, total_desc, d_prepared, c->stream));
+    GMS_HIP(gms::launch_bf_prepare(desc_kind, d_desc, d_frame_off, n_frames, total_desc, d_prepared, c->stream));
     return GMS_OK;
 }
 

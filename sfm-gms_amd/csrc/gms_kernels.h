@@ -69,7 +69,8 @@ size_t     tile_ws_bytes_per_pair(const FilterParams& p, int mcap, bool need_mas
 hipError_t launch_filter_tiles(const FilterParams& p, int mcap, void* ws, const uint32_t** flags_out, hipStream_t stream);
 // brute-force descriptor matcher (bf_kernels.hip)
 size_t     bf_prepared_bytes(int kind, int64_t total, int n_frames);
-hipError_t launch_bf_prepare(const void* d_desc, const int64_t* d_frame_off, int n_frames, int64_t total, void* d_prep, hipStream_t stream);
+hipError_t launch_bf_prepare(int kind, const void* d_desc, const int64_t* d_frame_off, int n_frames, int64_t total, void* d_prep,
+                             hipStream_t stream);
 hipError_t launch_bf_match(int kind, const void* d_desc, const void* d_prep, int64_t total, const int64_t* d_frame_off, int n_frames,
                            const gms_pair* d_pairs, int n_pairs, int max_query, gms_dmatch* d_matches, hipStream_t stream);
 // consumers of the filtered matches (consumer_kernels.hip)

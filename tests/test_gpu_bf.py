@@ -42,9 +42,10 @@ def test_hamming_small_frames_every_tail(ctx, pkg, oracle, synth):
     batch, table, dt = _tables(ctx, pkg, synth, descs, pkg.GMS_DESC_HAMMING256)
     ab = [(a, b) for a in range(len(counts)) for b in range(len(counts)) if a != b]
     pairs = _pairs(pkg, counts, ab)
-    got = batch.match_pairs(ctx, dt, pairs)
-    _check(oracle, descs, pairs, got, True)
-    assert (got["imgIdx"] == 0).all()
+    for use_prepared in (True, False):       # the matrix-core kernel, and the vector-ALU kernel on the raw rows
+        got = batch.match_pairs(ctx, dt, pairs, use_prepared)
+        _check(oracle, descs, pairs, got, True)
+        assert (got["imgIdx"] == 0).all()
 
 
 def test_hamming_many_pairs_take_the_four_rows_per_lane_kernel(ctx, pkg, oracle, synth):
@@ -52,8 +53,9 @@ def test_hamming_many_pairs_take_the_four_rows_per_lane_kernel(ctx, pkg, oracle,
     batch, table, dt = _tables(ctx, pkg, synth, descs, pkg.GMS_DESC_HAMMING256)
     ab = [(a, b) for a in range(12) for b in range(12) if a != b] * 5      # 660 pairs x 2 tiles >= 1024 blocks
     pairs = _pairs(pkg, [1500] * 12, ab)
-    got = batch.match_pairs(ctx, dt, pairs)
+    got = batch.match_pairs(ctx, dt, pairs, use_prepared=False)
     _check(oracle, descs, pairs[::37], got, True)
+    assert got.tobytes() == batch.match_pairs(ctx, dt, pairs).tobytes()   # the matrix-core kernel agrees on every pair
     first = got[:1500]
     assert (first["trainIdx"] == first["queryIdx"]).mean() > 0.95   # the same scene point is the nearest neighbour
 
@@ -62,8 +64,9 @@ def test_hamming_10k_config2(ctx, pkg, oracle, synth):
     descs = synth.sequence_descriptors(22, 2, 10000, "orb")
     batch, table, dt = _tables(ctx, pkg, synth, descs, pkg.GMS_DESC_HAMMING256, size=(1920, 1080))
     pairs = _pairs(pkg, [10000, 10000], [(0, 1), (1, 0)])
-    got = batch.match_pairs(ctx, dt, pairs)
-    _check(oracle, descs, pairs, got, True)
+    for use_prepared in (True, False):
+        got = batch.match_pairs(ctx, dt, pairs, use_prepared)
+        _check(oracle, descs, pairs, got, True)
 
 
 def test_l2_sift_like_rows_on_the_matrix_cores(ctx, pkg, oracle, synth):

@@ -18,6 +18,8 @@ batch = importlib.import_module("sfm-gms_amd.batch")
 d = importlib.import_module("sfm-gms_amd.dist")
 
 kind = sys.argv[1] if len(sys.argv) > 1 else "orb"
+use_prepared = "valu" not in kind
+kind = kind.replace("-valu", "")
 n_pairs = int(sys.argv[2]) if len(sys.argv) > 2 else 256
 n_kp, size = 10000, (1920, 1080)
 n_frames = 32
@@ -38,7 +40,7 @@ torch.cuda.synchronize()
 
 
 def run(with_filter):
-    dt.match_device(d_pairs.data_ptr(), n_pairs, n_kp, d_matches.data_ptr())
+    dt.match_device(d_pairs.data_ptr(), n_pairs, n_kp, d_matches.data_ptr(), use_prepared)
     if with_filter:
         ctx.filter_device(table.d_pts.data_ptr(), table.d_frame_off.data_ptr(), n_frames, d_pairs.data_ptr(), n_pairs, n_kp,
                           d_matches.data_ptr(), d_out.data_ptr(), d_res.data_ptr(), None, False, False, 6.0)
