@@ -208,6 +208,20 @@ int gms_gather_points_device(gms_ctx* ctx, const gms_keypoint* d_kp1, int n1, co
                              const gms_dmatch* d_matches, const int32_t* d_n_matches, int max_matches,
                              float* d_coords1, float* d_coords2, int32_t* d_status);
 
+/* gms_triangulate_device: SfMUtil.cpp:76-82 and 128-143 for the gathered points -- cv::undistortPoints (camera = fx, fy, cx, cy;
+ * dist = k1, k2, p1, p2, k3 or NULL), cv::triangulatePoints with the 3 x 4 row-major projection matrices P1, P2 (the reference
+ * uses [I|0] and [R|t] from recoverPose), division by the fourth coordinate. d_points3d receives 3 doubles per match;
+ * d_stats the sums of squared reprojection errors in both views (normalised image coordinates), the number of finite points
+ * and how many of them lie behind a camera. fp64; agrees with OpenCV's SVD-based routine to rounding, not bit for bit.
+ * camera / dist / P1 / P2 are HOST pointers (they travel as kernel arguments). */
+typedef struct gms_triangulation_stats {
+    double  sum_sq_err1, sum_sq_err2;
+    int64_t count, behind;
+} gms_triangulation_stats;
+int gms_triangulate_device(gms_ctx* ctx, const double camera[4], const double dist[5], const double P1[12], const double P2[12],
+                           const float* d_coords1, const float* d_coords2, const int32_t* d_n_matches, int max_matches,
+                           double* d_points3d, gms_triangulation_stats* d_stats);
+
 /* ---- ingest format -----------------------------------------------------------------------------------------
  * The reference keeps detector and matcher output in process (std::vector<cv::KeyPoint>, cv::Mat descriptors,
  * std::vector<cv::DMatch>: FeatureMatchUtil.cpp:9-12,58-68; DisparityUtil.cpp:108,137-143) and has no on-disk form. One

@@ -153,6 +153,16 @@ class GmsContext:
                                                   int(max_matches), d_coords1, d_coords2, d_status),
                self._lib, "gms_gather_points_device")
 
+    def triangulate_device(self, camera, dist, P1, P2, d_coords1, d_coords2, d_n_matches, max_matches, d_points3d, d_stats):
+        """gms_triangulate_device: camera = (fx, fy, cx, cy), dist = (k1, k2, p1, p2, k3) or None, P1 / P2 3 x 4 (host values)."""
+        cam = np.ascontiguousarray(camera, dtype=np.float64).reshape(4)
+        dc = None if dist is None else np.ascontiguousarray(dist, dtype=np.float64).reshape(5)
+        p1 = np.ascontiguousarray(P1, dtype=np.float64).reshape(12)
+        p2 = np.ascontiguousarray(P2, dtype=np.float64).reshape(12)
+        _check(self._lib.gms_triangulate_device(self._h, cam.ctypes.data, None if dc is None else dc.ctypes.data, p1.ctypes.data,
+                                                p2.ctypes.data, d_coords1, d_coords2, d_n_matches, int(max_matches), d_points3d,
+                                                d_stats), self._lib, "gms_triangulate_device")
+
     def selftest_threshold(self, T, n, score, factor):
         T = np.ascontiguousarray(T, dtype=np.int32)
         n = np.ascontiguousarray(n, dtype=np.int32)

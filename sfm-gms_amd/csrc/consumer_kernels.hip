@@ -104,7 +104,160 @@ gather_points_kernel(const gms_keypoint* __restrict__ kp1, int n1, const gms_key
     coords2[i] = make_float2(kp2[m.trainIdx].x, kp2[m.trainIdx].y);
 }
 
+// ---- two-view triangulation + reprojection error (SfMUtil.cpp:76-82,128-143) --------------------------------------------------------
+// Per surviving match: cv::undistortPoints with the camera matrix and (k1, k2, p1, p2, k3) -- the published five fixed-point
+// iterations -- gives normalised coordinates; cv::triangulatePoints' homogeneous DLT (rows x P[2] - P[0], y P[2] - P[1] of both
+// cameras, the right singular vector of the smallest singular value) gives X; SfMUtil.cpp:134-139 divides by X[3]. The singular
+// vector is computed as the eigenvector of the smallest eigenvalue of A^T A by cyclic Jacobi rotations in fp64 (a 4 x 4 symmetric
+// matrix: exact up to rounding after a few sweeps). Floating point, not bit-exact against OpenCV's SVD: the tests state the tolerance.
+struct CameraModel {
+    double fx, fy, cx, cy, k1, k2, p1, p2, k3;
+    double P1[12], P2[12];
+};
+
+__device__ inline void undistort_point(const CameraModel& c, double u, double v, double& xo, double& yo)
+{
+    const double x0 = (u - c.cx) / c.fx, y0 = (v - c.cy) / c.fy;
+    double x = x0, y = y0;
+    if (c.k1 != 0.0 || c.k2 != 0.0 || c.p1 != 0.0 || c.p2 != 0.0 || c.k3 != 0.0) {
+        for (int it = 0; it < 5; ++it) {
+            const double r2 = x * x + y * y;
+            const double icdist = 1.0 / (1.0 + ((c.k3 * r2 + c.k2) * r2 + c.k1) * r2);
+            const double dx = 2.0 * c.p1 * x * y + c.p2 * (r2 + 2.0 * x * x);
+            const double dy = c.p1 * (r2 + 2.0 * y * y) + 2.0 * c.p2 * x * y;
+            x = (x0 - dx) * icdist;
+            y = (y0 - dy) * icdist;
+        }
+    }
+    xo = x;
+    yo = y;
+}
+
+__global__ void __launch_bounds__(256)
+triangulate_kernel(CameraModel cam, const float2* __restrict__ coords1, const float2* __restrict__ coords2,
+                   const int32_t* __restrict__ n_matches, int cap, double* __restrict__ points3d, gms_triangulation_stats* __restrict__ stats)
+{
+    const int n = min(*n_matches, cap);
+    const int i = (int)(blockIdx.x * 256u + threadIdx.x);
+    double e1 = 0.0, e2 = 0.0;
+    unsigned long long cnt = 0, behind = 0;
+    if (i < n) {
+        double x1, y1, x2, y2;
+        undistort_point(cam, (double)coords1[i].x, (double)coords1[i].y, x1, y1);
+        undistort_point(cam, (double)coords2[i].x, (double)coords2[i].y, x2, y2);
+        double A[4][4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            A[0][k] = x1 * cam.P1[8 + k] - cam.P1[k];
+            A[1][k] = y1 * cam.P1[8 + k] - cam.P1[4 + k];
+            A[2][k] = x2 * cam.P2[8 + k] - cam.P2[k];
+            A[3][k] = y2 * cam.P2[8 + k] - cam.P2[4 + k];
+        }
+        double S[4][4], V[4][4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                S[a][b] = A[0][a] * A[0][b] + A[1][a] * A[1][b] + A[2][a] * A[2][b] + A[3][a] * A[3][b];
+                V[a][b] = a == b ? 1.0 : 0.0;
+            }
+        for (int sweep = 0; sweep < 12; ++sweep) {
+            double off = 0.0;
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = a + 1; b < 4; ++b) off += S[a][b] * S[a][b];
+            if (off < 1e-300) break;
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+#pragma unroll
+                for (int q = p + 1; q < 4; ++q) {
+                    if (S[p][q] == 0.0) continue;
+                    const double theta = (S[q][q] - S[p][p]) / (2.0 * S[p][q]);
+                    const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                    const double cs = 1.0 / sqrt(t * t + 1.0), sn = t * cs;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {  // S <- S J (columns p, q)
+                        const double skp = S[k][p], skq = S[k][q];
+                        S[k][p] = cs * skp - sn * skq;
+                        S[k][q] = sn * skp + cs * skq;
+                    }
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {  // S <- J^T S (rows p, q)
+                        const double spk = S[p][k], sqk = S[q][k];
+                        S[p][k] = cs * spk - sn * sqk;
+                        S[q][k] = sn * spk + cs * sqk;
+                    }
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const double vkp = V[k][p], vkq = V[k][q];
+                        V[k][p] = cs * vkp - sn * vkq;
+                        V[k][q] = sn * vkp + cs * vkq;
+                    }
+                }
+        }
+        int best = 0;
+#pragma unroll
+        for (int k = 1; k < 4; ++k) best = S[k][k] < S[best][best] ? k : best;
+        double X[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) X[k] = best == 0 ? V[k][0] : best == 1 ? V[k][1] : best == 2 ? V[k][2] : V[k][3];
+        const double px = X[0] / X[3], py = X[1] / X[3], pz = X[2] / X[3];  // SfMUtil.cpp:134-137
+        points3d[3 * (size_t)i] = px;
+        points3d[3 * (size_t)i + 1] = py;
+        points3d[3 * (size_t)i + 2] = pz;
+        // reprojection through both cameras, in normalised image coordinates
+        const double w1 = cam.P1[8] * px + cam.P1[9] * py + cam.P1[10] * pz + cam.P1[11];
+        const double w2 = cam.P2[8] * px + cam.P2[9] * py + cam.P2[10] * pz + cam.P2[11];
+        const double u1 = (cam.P1[0] * px + cam.P1[1] * py + cam.P1[2] * pz + cam.P1[3]) / w1 - x1;
+        const double v1 = (cam.P1[4] * px + cam.P1[5] * py + cam.P1[6] * pz + cam.P1[7]) / w1 - y1;
+        const double u2 = (cam.P2[0] * px + cam.P2[1] * py + cam.P2[2] * pz + cam.P2[3]) / w2 - x2;
+        const double v2 = (cam.P2[4] * px + cam.P2[5] * py + cam.P2[6] * pz + cam.P2[7]) / w2 - y2;
+        const bool finite = isfinite(px) && isfinite(py) && isfinite(pz) && isfinite(u1) && isfinite(v1) && isfinite(u2) && isfinite(v2);
+        if (finite) {
+            e1 = u1 * u1 + v1 * v1;
+            e2 = u2 * u2 + v2 * v2;
+            cnt = 1;
+            behind = (w1 <= 0.0 || w2 <= 0.0) ? 1 : 0;  // fails the cheirality test of recoverPose (SfMUtil.cpp:45)
+        }
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        e1 += __shfl_xor(e1, o);
+        e2 += __shfl_xor(e2, o);
+        cnt += __shfl_xor(cnt, o);
+        behind += __shfl_xor(behind, o);
+    }
+    if ((threadIdx.x & 63) == 0 && cnt) {
+        atomicAdd(&stats->sum_sq_err1, e1);
+        atomicAdd(&stats->sum_sq_err2, e2);
+        atomicAdd(reinterpret_cast<unsigned long long*>(&stats->count), cnt);
+        atomicAdd(reinterpret_cast<unsigned long long*>(&stats->behind), behind);
+    }
+}
+
 }  // namespace
+
+hipError_t launch_triangulate(const double* camera, const double* dist, const double* P1, const double* P2, const float* d_coords1,
+                              const float* d_coords2, const int32_t* d_n_matches, int max_matches, double* d_points3d,
+                              gms_triangulation_stats* d_stats, hipStream_t stream)
+{
+    CameraModel cam;
+    cam.fx = camera[0]; cam.fy = camera[1]; cam.cx = camera[2]; cam.cy = camera[3];
+    cam.k1 = dist ? dist[0] : 0.0; cam.k2 = dist ? dist[1] : 0.0; cam.p1 = dist ? dist[2] : 0.0; cam.p2 = dist ? dist[3] : 0.0;
+    cam.k3 = dist ? dist[4] : 0.0;
+    for (int k = 0; k < 12; ++k) {
+        cam.P1[k] = P1[k];
+        cam.P2[k] = P2[k];
+    }
+    hipError_t e = hipMemsetAsync(d_stats, 0, sizeof(gms_triangulation_stats), stream);
+    if (e != hipSuccess) return e;
+    if (max_matches > 0)
+        hipLaunchKernelGGL(triangulate_kernel, dim3((unsigned)((max_matches + 255) / 256)), dim3(256), 0, stream, cam,
+                           reinterpret_cast<const float2*>(d_coords1), reinterpret_cast<const float2*>(d_coords2), d_n_matches, max_matches,
+                           d_points3d, d_stats);
+    return hipGetLastError();
+}
 
 hipError_t launch_disparity(const gms_keypoint* d_kp1, int n1, const gms_keypoint* d_kp2, int n2, const gms_dmatch* d_matches,
                             const int32_t* d_n_matches, int max_matches, int w, int h, const uint8_t* d_gt, int disp_ratio,

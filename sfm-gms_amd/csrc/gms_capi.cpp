@@ -738,6 +738,19 @@ int gms_gather_points_device(gms_ctx* c, const gms_keypoint* d_kp1, int n1, cons
     return GMS_OK;
 }
 
+int gms_triangulate_device(gms_ctx* c, const double camera[4], const double dist[5], const double P1[12], const double P2[12],
+                           const float* d_coords1, const float* d_coords2, const int32_t* d_n_matches, int max_matches,
+                           double* d_points3d, gms_triangulation_stats* d_stats)
+{
+    if (!c || !camera || !P1 || !P2 || !d_n_matches || !d_stats || max_matches < 0) return GMS_ERR_BAD_ARG;
+    if (max_matches > 0 && (!d_coords1 || !d_coords2 || !d_points3d)) return GMS_ERR_BAD_ARG;
+    if (camera[0] == 0.0 || camera[1] == 0.0) return GMS_ERR_BAD_ARG;
+    std::lock_guard<std::mutex> lock(c->mu);
+    GMS_HIP(hipSetDevice(c->device));
+    GMS_HIP(gms::launch_triangulate(camera, dist, P1, P2, d_coords1, d_coords2, d_n_matches, max_matches, d_points3d, d_stats, c->stream));
+    return GMS_OK;
+}
+
 int gms_selftest_threshold(gms_ctx* c, const int32_t* T, const int32_t* n, const int32_t* score, double factor,
                            int count, uint8_t* out)
 {

@@ -80,6 +80,9 @@ hipError_t launch_disparity(const gms_keypoint* d_kp1, int n1, const gms_keypoin
 hipError_t launch_gather_points(const gms_keypoint* d_kp1, int n1, const gms_keypoint* d_kp2, int n2, const gms_dmatch* d_matches,
                                 const int32_t* d_n_matches, int max_matches, float* d_coords1, float* d_coords2, int32_t* d_status,
                                 hipStream_t stream);
+hipError_t launch_triangulate(const double* camera, const double* dist, const double* P1, const double* P2, const float* d_coords1,
+                              const float* d_coords2, const int32_t* d_n_matches, int max_matches, double* d_points3d,
+                              gms_triangulation_stats* d_stats, hipStream_t stream);
 hipError_t launch_threshold(const int32_t* d_T, const int32_t* d_n, const int32_t* d_score, double factor,
                             int count, uint8_t* d_out, hipStream_t stream);
 

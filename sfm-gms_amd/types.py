@@ -28,3 +28,4 @@ GMS_DESC_HAMMING256, GMS_DESC_L2_F32X128 = 0, 1
 # gms_disparity_stats (include/gms.h)
 DISPARITY_STATS_DTYPE = np.dtype([("count", "<i8"), ("sum_sq", "<i8"), ("max_abs", "<i4"), ("status", "<i4")])
 assert DISPARITY_STATS_DTYPE.itemsize == 24
+TRIANGULATION_STATS_DTYPE = np.dtype([("sum_sq_err1", "<f8"), ("sum_sq_err2", "<f8"), ("count", "<i8"), ("behind", "<i8")])

@@ -114,3 +114,85 @@ def test_no_ground_truth_no_matches_and_domain_errors(ctx, pkg, oracle, synth):
     far[3, 0] = 40.0             # lands outside the 32-pixel-wide map
     kept, disp, stats, c1, c2, st = _run(ctx, pkg, oracle, dict(base, kp1=synth.make_keypoints(far)), filtered=False)
     assert int(stats["status"]) == -2 and st == 0
+
+
+# ---- BASELINE config 5 on synthetic cameras: GMS -> matched points -> undistort -> triangulate -> reprojection error ------------
+def test_two_view_loop_on_synthetic_cameras(ctx, pkg, oracle, synth):
+    """3-D points seen by two calibrated cameras (SfMUtil.cpp's P1 = [I|0], P2 = [R|t]); half of the putative matches are wrong.
+    The GPU GMS feeds the GPU gather and triangulation; against the oracle's filter and a numpy SVD triangulation. Floating point
+    part: points agree to 1e-6 relative, error sums to 1e-9 relative + 1e-12."""
+    import torch
+    import sfm_ref
+    batch = importlib.import_module("sfm-gms_amd.batch")
+    types = importlib.import_module("sfm-gms_amd.types")
+    rng = np.random.default_rng(12)
+    n, size = 6000, (1920, 1080)
+    camera = (1400.0, 1380.0, 960.0, 540.0)
+    dist = (-0.12, 0.05, 0.001, -0.0007, 0.01)
+    ang = np.deg2rad(6.0)
+    R = np.array([[np.cos(ang), 0, np.sin(ang)], [0, 1, 0], [-np.sin(ang), 0, np.cos(ang)]])
+    t = np.array([[-0.6], [0.02], [0.05]])
+    P1 = np.hstack([np.eye(3), np.zeros((3, 1))])
+    P2 = np.hstack([R, t])
+    X = np.stack([rng.uniform(-2.2, 2.2, n), rng.uniform(-1.2, 1.2, n), rng.uniform(4.0, 9.0, n)], axis=1)
+
+    def project(P):
+        h = np.concatenate([X, np.ones((n, 1))], axis=1) @ P.T
+        x, y = h[:, 0] / h[:, 2], h[:, 1] / h[:, 2]
+        k1, k2, p1, p2, k3 = dist                       # forward distortion model
+        r2 = x * x + y * y
+        rad = 1 + ((k3 * r2 + k2) * r2 + k1) * r2
+        xd = x * rad + 2 * p1 * x * y + p2 * (r2 + 2 * x * x)
+        yd = y * rad + p1 * (r2 + 2 * y * y) + 2 * p2 * x * y
+        return np.stack([xd * camera[0] + camera[2], yd * camera[1] + camera[3]], axis=1)
+
+    uv1, uv2 = project(P1), project(P2)
+    ok = (uv1[:, 0] > 1) & (uv1[:, 0] < size[0] - 2) & (uv1[:, 1] > 1) & (uv1[:, 1] < size[1] - 2) & \
+         (uv2[:, 0] > 1) & (uv2[:, 0] < size[0] - 2) & (uv2[:, 1] > 1) & (uv2[:, 1] < size[1] - 2)
+    uv1, uv2 = uv1[ok].astype(np.float32), uv2[ok].astype(np.float32)
+    n = len(uv1)
+    assert n > 3000
+    kp1, kp2 = synth.make_keypoints(uv1), synth.make_keypoints(uv2)
+    train = np.arange(n)
+    wrong = rng.uniform(size=n) < 0.5
+    train[wrong] = rng.integers(0, n, int(wrong.sum()))
+    matches = synth.make_matches(np.arange(n), train, rng)
+
+    table = batch.FrameTable(ctx, [kp1, kp2], [size, size])
+    dev = table.device
+    pairs = np.zeros(1, dtype=pkg.PAIR_DTYPE)
+    pairs[0] = (0, 1, n, 0, 0)
+    d_pairs, d_matches = batch._to_dev(pairs, dev), batch._to_dev(matches, dev)
+    d_out = torch.zeros(n * 16, dtype=torch.uint8, device=dev)
+    d_res = torch.zeros(16, dtype=torch.uint8, device=dev)
+    d_c1 = torch.zeros(2 * n, dtype=torch.float32, device=dev)
+    d_c2 = torch.zeros(2 * n, dtype=torch.float32, device=dev)
+    d_st = torch.zeros(1, dtype=torch.int32, device=dev)
+    d_pts = torch.zeros(3 * n, dtype=torch.float64, device=dev)
+    d_stats = torch.zeros(32, dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    ctx.filter_device(table.d_pts.data_ptr(), table.d_frame_off.data_ptr(), 2, d_pairs.data_ptr(), 1, n, d_matches.data_ptr(),
+                      d_out.data_ptr(), d_res.data_ptr(), None, True, True, 6.0)        # FeatureMatchUtil.cpp:69 flags
+    kpb = types.KEYPOINT_DTYPE.itemsize
+    ctx.gather_points_device(table.d_kp.data_ptr(), n, table.d_kp.data_ptr() + n * kpb, n, d_out.data_ptr(), d_res.data_ptr(), n,
+                             d_c1.data_ptr(), d_c2.data_ptr(), d_st.data_ptr())
+    ctx.triangulate_device(camera, dist, P1, P2, d_c1.data_ptr(), d_c2.data_ptr(), d_res.data_ptr(), n, d_pts.data_ptr(),
+                           d_stats.data_ptr())
+    ctx.synchronize()
+    k = int(d_res.cpu().numpy().view(np.int32)[0])
+    rc, want, _, _ = oracle.match(size, size, kp1, kp2, matches, True, True, 6.0)
+    assert rc == 0 and k == len(want) and d_out.cpu().numpy().view(pkg.DMATCH_DTYPE)[:k].tobytes() == want.tobytes()
+    assert k > 0.8 * (~wrong).sum() and (want["queryIdx"] == want["trainIdx"]).mean() > 0.97
+    _, w1, w2 = oracle.gather(kp1, kp2, want)
+    xy1, xy2 = sfm_ref.undistort_points(w1, camera, dist), sfm_ref.undistort_points(w2, camera, dist)
+    ref = sfm_ref.triangulate(P1, P2, xy1, xy2)
+    got = d_pts.cpu().numpy().reshape(-1, 3)[:k]
+    true = (want["queryIdx"] == want["trainIdx"])
+    assert np.allclose(got[true], ref[true], rtol=1e-6, atol=1e-9)                      # well-conditioned (true correspondences)
+    stats = d_stats.cpu().numpy().view(types.TRIANGULATION_STATS_DTYPE)[0]
+    e1, e2, behind = sfm_ref.reprojection_sums(P1, P2, xy1, xy2, got)
+    assert int(stats["count"]) == k and int(stats["behind"]) == behind
+    assert abs(stats["sum_sq_err1"] - e1) <= 1e-9 * e1 + 1e-12 and abs(stats["sum_sq_err2"] - e2) <= 1e-9 * e2 + 1e-12
+    # the survivors that are true correspondences reconstruct the scene: reprojection error at the level of the fp32 pixel rounding
+    Xk = X[ok][want["queryIdx"]]
+    assert np.abs(got[true] - Xk[true]).max() < 2e-2
