@@ -8,8 +8,11 @@
 // layout-identical to gms_keypoint / gms_dmatch); without them the same-shaped PODs below stand in, so the
 // call sites compile unchanged apart from the namespace. Link with libgms_hip.so.
 #pragma once
+#include <algorithm>
+#include <cstdint>
 #include <stdexcept>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "gms.h"
@@ -69,6 +72,56 @@ inline void matchGMS(const Size& size1, const Size& size2, const std::vector<Key
     if (rc != GMS_OK) throw std::runtime_error(std::string("mi355::matchGMS: ") + gms_error_string(rc));
     out.resize((size_t)n_out);
     matchesGMS.swap(out);
+}
+
+// The same filter for a whole sequence in one call: what a caller looping `matchGMS` over image pairs (FeatureMatchUtil.cpp:66-69
+// once per pair) switches to for throughput. keypoints[f] / sizes[f] describe frame f; pair p filters matches1to2[p] between frames
+// pairs[p].first (query side) and pairs[p].second (train side); matchesGMS[p] receives the survivors. Host vectors in, host vectors
+// out: the library stages them through pinned memory on two streams (gms_filter_host_batch) and keeps the frames resident on the GPU
+// for the duration of the call. Pairs the reference has undefined behaviour on come back empty with ok[p] = false (if given).
+inline void matchGMSBatch(const std::vector<Size>& sizes, const std::vector<std::vector<KeyPoint>>& keypoints,
+                          const std::vector<std::pair<int, int>>& pairs, const std::vector<std::vector<DMatch>>& matches1to2,
+                          std::vector<std::vector<DMatch>>& matchesGMS, const bool withRotation = false, const bool withScale = false,
+                          const double thresholdFactor = 6.0, std::vector<bool>* ok = nullptr)
+{
+    if (sizes.size() != keypoints.size() || pairs.size() != matches1to2.size()) throw std::invalid_argument("mi355::matchGMSBatch: sizes");
+    static gms_ctx* ctx = nullptr;  // one context per process, created on first use
+    if (!ctx) {
+        const int rc = gms_ctx_create(0, &ctx);
+        if (rc != GMS_OK) throw std::runtime_error(std::string("mi355::matchGMSBatch: ") + gms_error_string(rc));
+    }
+    std::vector<int64_t> frame_off(keypoints.size() + 1, 0);
+    std::vector<int32_t> wh(2 * keypoints.size());
+    for (size_t f = 0; f < keypoints.size(); ++f) {
+        frame_off[f + 1] = frame_off[f] + (int64_t)keypoints[f].size();
+        wh[2 * f] = sizes[f].width;
+        wh[2 * f + 1] = sizes[f].height;
+    }
+    std::vector<KeyPoint> kp_all((size_t)frame_off.back());
+    for (size_t f = 0; f < keypoints.size(); ++f) std::copy(keypoints[f].begin(), keypoints[f].end(), kp_all.begin() + frame_off[f]);
+    std::vector<gms_pair> prs(pairs.size());
+    int64_t total = 0;
+    for (size_t p = 0; p < pairs.size(); ++p) {
+        prs[p] = gms_pair{pairs[p].first, pairs[p].second, (int32_t)matches1to2[p].size(), 0, total};
+        total += (int64_t)matches1to2[p].size();
+    }
+    std::vector<DMatch> m_all((size_t)total), out_all((size_t)total);
+    for (size_t p = 0; p < pairs.size(); ++p) std::copy(matches1to2[p].begin(), matches1to2[p].end(), m_all.begin() + prs[p].match_off);
+    std::vector<gms_pair_result> res(pairs.size());
+    const int rc = gms_filter_host_batch(ctx, reinterpret_cast<const gms_keypoint*>(kp_all.data()), frame_off.data(), wh.data(),
+                                         (int)keypoints.size(), prs.data(), (int)prs.size(), reinterpret_cast<const gms_dmatch*>(m_all.data()),
+                                         withRotation ? 1 : 0, withScale ? 1 : 0, thresholdFactor,
+                                         reinterpret_cast<gms_dmatch*>(out_all.data()), res.data());
+    if (rc != GMS_OK) throw std::runtime_error(std::string("mi355::matchGMSBatch: ") + gms_error_string(rc));
+    matchesGMS.assign(pairs.size(), std::vector<DMatch>());
+    if (ok) ok->assign(pairs.size(), true);
+    for (size_t p = 0; p < pairs.size(); ++p) {
+        if (res[p].status != GMS_OK) {
+            if (ok) (*ok)[p] = false;
+            continue;
+        }
+        matchesGMS[p].assign(out_all.begin() + prs[p].match_off, out_all.begin() + prs[p].match_off + res[p].n_inliers);
+    }
 }
 
 }  // namespace mi355

@@ -4,6 +4,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <exception>
+#include <utility>
 
 #include "mi355_gms.hpp"
 
@@ -37,6 +38,25 @@ int main()
                     sum = (sum ^ v) * 1099511628211ull;
             }
             std::printf("%zu %llu\n", out.size(), (unsigned long long)sum);
+        }
+        // the batch form: the same pair three times (forwards, with the roles of the frames swapped is another input, so: twice
+        // forwards with different flags would need two calls -- one call, one flag set) plus an empty pair in the middle
+        std::vector<std::vector<mi355::KeyPoint>> frames = {kp1, kp2};
+        std::vector<mi355::Size> sizes = {mi355::Size(w, h), mi355::Size(w, h)};
+        std::vector<std::pair<int, int>> prs = {{0, 1}, {0, 1}, {0, 1}};
+        std::vector<std::vector<mi355::DMatch>> in = {matches, {}, matches}, outs;
+        in[2].resize(n / 2);
+        std::vector<bool> ok;
+        mi355::matchGMSBatch(sizes, frames, prs, in, outs, true, true, 6.0, &ok);
+        for (size_t p = 0; p < outs.size(); ++p) {
+            uint64_t sum = 1469598103934665603ull;
+            for (const auto& m : outs[p]) {
+                uint32_t bits;
+                __builtin_memcpy(&bits, &m.distance, 4);
+                for (uint32_t v : {(uint32_t)m.queryIdx, (uint32_t)m.trainIdx, (uint32_t)m.imgIdx, bits})
+                    sum = (sum ^ v) * 1099511628211ull;
+            }
+            std::printf("%zu %llu %d\n", outs[p].size(), (unsigned long long)sum, (int)ok[p]);
         }
     } catch (const std::exception& e) {
         std::fprintf(stderr, "error: %s\n", e.what());

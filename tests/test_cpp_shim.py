@@ -66,3 +66,14 @@ def test_shim_matches_oracle(tmp_path, oracle, pkg, synth):
         for v in want.view(np.uint32).reshape(-1):
             s = ((s ^ int(v)) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
         assert (int(lines[2 * k]), int(lines[2 * k + 1])) == (len(want), s)
+    # the batch form (matchGMSBatch -> gms_filter_host_batch): the pair, an empty pair, the first half of the pair's matches
+    def checksum(arr):
+        s = 1469598103934665603
+        for v in arr.view(np.uint32).reshape(-1):
+            s = ((s ^ int(v)) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+        return s
+    kp1, kp2 = synth.make_keypoints(xy1), synth.make_keypoints(xy2)
+    for p, mm in enumerate((m, m[:0], m[: len(m) // 2])):
+        rc, want, _, _ = oracle.match(size, size, kp1, kp2, mm, True, True, 6.0)
+        assert rc == 0
+        assert [int(x) for x in lines[4 + 3 * p: 7 + 3 * p]] == [len(want), checksum(want), 1]
