@@ -250,9 +250,9 @@ int filter_launch(gms_ctx* c, hipStream_t st, const float* d_pts, const int64_t*
     // matrix) / 72 us (hashed) at 10k matches, in proportion to max_m -- in ticks of the 100 MHz wall clock. Only launches of
     // at least four dispatch rounds are staggered.
     p.stagger_ticks = 0;
-    if (n_pairs >= 4 * p.stagger_blocks && kpt) {
+    if (n_pairs >= 4 * p.stagger_blocks && kpt && max_m >= 2048) {  // (measured neutral at 4k matches, -1 % at 500: tools/measure_misc.py)
         const double us10k = knobs().stagger_us >= 0 ? (double)knobs().stagger_us : (p.dense ? 26.0 : 72.0);
-        p.stagger_ticks = (int)(us10k * 100.0 * std::max(max_m, 1024) / 10000.0);
+        p.stagger_ticks = (int)(us10k * 100.0 * max_m / 10000.0);
     }
 #ifdef GMS_PHASE_TIMING
     p.diag = g_diag;
@@ -493,27 +493,38 @@ int gms_match_ctx(gms_ctx* c, const gms_keypoint* kp1, int n1, int w1, int h1,
     if (m) std::memcpy(hin + off_m, matches, (size_t)m * sizeof(gms_dmatch));
     pack_xy(kp1, (size_t)n1, (float*)(hin + off_xy));
     pack_xy(kp2, (size_t)n2, (float*)(hin + off_xy) + 2 * (size_t)n1);
-    GMS_HIP(hipMemcpyAsync(L.din.p, hin, in_bytes, hipMemcpyHostToDevice, st));
+    // Small calls (up to 16k matches) skip the copy engines altogether: the kernels read the pinned block and write the pinned
+    // result block directly over PCIe (every input byte is read once -- the records stay in registers -- and every output byte
+    // written once), which saves the fixed cost of two DMA operations. Larger calls stage through device memory.
+    const bool zero_copy = m <= 16384;
     const char* din = (const char*)L.din.p;
+    char* dout = (char*)L.dout.p;
+    if (zero_copy) {
+        void *dev_in = nullptr, *dev_out = nullptr;
+        GMS_HIP(hipHostGetDevicePointer(&dev_in, L.hin.p, 0));
+        GMS_HIP(hipHostGetDevicePointer(&dev_out, L.hout.p, 0));
+        din = (const char*)dev_in;
+        dout = (char*)dev_out;
+    } else {
+        GMS_HIP(hipMemcpyAsync(L.din.p, hin, in_bytes, hipMemcpyHostToDevice, st));
+    }
     const int64_t* d_foff = (const int64_t*)din;
     const int32_t* d_wh = (const int32_t*)(din + offsetof(CallHeader, wh));
     const gms_pair* d_pair = (const gms_pair*)(din + offsetof(CallHeader, pair));
-    gms_pair_result* d_res = (gms_pair_result*)L.dout.p;
-    gms_dmatch* d_out = (gms_dmatch*)((char*)L.dout.p + sizeof(gms_pair_result));
+    gms_pair_result* d_res = (gms_pair_result*)dout;
+    gms_dmatch* d_out = (gms_dmatch*)(dout + sizeof(gms_pair_result));
     if (nkp) GMS_HIP(gms::launch_normalize(din + off_xy, 8, d_foff, d_wh, 2, (int64_t)nkp, (float*)c->tab_pts.p, st));
     GMS_TRY(filter_launch(c, st, (const float*)c->tab_pts.p, d_foff, 2, d_pair, 1, m, (const gms_dmatch*)(din + off_m),
                           with_rotation, with_scale, threshold_factor, d_out, d_res, nullptr));
-    // Calls up to 16k matches fetch the result record and all m output slots in the same round trip (256 KB over PCIe costs less
-    // than a second synchronisation); larger ones fetch the record first and then exactly the survivors.
-    const bool eager = m <= 16384;
-    GMS_HIP(hipMemcpyAsync(L.hout.p, L.dout.p, eager ? out_bytes : sizeof(gms_pair_result), hipMemcpyDeviceToHost, st));
+    // Staged calls fetch the result record first and then exactly the survivors.
+    if (!zero_copy) GMS_HIP(hipMemcpyAsync(L.hout.p, L.dout.p, sizeof(gms_pair_result), hipMemcpyDeviceToHost, st));
     GMS_HIP(hipStreamSynchronize(st));
     const gms_pair_result r = *(const gms_pair_result*)L.hout.p;
     if (result) *result = r;
     if (r.status != GMS_OK) return r.status;
     if (r.n_inliers < 0 || r.n_inliers > m) return GMS_ERR_HIP;  // (cannot happen: the kernels count what they wrote)
     const size_t keep_bytes = (size_t)r.n_inliers * sizeof(gms_dmatch);
-    if (!eager && keep_bytes) {
+    if (!zero_copy && keep_bytes) {
         GMS_HIP(hipMemcpyAsync((char*)L.hout.p + sizeof(gms_pair_result), d_out, keep_bytes, hipMemcpyDeviceToHost, st));
         GMS_HIP(hipStreamSynchronize(st));
     }
