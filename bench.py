@@ -41,12 +41,12 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--pairs", type=int, default=4096, help="image pairs per step per GPU (one chunk)")
+    ap.add_argument("--pairs", type=int, default=8192, help="image pairs per step per GPU (one chunk = one launch: 1.3 GB of matches in, up to 1.3 GB out)")
     ap.add_argument("--frames", type=int, default=1000, help="frames of the synthetic sequence (config 3: 1000)")
     ap.add_argument("--features", type=int, default=10000)
     ap.add_argument("--inlier-frac", type=float, default=0.5)
     ap.add_argument("--max-resident", type=int, default=24,
-                    help="chunks kept resident in HBM (1.3 GB each at the defaults); more steps cycle through them")
+                    help="chunks kept resident in HBM (2.6 GB each at the defaults); more steps cycle through them")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the all-core CPU baseline (0 = every CPU this process may use)")
     ap.add_argument("--cpu-reps", type=int, default=5)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg (profiling runs)")

@@ -5,7 +5,8 @@ set -e
 export TMPDIR=/tmp
 OUT=$PWD/gpurun_out/pmc
 rm -rf "$OUT"; mkdir -p "$OUT"
-ARGS="bench.py --steps 3 --warmup 1 --no-cpu --no-extra --pairs 1024"
+ARGS="$GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu --no-extra --pairs 1024"
+cd /tmp
 P1="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS"
 P2="SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_BRANCH SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INST_CYCLES_SALU"
 P3="SQ_INSTS_LDS_ATOMIC SQ_INSTS_LDS_LOAD SQ_INSTS_LDS_STORE SQ_LDS_ATOMIC_RETURN SQ_INSTS_VMEM SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VMEM SQ_INSTS_SMEM"

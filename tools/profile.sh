@@ -9,9 +9,10 @@ set -e
 export TMPDIR=/tmp
 OUT=$PWD/gpurun_out/prof
 rm -rf "$OUT"; mkdir -p "$OUT"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 bench.py > "$OUT/bench_under_trace.json" 2> "$OUT/trace.log" || { tail -5 "$OUT/trace.log"; exit 1; }
+cd /tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 "$GRAFT_REPO_ROOT/bench.py" > "$OUT/bench_under_trace.json" 2> "$OUT/trace.log" || { tail -5 "$OUT/trace.log"; exit 1; }
 for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $C --output-format csv -d "$OUT/pmc_$C" -- python3 bench.py --no-cpu --no-extra --steps 5 --warmup 2 > "$OUT/bench_under_$C.json" 2> "$OUT/pmc_$C.log" || { tail -5 "$OUT/pmc_$C.log"; exit 1; }
+  rocprofv3 --pmc $C --output-format csv -d "$OUT/pmc_$C" -- python3 "$GRAFT_REPO_ROOT/bench.py" --no-cpu --no-extra --steps 5 --warmup 2 > "$OUT/bench_under_$C.json" 2> "$OUT/pmc_$C.log" || { tail -5 "$OUT/pmc_$C.log"; exit 1; }
 done
 python3 - "$OUT" <<'PY'
 import csv, glob, json, sys
@@ -26,11 +27,11 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
     vals = []
     for fn in glob.glob(out + f"/pmc_{c}/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(fn)):
-            if "filter_kernel" in r.get("Kernel_Name", "") and r["Counter_Name"] == c:
+            if "filter_kernel_dense<" in r.get("Kernel_Name", "") and r["Counter_Name"] == c:
                 vals.append(float(r["Counter_Value"]))
     summary[c] = {"mean_per_launch": sum(vals) / len(vals) if vals else None, "launches": len(vals)}
 json.dump(summary, open(out + "/pmc_traffic_raw.json", "w"), indent=1)
 print(json.dumps(summary))
-for r in rows[:6]:
+for r in rows[:10]:
     print({k: r[k] for k in list(r.keys())[:6]})
 PY
