@@ -13,6 +13,7 @@
 #include <cstring>
 #include <mutex>
 #include <new>
+#include <thread>
 #include <vector>
 
 #include "gms.h"
@@ -297,6 +298,40 @@ int filter_launch(gms_ctx* c, hipStream_t st, const float* d_pts, const int64_t*
 // Staging block of a chunk, host (pinned) and device alike:  [ pairs (24 B each, 16-aligned) | matches (16 B each) ]
 // and coming back:                                            [ results (16 B each) | out (16 B each) ]
 size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
+
+// Host-side staging is memory-bound on one core (about 7 GB/s into pinned memory, a fraction of what PCIe moves): the copies of a
+// chunk are cut into jobs and run on a few threads.
+struct CopyJob {
+    void* dst;
+    const void* src;
+    size_t bytes;
+};
+void run_copy_jobs(const std::vector<CopyJob>& jobs)
+{
+    size_t total = 0;
+    for (const CopyJob& j : jobs) total += j.bytes;
+    unsigned hw = std::thread::hardware_concurrency();
+    const unsigned n_thr = (unsigned)std::min<size_t>(std::min<size_t>(hw ? hw : 4, 8), total / ((size_t)2 << 20) + 1);  // >= 2 MB per thread
+    auto work = [&](unsigned t) {
+        // thread t takes the byte range [t, t + 1) * total / n_thr of the concatenated jobs
+        const size_t lo = total * t / n_thr, hi = total * (t + 1) / n_thr;
+        size_t pos = 0;
+        for (const CopyJob& j : jobs) {
+            const size_t a = std::max(lo, pos), b = std::min(hi, pos + j.bytes);
+            if (a < b) std::memcpy((char*)j.dst + (a - pos), (const char*)j.src + (a - pos), b - a);
+            pos += j.bytes;
+            if (pos >= hi) break;
+        }
+    };
+    if (n_thr <= 1) {
+        work(0);
+        return;
+    }
+    std::vector<std::thread> pool;
+    for (unsigned t = 1; t < n_thr; ++t) pool.emplace_back(work, t);
+    work(0);
+    for (std::thread& th : pool) th.join();
+}
 
 // (pt.x, pt.y) of n keypoints, 8 bytes each: all the filter reads of a cv::KeyPoint (DLL@0x1800485d4) and all that has to
 // cross PCIe. Pure data movement; the divide by the image size happens on the GPU (normalize_kernel).
@@ -652,13 +687,16 @@ int gms_filter_host_batch(gms_ctx* c, const gms_keypoint* kp, const int64_t* fra
         const gms_pair_result* res = (const gms_pair_result*)L.hout.p;
         const gms_dmatch* o = (const gms_dmatch*)((const char*)L.hout.p + out_res_bytes);
         size_t local = 0;
+        std::vector<CopyJob> jobs;
+        jobs.reserve((size_t)ch.count);
         for (int i = 0; i < ch.count; ++i) {
             const gms_pair& pr = pairs[ch.first + i];
             results[ch.first + i] = res[i];
             if (res[i].status == GMS_OK && res[i].n_inliers > 0)
-                std::memcpy(out + pr.match_off, o + local, (size_t)res[i].n_inliers * sizeof(gms_dmatch));
+                jobs.push_back(CopyJob{out + pr.match_off, o + local, (size_t)res[i].n_inliers * sizeof(gms_dmatch)});
             local += (size_t)pr.m;
         }
+        run_copy_jobs(jobs);
         return GMS_OK;
     };
     for (size_t k = 0; k < chunks.size(); ++k) {
@@ -669,13 +707,16 @@ int gms_filter_host_batch(gms_ctx* c, const gms_keypoint* kp, const int64_t* fra
         gms_dmatch* hm = (gms_dmatch*)((char*)L.hin.p + in_pairs_bytes);
         size_t local = 0;
         int chunk_max_m = 0;
+        std::vector<CopyJob> jobs;
+        jobs.reserve((size_t)ch.count);
         for (int i = 0; i < ch.count; ++i) {
             const gms_pair& pr = pairs[ch.first + i];
             hp[i] = gms_pair{pr.frame_a, pr.frame_b, pr.m, 0, (int64_t)local};
-            if (pr.m) std::memcpy(hm + local, matches + pr.match_off, (size_t)pr.m * sizeof(gms_dmatch));
+            if (pr.m) jobs.push_back(CopyJob{hm + local, matches + pr.match_off, (size_t)pr.m * sizeof(gms_dmatch)});
             local += (size_t)pr.m;
             chunk_max_m = std::max(chunk_max_m, pr.m);
         }
+        run_copy_jobs(jobs);
         GMS_HIP(hipMemcpyAsync(L.din.p, L.hin.p, in_pairs_bytes + local * sizeof(gms_dmatch), hipMemcpyHostToDevice, L.stream));
         GMS_TRY(filter_launch(c, L.stream, (const float*)c->tab_pts.p, d_foff, n_frames, (const gms_pair*)L.din.p, ch.count,
                               chunk_max_m, (const gms_dmatch*)((const char*)L.din.p + in_pairs_bytes), with_rotation, with_scale,

@@ -69,6 +69,21 @@ __device__ __forceinline__ int rotated_position(int rot, int u) { return (int)((
 __device__ __forceinline__ int position_dx(int q) { return (int)((0x24924u >> (q << 1)) & 3u) - 1; }  // q % 3 - 1
 __device__ __forceinline__ int position_dy(int q) { return (int)((0x2a540u >> (q << 1)) & 3u) - 1; }  // q / 3 - 1
 
+// All of a rotation pattern in one word: for the eight outer neighbours k8 = 0..7 (positions 0,1,2,3,5,6,7,8 of the 3 x 3 block),
+// where pattern rot + 1 sends it, as (dx + 1) | (dy + 1) << 2 in bits 4 k8 .. 4 k8 + 3. A compile-time constant per rotation.
+constexpr uint32_t rotation_pack(int rot)
+{
+    constexpr int kRingIndex[9] = {0, 1, 2, 7, -1, 3, 6, 5, 4};  // position -> ring index
+    uint32_t w = 0;
+    for (int k8 = 0; k8 < 8; ++k8) {
+        const int k = k8 < 4 ? k8 : k8 + 1;
+        const int q = (int)((0x36785210u >> (((kRingIndex[k] - rot) & 7) << 2)) & 15u);
+        const int dx = (int)((0x24924u >> (q << 1)) & 3u), dy = (int)((0x2a540u >> (q << 1)) & 3u);  // already + 1
+        w |= (uint32_t)(dx | (dy << 2)) << (4 * k8);
+    }
+    return w;
+}
+
 // lane ^ 1 exchange on the VALU (DPP quad_perm [1,0,3,2]), no LDS round trip
 __device__ __forceinline__ uint32_t dpp_xor1(uint32_t x)
 {

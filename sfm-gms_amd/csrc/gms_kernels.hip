@@ -52,11 +52,13 @@ namespace gms {
 #ifdef GMS_PHASE_TIMING
 #define GMS_STAMP_DECL unsigned long long ph_[16] = {0}; unsigned long long t_prev_ = __builtin_readcyclecounter();
 #define GMS_STAMP(k) do { unsigned long long t_ = __builtin_readcyclecounter(); ph_[k] += t_ - t_prev_; t_prev_ = t_; } while (0)
-#define GMS_STAMP_FLUSH do { if (tid == 0 && p.diag) { for (int k_ = 0; k_ < 16; ++k_) p.diag[pair_idx * 16 + k_] = ph_[k_]; } } while (0)
+#define GMS_STAMP_FLUSH_AT(idx_) do { if (tid == 0 && p.diag) { for (int k_ = 0; k_ < 16; ++k_) p.diag[(size_t)(idx_) * 16 + k_] = ph_[k_]; } } while (0)
+#define GMS_STAMP_FLUSH GMS_STAMP_FLUSH_AT(pair_idx)
 #else
 #define GMS_STAMP_DECL
 #define GMS_STAMP(k)
 #define GMS_STAMP_FLUSH
+#define GMS_STAMP_FLUSH_AT(idx_)
 #endif
 
 // byte offset (0, 4, 8, 12) of the slot of bucket v whose key is r (kr = r << 21), or -1
@@ -763,7 +765,7 @@ __device__ __forceinline__ void hash_pair(const FilterParams& p, uint32_t* smem,
             if ((inm >> c) & 1u) *reinterpret_cast<uint4*>(&out[pos[c]]) = v[c];
     }
     GMS_STAMP(9);  // copy-out
-    GMS_STAMP_FLUSH;
+    GMS_STAMP_FLUSH_AT(pair_idx + (resumed ? p.n_pairs : 0));  // (behind the byte-matrix kernel's stamps of the same launch)
     if (tid == 0) {
         gms_pair_result r;
         r.n_inliers = failed ? 0 : (int)total;
@@ -1363,6 +1365,7 @@ __device__ __forceinline__ bool dense_scales_pair(const FilterParams& p, uint32_
     uint32_t* trash = smem + kDenseTrashOff / 4;
     uint32_t* bestmask = smem + kDenseBestMaskOff / 4;
 
+    GMS_STAMP_DECL
     if (tid < 32) misc[tid] = 0;
     if (tid < 16) trash[tid] = 0;
     if (tid < kFineN / 4) nfine32[tid] = 0;
@@ -1392,9 +1395,10 @@ __device__ __forceinline__ bool dense_scales_pair(const FilterParams& p, uint32_
     __syncthreads();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (see dense_pair: the left-side gathers go out together)
 
+    GMS_STAMP(4);  // records and frame B landed
     // code word as in dense_pair (E = E(r) of the current scale, 10 bits); cell1 = left cell under grid type 1; rs = the
     // right cells of scales 1, 2 and 3 (bits 0..7, 8..15, 16..25)
-    uint32_t code[KPT], cell1[KPT], rs[KPT];
+    uint32_t code[KPT], aux[KPT];  // aux = left cell under grid type 1 : 9 | right cell on the 20 x 20 grid : 9 | on the 28 x 28 grid : 10
     {
         float2 a[KPT], b[KPT];
 #pragma unroll
@@ -1434,8 +1438,8 @@ __device__ __forceinline__ bool dense_scales_pair(const FilterParams& p, uint32_
             const uint32_t q = (hx & 1u) + __umul24(hy & 1u, 20u);
             const uint32_t edge = ((hx + 25u) & kDEdgeX) | ((hy + 89u) & kDEdgeY);
             code[k] = binned ? (q | edge | ((403u - r[0]) << kDEShift)) : kDNever;
-            cell1[k] = binned ? __umul24(hy >> 1, (uint32_t)kLeftW) + (hx >> 1) : 0u;
-            rs[k] = binned ? (r[1] | (r[2] << 8) | (r[3] << 16)) : 0u;
+            // (the 10 x 10 and 14 x 14 cells follow from the 20 x 20 and 28 x 28 ones: fl(10 n) = fl(20 n) / 2 exactly, and 14 / 28 alike)
+            aux[k] = binned ? ((__umul24(hy >> 1, (uint32_t)kLeftW) + (hx >> 1)) | (r[0] << 9) | (r[3] << 18)) : 0u;
         }
         if (any_bad) misc[8] = 1;
         if (spill) misc[13] = 1;  // (not misc[11]: that one is written again while slower waves may still be reading this)
@@ -1463,18 +1467,9 @@ __device__ __forceinline__ bool dense_scales_pair(const FilterParams& p, uint32_
     // are taken 8 at a time, each band with one halo row on either side in LDS (at most 10 rows = 157 600 bytes); per
     // grid type a band bins the matches of the rows it holds, verifies and marks its own rows' cells and takes every
     // increment back before the next band.
-    // With rotation a thread always verifies the same rotation (item & 7 == tid & 7): where the rotation pattern sends each
-    // of the eight outer neighbours is worked out once, as (dx + 1) | (dy + 1) << 2 in four bits per neighbour.
-    uint32_t rot_pack = 0;
-    if (ROT) {
-#pragma unroll
-        for (int k8 = 0; k8 < 8; ++k8) {
-            const int k = k8 < 4 ? k8 : k8 + 1;
-            constexpr int kRingIndex[9] = {0, 1, 2, 7, -1, 3, 6, 5, 4};  // position -> ring index
-            const int q = rotated_position(tid & 7, kRingIndex[k]);
-            rot_pack |= (uint32_t)((position_dx(q) + 1) | ((position_dy(q) + 1) << 2)) << (4 * k8);
-        }
-    }
+    // With rotation a lane verifies four of the eight rotations of its cell (two lanes per cell: item & 1 == tid & 1 picks
+    // rotations 0..3 or 4..7; the left side of the nine neighbour pairs is shared by the four). Where a rotation pattern sends the
+    // eight outer neighbours is a compile-time word (rotation_pack): the lane selects its four at the point of use.
 
     // returns 0 = done, 1 = a cell above 255 matches (everything is run again CROWDED), 2 = a matrix entry at its limit
     auto run_scale = [&](auto banded_c, auto crowded_c, const int s) -> int {
@@ -1486,7 +1481,14 @@ __device__ __forceinline__ bool dense_scales_pair(const FilterParams& p, uint32_
         if (s > 0) {
 #pragma unroll
             for (int k = 0; k < KPT; ++k) {
-                const uint32_t r = s == 1 ? (rs[k] & 0xFFu) : s == 2 ? ((rs[k] >> 8) & 0xFFu) : (rs[k] >> 16);
+                uint32_t r;
+                if (s == 3) {
+                    r = aux[k] >> 18;
+                } else {  // halve the finer grid's cell coordinates: 20 -> 10 (s == 1), 28 -> 14 (s == 2)
+                    const uint32_t fine = s == 1 ? (aux[k] >> 9) & 0x1FFu : aux[k] >> 18, wf = s == 1 ? 20u : 28u;
+                    const uint32_t fy = (fine * (s == 1 ? 3277u : 2341u)) >> 16, fx = fine - fy * wf;  // fine / wf for fine < 784
+                    r = (fy >> 1) * (wf >> 1) + (fx >> 1);
+                }
                 if (!(code[k] & kDNever)) code[k] = (code[k] & ~(kSEMask << kDEShift)) | ((nr + 3u - r) << kDEShift);
             }
         }
@@ -1506,7 +1508,7 @@ __device__ __forceinline__ bool dense_scales_pair(const FilterParams& p, uint32_
 #pragma unroll
                 for (int k = 0; k < KPT; ++k) {
                     const uint32_t cw = code[k];
-                    const uint32_t l = cell1[k] + (cw & q_mask);
+                    const uint32_t l = (aux[k] & 0x1FFu) + (cw & q_mask);
                     if ((cw & out_mask) == 0) atomicAdd(&nl32cur[l >> 1], 1u << ((l & 1u) << 4));
                 }
             }
@@ -1528,7 +1530,7 @@ __device__ __forceinline__ bool dense_scales_pair(const FilterParams& p, uint32_
 #pragma unroll
                     for (int c = 0; c < kChunk; ++c) {
                         const uint32_t cw = code[k0 + c];
-                        const uint32_t l = cell1[k0 + c] + (cw & q_mask) - cell0;
+                        const uint32_t l = (aux[k0 + c] & 0x1FFu) + (cw & q_mask) - cell0;
                         in[c] = (cw & out_mask) == 0 && (!BANDED || l < n_held);
                         row[c] = __umul24(l, stride);
                         at[c] = row[c] + ((cw >> kDEShift) & kSEMask);
@@ -1543,7 +1545,9 @@ __device__ __forceinline__ bool dense_scales_pair(const FilterParams& p, uint32_
                         if (in[c]) atomicMax(lds_at(smem, row[c]), key_tag | (before << 11) | ((code[k0 + c] >> kDEShift) & kSEMask));
                     }
                 }
+                GMS_STAMP(3);  // insert
                 __syncthreads();
+                GMS_STAMP(11);  // insert: wait for the other waves
                 if (!CROWDED && misc[11] != 0) {  // a cell above 255 matches (workgroup-uniform; nothing has been written out)
                     status = 1;
                     break;
@@ -1553,12 +1557,17 @@ __device__ __forceinline__ bool dense_scales_pair(const FilterParams& p, uint32_
                     break;
                 }
 
-                // ---- verifyCellPairs for the cells of the own rows
+                // ---- verifyCellPairs for the cells of the own rows. Without rotation: two lanes per left cell, four of the eight outer
+                //      neighbour pairs each. With rotation: four lanes per cell, two of the eight rotations each over all eight pairs
+                //      (the left side of a pair is shared by the lane's rotations; 1600 items instead of 3200).
                 {
-                    const int n_items = (int)n_own * (ROT ? 8 : 2);
+                    constexpr int kNR = ROT ? 2 : 1;             // rotations per lane
+                    constexpr int kLanesPerCell = ROT ? 4 : 2, kCellShift = ROT ? 2 : 1;
+                    const int n_items = (int)n_own * kLanesPerCell;
                     for (int item = tid; item < ((n_items + 63) & ~63); item += NT) {
                         const bool live = item < n_items;
-                        const int i = (int)own0 + (live ? (ROT ? (item >> 3) : (item >> 1)) : 0);
+                        const int i = (int)own0 + (live ? (item >> kCellShift) : 0);
+                        const int sub = item & (kLanesPerCell - 1);
                         const int half = item & 1;  // !ROT only
                         const int ix = i % kLeftW, iy = i / kLeftW;
                         const uint32_t ni = live ? (CROWDED ? (uint32_t)nl16cur[i] : (uint32_t)nleft8[i]) : 0u;
@@ -1568,55 +1577,68 @@ __device__ __forceinline__ bool dense_scales_pair(const FilterParams& p, uint32_
                         const uint32_t ej = ni ? (best & 0x7FFu) : nr + 3u;
                         const uint32_t j = nr + 3u - ej;
                         const int jy = (int)((j * wr_magic) >> 16), jx = (int)j - jy * (int)wr;
-                        uint32_t score = 0, tn = 0;  // tn = (sum of nLeft << 4) | numpair
+                        uint32_t score[kNR], tn[kNR];  // tn = (sum of nLeft << 4) | numpair
+                        uint32_t rpack[kNR];           // where the lane's rotations send the eight outer neighbours (rotation_pack)
 #pragma unroll
-                        for (int h = 0; h < (ROT ? 8 : 4); h += 4) {
+                        for (int jr = 0; jr < kNR; ++jr) {
+                            score[jr] = tn[jr] = 0;
+                            rpack[jr] = sub == 0 ? rotation_pack(jr) : sub == 1 ? rotation_pack(2 + jr) : sub == 2 ? rotation_pack(4 + jr) : rotation_pack(6 + jr);
+                        }
 #pragma unroll
-                            for (int c = 0; c < 4; ++c) {
-                                int ldx, ldy, rdx, rdy;
+                        for (int c = 0; c < (ROT ? 8 : 4); ++c) {
+                            int ldx, ldy;
+                            if (ROT) {
+                                const int k = c < 4 ? c : c + 1;
+                                ldx = (k % 3) - 1; ldy = (k / 3) - 1;
+                            } else {
+                                ldx = half ? ((c + 5) % 3) - 1 : (c % 3) - 1;
+                                ldy = half ? ((c + 5) / 3) - 1 : (c / 3) - 1;
+                            }
+                            const int lx = ix + ldx, ly = iy + ldy;
+                            const bool okl = ni != 0 && (uint32_t)lx < (uint32_t)kLeftW && (uint32_t)ly < (uint32_t)kLeftH;
+                            const uint32_t ll = okl ? (uint32_t)(lx + ly * kLeftW) : (uint32_t)i;  // within one row of an own row: held
+                            const uint32_t nll = CROWDED ? (uint32_t)nl16cur[ll] : (uint32_t)nleft8[ll];
+                            const uint32_t rowb = (ll - cell0) * stride;
+#pragma unroll
+                            for (int jr = 0; jr < kNR; ++jr) {
+                                int rdx = ldx, rdy = ldy;
                                 if (ROT) {
-                                    const int k8 = h + c;
-                                    const int k = k8 < 4 ? k8 : k8 + 1;
-                                    ldx = (k % 3) - 1; ldy = (k / 3) - 1;
-                                    rdx = (int)((rot_pack >> (4 * k8)) & 3u) - 1;
-                                    rdy = (int)((rot_pack >> (4 * k8 + 2)) & 3u) - 1;
-                                } else {
-                                    ldx = half ? ((c + 5) % 3) - 1 : (c % 3) - 1;
-                                    ldy = half ? ((c + 5) / 3) - 1 : (c / 3) - 1;
-                                    rdx = ldx; rdy = ldy;
+                                    rdx = (int)((rpack[jr] >> (4 * c)) & 3u) - 1;
+                                    rdy = (int)((rpack[jr] >> (4 * c + 2)) & 3u) - 1;
                                 }
-                                const int lx = ix + ldx, ly = iy + ldy;
                                 const int rx = jx + rdx, ry = jy + rdy;
-                                const bool okl = ni != 0 && (uint32_t)lx < (uint32_t)kLeftW && (uint32_t)ly < (uint32_t)kLeftH;
                                 const bool okp = okl && (uint32_t)rx < wr && (uint32_t)ry < wr;
-                                const uint32_t ll = okl ? (uint32_t)(lx + ly * kLeftW) : (uint32_t)i;  // within one row of an own row: held
-                                const uint32_t nll = CROWDED ? (uint32_t)nl16cur[ll] : (uint32_t)nleft8[ll];
-                                const uint32_t cnt = dense8[(ll - cell0) * stride + (okp ? nr + 3u - (uint32_t)(rx + ry * (int)wr) : 4u)];
-                                score += okp ? cnt : 0u;
-                                tn += okp ? ((nll << 4) | 1u) : 0u;
+                                const uint32_t cnt = dense8[rowb + (okp ? nr + 3u - (uint32_t)(rx + ry * (int)wr) : 4u)];
+                                score[jr] += okp ? cnt : 0u;
+                                tn[jr] += okp ? ((nll << 4) | 1u) : 0u;
                             }
                         }
+                        uint32_t bits = 0;
                         if (!ROT) {
-                            score += dpp_xor1(score);
-                            tn += dpp_xor1(tn);
+                            score[0] += dpp_xor1(score[0]);
+                            tn[0] += dpp_xor1(tn[0]);
                         }
-                        score += (best >> 11) + 1u;
-                        tn += (ni << 4) | 1u;
-                        uint32_t pass = 0;
-                        if (ni != 0 && (ROT || half == 0))
-                            pass = (CROWDED ? threshold_rejects(tn >> 4, tn & 15u, score, p.threshold_factor, thr_fast)
-                                            : dense_threshold_rejects(tn >> 4, tn & 15u, score, p.threshold_factor, thr_fast, f2i)) ? 0u : 1u;
-                        uint32_t bits = pass;
-                        bool writer = ni != 0 && half == 0;
-                        if (ROT) {
-                            const unsigned long long bal = __ballot(pass);
-                            bits = (uint32_t)(bal >> (lane & 56)) & 0xFFu;
-                            writer = ni != 0 && (lane & 7) == 0;
+#pragma unroll
+                        for (int jr = 0; jr < kNR; ++jr) {
+                            const uint32_t sc = score[jr] + (best >> 11) + 1u, t = tn[jr] + ((ni << 4) | 1u);
+                            uint32_t pass = 0;
+                            if (ni != 0 && (ROT || half == 0))
+                                pass = (CROWDED ? threshold_rejects(t >> 4, t & 15u, sc, p.threshold_factor, thr_fast)
+                                                : dense_threshold_rejects(t >> 4, t & 15u, sc, p.threshold_factor, thr_fast, f2i)) ? 0u : 1u;
+                            bits |= pass << jr;
                         }
-                        if (writer) smem[hdr] = (ej << 8) | bits;
+                        if (ROT) {  // the cell's four lanes hold rotations (0,1) (2,3) (4,5) (6,7): gather the quad's bit pairs (DPP quad_perm broadcasts)
+                            const uint32_t b0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)bits, 0x00, 0xF, 0xF, false);
+                            const uint32_t b1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)bits, 0x55, 0xF, 0xF, false);
+                            const uint32_t b2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)bits, 0xAA, 0xF, 0xF, false);
+                            const uint32_t b3 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)bits, 0xFF, 0xF, 0xF, false);
+                            bits = b0 | (b1 << 2) | (b2 << 4) | (b3 << 6);
+                        }
+                        if (ni != 0 && sub == 0) smem[hdr] = (ej << 8) | bits;
                     }
                 }
                 __syncthreads();
+                GMS_STAMP(5);  // verify
 
                 // ---- mark the matches of the own rows; every increment of the rows held is taken back
                 {
@@ -1625,7 +1647,7 @@ __device__ __forceinline__ bool dense_scales_pair(const FilterParams& p, uint32_
 #pragma unroll
                     for (int k = 0; k < KPT; ++k) {
                         const uint32_t cw = code[k];
-                        const uint32_t l = cell1[k] + (cw & q_mask);
+                        const uint32_t l = (aux[k] & 0x1FFu) + (cw & q_mask);
                         const uint32_t row = __umul24(l - cell0, stride);
                         cr[k] = 0xFFFFFFFFu;
                         if ((cw & out_mask) == 0 && (!BANDED || l - cell0 < n_held)) {
@@ -1641,6 +1663,7 @@ __device__ __forceinline__ bool dense_scales_pair(const FilterParams& p, uint32_
                     }
                 }
                 __syncthreads();
+                GMS_STAMP(6);  // mark
             }
             if (status != 0) break;
         }
@@ -1692,6 +1715,7 @@ __device__ __forceinline__ bool dense_scales_pair(const FilterParams& p, uint32_
         for (int k = 0; k < KPT; ++k) code[k] &= ~(0xFFu << kSAccShift);
         __syncthreads();
         if (tid < 8) misc[tid] = 0;
+        GMS_STAMP(7);  // count + select
         return 0;
     };
 
@@ -1731,6 +1755,8 @@ __device__ __forceinline__ bool dense_scales_pair(const FilterParams& p, uint32_
         part[3] = (uint32_t)best_rot;
     }
     for (int i = tid; i < (kMcap >> 5); i += NT) part[kPartialHeaderDw + i] = best_count ? bestmask[i] : 0u;
+    GMS_STAMP(9);  // record written
+    GMS_STAMP_FLUSH;
     return true;
 }
 

@@ -38,22 +38,25 @@ def main():
     ctx.set_stream(stream.cuda_stream)
     args = argparse.Namespace(pairs=a.pairs, frames=200, features=a.features, inlier_frac=0.5, warmup=1, steps=1, max_resident=2)
     wl = bench.Workload(args, 0, 1, dev, pkg, ctx)
-    dbuf = torch.zeros(a.pairs * 16, dtype=torch.int64, device=dev)
+    dbuf = torch.zeros(2 * a.pairs * 16, dtype=torch.int64, device=dev)  # with scale hypotheses: first kernel's stamps, then the second's
     lib.gms_diag_set_buffer.argtypes = [C.c_void_p]
     lib.gms_diag_set_buffer(dbuf.data_ptr())
     for _ in range(3):
         with torch.cuda.stream(stream):
             wl.launch(ctx, 0, bool(a.rot), bool(a.scale))
     torch.cuda.synchronize()
-    raw = dbuf.cpu().numpy().reshape(-1, 16)
-    if a.starts:
-        np.save(a.starts, raw[:, 14:16])
-    d = raw[:, :16].astype(np.float64)
-    d[:, 14:16] = 0
-    mean = d.mean(axis=0)
-    tot = mean.sum()
-    out = {"pairs": a.pairs, "rot": a.rot, "scale": a.scale, "total_cycles": tot,
-           "phases": {n: {"cycles": float(c), "share": float(c / tot)} for n, c in zip(PHASES, mean)}}
+    raw_all = dbuf.cpu().numpy().reshape(2, -1, 16)
+    out = {"pairs": a.pairs, "rot": a.rot, "scale": a.scale}
+    for name, raw in (("kernel_1", raw_all[0]), ("kernel_2_scale4_hashed", raw_all[1])):
+        if name != "kernel_1" and not raw.any():
+            continue
+        if a.starts and name == "kernel_1":
+            np.save(a.starts, raw[:, 14:16])
+        d = raw[:, :16].astype(np.float64)
+        d[:, 14:16] = 0
+        mean = d.mean(axis=0)
+        tot = mean.sum()
+        out[name] = {"total_cycles": tot, "phases": {n: {"cycles": float(c), "share": float(c / tot)} for n, c in zip(PHASES, mean) if c > 0}}
     print(json.dumps(out, indent=1))
 
 
