@@ -49,6 +49,8 @@ def parse():
                     help="chunks kept resident in HBM (2.6 GB each at the defaults); more steps cycle through them")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the all-core CPU baseline (0 = every CPU this process may use)")
     ap.add_argument("--cpu-reps", type=int, default=5)
+    ap.add_argument("--spatial-order", action="store_true",
+                    help="diagnostic: keypoints listed cell by cell instead of in random order (LDS bank-conflict experiment, DESIGN.md 6)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg (profiling runs)")
     ap.add_argument("--no-extra", action="store_true", help="skip the rot+scale side measurement")
     return ap.parse_args()
@@ -76,7 +78,8 @@ class Workload:
         batch = importlib.import_module(PKG + ".batch")
         self.dist = importlib.import_module(PKG + ".dist")
         self.n_kp = args.features
-        self.frames = synth.make_sequence(1000, args.frames, size=SIZE, n_kp=self.n_kp)  # the same sequence on every rank
+        self.frames = synth.make_sequence(1000, args.frames, size=SIZE, n_kp=self.n_kp,  # the same sequence on every rank
+                                          spatial_order=getattr(args, "spatial_order", False))
         self.table = batch.FrameTable(ctx, self.frames, [SIZE] * args.frames, device=dev)
         n_chunks = min(args.warmup + args.steps, max(1, args.max_resident))
         self.plan = self.dist.RankPlan(args.frames, self.n_kp, args.pairs, n_chunks, rank, world)

@@ -72,7 +72,7 @@ def make_pair(case_id, size1=(1920, 1080), size2=None, n1=10000, n2=None, inlier
     return kp1, kp2, matches
 
 
-def make_sequence(case_id, n_frames, size=(1920, 1080), n_kp=10000, drift_px=6.0, noise_px=1.5):
+def make_sequence(case_id, n_frames, size=(1920, 1080), n_kp=10000, drift_px=6.0, noise_px=1.5, spatial_order=False):
     """A sequence of frames observing one scene under a slow drift (BASELINE config 3): frame f sees
     base point i at base[i] + f * drift + noise (kept inside the image), so keypoint i of frame a
     truly corresponds to keypoint i of frame b."""
@@ -81,6 +81,9 @@ def make_sequence(case_id, n_frames, size=(1920, 1080), n_kp=10000, drift_px=6.0
     margin = 0.15
     base = np.stack([rng.uniform(margin * w, (1 - margin) * w, n_kp),
                      rng.uniform(margin * h, (1 - margin) * h, n_kp)], axis=1)
+    if spatial_order:  # keypoint index follows the 20 x 20 cell (a detector that emits row by row): neighbours in the list share cells
+        cell = (base[:, 1] * 20 // h).astype(np.int64) * 20 + (base[:, 0] * 20 // w).astype(np.int64)
+        base = base[np.argsort(cell, kind="stable")]
     direction = rng.uniform(-1, 1, 2)
     direction /= np.linalg.norm(direction)
     frames = []

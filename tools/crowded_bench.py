@@ -35,16 +35,16 @@ for name, fn in (("uniform", orig), ("crowded", squeezed)):
     dev = torch.device("cuda", 0)
     stream = torch.cuda.Stream(device=dev)
     ctx.set_stream(stream.cuda_stream)
-    args = argparse.Namespace(pairs=4096, frames=128, features=10000, inlier_frac=0.5)
-    wl = bench.build_workload(args, 0, 1, dev, pkg, synth, ctx)
+    args = argparse.Namespace(pairs=4096, frames=200, features=10000, inlier_frac=0.5, warmup=2, steps=10, max_resident=12)
+    wl = bench.Workload(args, 0, 1, dev, pkg, ctx)
     w, k = bench.timed_steps(ctx, wl, stream, 10, 2, False, False, None)
-    rate_mt, rate1, ok, n = bench.cpu_leg(argparse.Namespace(cpu_pairs=64, cpu_threads=16), wl, pkg, False, False, 64, 16)
-    out[name] = {"pairs_per_s": 4096 * 10 / w, "kernel_ms": k, "parity_64_pairs": ok}
-    sub = dict(wl)
-    sub["n_pairs"] = 512
-    w2, k2 = bench.timed_steps(ctx, sub, stream, 6, 2, True, True, None)
-    rate_mt2, rate12, ok2, n2 = bench.cpu_leg(argparse.Namespace(cpu_pairs=16, cpu_threads=16), sub, pkg, True, True, 16, 16)
+    c, b = bench.check_parity(wl, pkg, range(len(wl.chunks)), False, False, sample={i: list(range(0, 4096, 512)) for i in range(len(wl.chunks))})
+    out[name] = {"pairs_per_s": 4096 * 10 / w, "kernel_ms": k, "parity_pairs": c, "mismatches": b}
+    w2, k2 = bench.timed_steps(ctx, wl, stream, 6, 2, True, True, None, n_pairs=512)
+    used = sorted({(2 + s) % len(wl.chunks) for s in range(6)})
+    c2, b2 = bench.check_parity(wl, pkg, used, True, True, sample={i: list(range(0, 512, 128)) for i in used})
     out[name]["rot_scale_pairs_per_s"] = 512 * 6 / w2
-    out[name]["rot_scale_parity_16_pairs"] = ok2
+    out[name]["rot_scale_parity_pairs"] = c2
+    out[name]["rot_scale_mismatches"] = b2
     ctx.close()
 print(json.dumps(out, indent=1))
