@@ -19,8 +19,8 @@ import argparse  # noqa: E402
 orig = synth.make_sequence
 
 
-def squeezed(case_id, n_frames, size=(1920, 1080), n_kp=10000, drift_px=6.0, noise_px=1.5):
-    frames = orig(case_id, n_frames, size=size, n_kp=n_kp, drift_px=drift_px, noise_px=noise_px)
+def squeezed(case_id, n_frames, size=(1920, 1080), n_kp=10000, drift_px=6.0, noise_px=1.5, spatial_order=False):
+    frames = orig(case_id, n_frames, size=size, n_kp=n_kp, drift_px=drift_px, noise_px=noise_px, spatial_order=spatial_order)
     w, h = size
     for f in frames:  # shrink towards the centre by 2.5x: 0.7 * 0.7 of the image -> 0.28 * 0.28 (about 36 cells)
         f["x"] = (w / 2 + (f["x"] - w / 2) / 2.5).astype(f["x"].dtype)
