@@ -205,8 +205,10 @@ constexpr int kL2Dim = 128;
 constexpr int kTileRows = 64;                    // train rows per LDS tile
 constexpr uint32_t kRowPitch = 256u + 16u;       // a 256-byte row + 16 B: the 32 rows a ds_read_b128 touches fall on different banks
 constexpr uint32_t kTileBytes = kTileRows * kRowPitch;               // 17 408
-constexpr uint32_t kNormOff = 2u * kTileBytes;                       // two tiles, then two norm tiles
-constexpr uint32_t kMfmaLdsBytes = kNormOff + 2u * kTileRows * 4u;   // 35 328
+constexpr int kSub = 2;                          // tiles per staging step (one workgroup barrier per step)
+constexpr uint32_t kStepBytes = kSub * kTileBytes;                   // 34 816
+constexpr uint32_t kNormOff = 2u * kStepBytes;                       // two steps' tiles, then two steps' norms
+constexpr uint32_t kMfmaLdsBytes = kNormOff + 2u * kSub * kTileRows * 4u;   // 70 656: two workgroups per CU
 constexpr int kQueriesPerBlock = 256;            // 4 waves x 64 query columns
 
 template <bool HAM>
@@ -272,38 +274,46 @@ bf_mfma_kernel(const uint4* __restrict__ rows, const uint32_t* __restrict__ norm
     const uint4* __restrict__ trB = rows + (size_t)f.offB * 16;
     const uint32_t* __restrict__ nrmB = norms + f.offB;
     const int n_tiles = (f.nB + kTileRows - 1) / kTileRows;
-    // stage tile t into buffer t & 1: 64 rows x 256 B = 1024 16-byte pieces, four per thread; rows beyond nB repeat the last row
-    // with a norm that never wins
-    struct Stage { uint4 v0, v1, v2, v3; uint32_t nv; };  // (named members, returned by value: stays in registers)
-    auto stage_load = [&](int t) -> Stage {
-        Stage st;
+    // stage step st (kSub tiles = 128 rows x 256 B = 2048 16-byte pieces, eight per thread) into buffer st & 1; rows beyond nB repeat
+    // the last row with a norm that never wins
+    const int n_steps = (n_tiles + kSub - 1) / kSub;
+    static_assert(kSub == 2, "eight named staging registers");
+    struct Stage { uint4 v0, v1, v2, v3, v4, v5, v6, v7; uint32_t nv; };  // (named members, returned by value: stays in registers)
+    auto stage_load = [&](int st) -> Stage {
+        Stage sg;
         auto piece = [&](int i) -> uint4 {
-            const int pc = i * 256 + tid, r = pc >> 4, c16 = pc & 15;
-            return trB[(size_t)min(t * kTileRows + r, f.nB - 1) * 16 + c16];
+            const int pc = i * 256 + tid;
+            return trB[(size_t)min(st * kSub * kTileRows + (pc >> 4), f.nB - 1) * 16 + (pc & 15)];
         };
-        st.v0 = piece(0); st.v1 = piece(1); st.v2 = piece(2); st.v3 = piece(3);
-        const int r = t * kTileRows + (tid & 63);
+        sg.v0 = piece(0); sg.v1 = piece(1); sg.v2 = piece(2); sg.v3 = piece(3);
+        sg.v4 = piece(4); sg.v5 = piece(5); sg.v6 = piece(6); sg.v7 = piece(7);
+        const int r = st * kSub * kTileRows + (tid & (kSub * kTileRows - 1));
         const Val big = kBig;
-        st.nv = (tid < kTileRows) ? (r < f.nB ? nrmB[r] : __builtin_bit_cast(uint32_t, big)) : 0u;
-        return st;
+        sg.nv = (tid < kSub * kTileRows) ? (r < f.nB ? nrmB[r] : __builtin_bit_cast(uint32_t, big)) : 0u;
+        return sg;
     };
-    auto stage_store = [&](int t, const Stage& st) {
-        unsigned char* base = lds + (uint32_t)(t & 1) * kTileBytes;
+    auto stage_store = [&](int st, const Stage& sg) {
+        unsigned char* base = lds + (uint32_t)(st & 1) * kStepBytes;
         auto put = [&](int i, const uint4& v) {
-            const int pc = i * 256 + tid, r = pc >> 4, c16 = pc & 15;
-            *reinterpret_cast<uint4*>(base + (uint32_t)r * kRowPitch + (uint32_t)c16 * 16u) = v;
+            const int pc = i * 256 + tid;
+            *reinterpret_cast<uint4*>(base + (uint32_t)(pc >> 4) * kRowPitch + (uint32_t)(pc & 15) * 16u) = v;
         };
-        put(0, st.v0); put(1, st.v1); put(2, st.v2); put(3, st.v3);
-        if (tid < kTileRows) reinterpret_cast<uint32_t*>(lds + kNormOff)[(t & 1) * kTileRows + tid] = st.nv;
+        put(0, sg.v0); put(1, sg.v1); put(2, sg.v2); put(3, sg.v3);
+        put(4, sg.v4); put(5, sg.v5); put(6, sg.v6); put(7, sg.v7);
+        if (tid < kSub * kTileRows) reinterpret_cast<uint32_t*>(lds + kNormOff)[(st & 1) * kSub * kTileRows + tid] = sg.nv;
     };
     Stage sv = stage_load(0);
     stage_store(0, sv);
     __syncthreads();
-    for (int t = 0; t < n_tiles; ++t) {
-        const bool more = t + 1 < n_tiles;
-        if (more) sv = stage_load(t + 1);  // in flight during this tile's MFMAs
-        const unsigned char* tb = lds + (uint32_t)(t & 1) * kTileBytes;
-        const uint32_t* nb = reinterpret_cast<const uint32_t*>(lds + kNormOff) + (t & 1) * kTileRows;
+    for (int st = 0; st < n_steps; ++st) {
+        const bool more = st + 1 < n_steps;
+        if (more) sv = stage_load(st + 1);  // in flight during this step's MFMAs
+#pragma unroll
+        for (int u = 0; u < kSub; ++u) {
+        const int t = st * kSub + u;
+        if (t >= n_tiles) break;            // workgroup-uniform
+        const unsigned char* tb = lds + (uint32_t)(st & 1) * kStepBytes + (uint32_t)u * kTileBytes;
+        const uint32_t* nb = reinterpret_cast<const uint32_t*>(lds + kNormOff) + ((st & 1) * kSub + u) * kTileRows;
         Acc acc[2][2];
         // C-in = the norm of the accumulator's row: rows (reg & 3) + 8 (reg >> 2) + 4 half of the 32-row block
 #pragma unroll
@@ -346,7 +356,8 @@ bf_mfma_kernel(const uint4* __restrict__ rows, const uint32_t* __restrict__ norm
             bestv[c] = lt ? mn : bestv[c];
             bestt[c] = lt ? t : bestt[c];
         }
-        if (more) stage_store(t + 1, sv);  // the other buffer: last read one barrier ago
+        }
+        if (more) stage_store(st + 1, sv);  // the other buffer: last read one barrier ago
         __syncthreads();
     }
     // ---- the two halves of the wave hold disjoint row sets of the same query: lower value, then earlier tile
