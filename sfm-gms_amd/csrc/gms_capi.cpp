@@ -51,9 +51,10 @@ namespace {
 //   GMS_BAND=0           keep large pairs on the HBM-slab kernel alone
 //   GMS_STAGGER_US=n     spread of the first dispatch round's start times at 10k matches per pair (0 = off)
 //   GMS_BAND_WS_BYTES=n  budget of the large-pair workspace (default 4 GiB); a batch is filtered in slices that fit it
+//   GMS_DEAL=0|1         never / always deal the matches to the lanes of the byte-matrix kernel (default: what the probe saw)
 struct Knobs {
     bool dense_on = true, band_on = true;
-    int stagger_us = -1;
+    int stagger_us = -1, deal = -1;
     size_t band_ws_budget = (size_t)4 << 30;
 };
 const Knobs& knobs()
@@ -63,6 +64,7 @@ const Knobs& knobs()
         if (const char* e = std::getenv("GMS_DENSE")) v.dense_on = std::atoi(e) != 0;
         if (const char* e = std::getenv("GMS_BAND")) v.band_on = std::atoi(e) != 0;
         if (const char* e = std::getenv("GMS_STAGGER_US")) v.stagger_us = std::atoi(e);
+        if (const char* e = std::getenv("GMS_DEAL")) v.deal = std::atoi(e) != 0 ? 1 : 0;
         if (const char* e = std::getenv("GMS_BAND_WS_BYTES")) {
             const long long b = std::atoll(e);
             if (b > 0) v.band_ws_budget = (size_t)b;
@@ -149,6 +151,10 @@ struct gms_ctx {
     hipStream_t stream = nullptr;
     std::mutex mu;  // every entry point that touches the context's buffers holds it
     DevBuf aux, big_ws, band_ws, partial_ws;
+    // "recent batches came in spatial order": a word in pinned host memory that order_probe_kernel writes now and then and the host
+    // reads, without waiting, when it picks the byte-matrix kernel's instantiation
+    uint32_t* order_flag = nullptr;
+    unsigned dense_launches = 0;
     // the workspaces above are shared by every launch of the context: the last launch that used them, and where
     hipEvent_t ws_event = nullptr;
     hipStream_t ws_stream = nullptr;
@@ -243,10 +249,12 @@ int filter_launch(gms_ctx* c, hipStream_t st, const float* d_pts, const int64_t*
     p.threshold_factor = threshold_factor;
     p.pair_flags = nullptr;
     p.partial = nullptr;
+    p.dealt = 0;
     right_grids(p.right_w, p.right_h);
     // the byte-matrix path is tried first whenever there are no scale hypotheses (the reference's default flags,
     // DisparityUtil.cpp:149,299)
     p.dense = (knobs().dense_on && !with_scale) ? 1 : 0;
+    p.dealt = (p.dense && kpt && (knobs().deal >= 0 ? knobs().deal != 0 : *(volatile uint32_t*)c->order_flag != 0u)) ? 1 : 0;
     // First-round stagger: the spread is about one pair's duration on the path the launch will mostly take -- 26 us (byte
     // matrix) / 72 us (hashed) at 10k matches, in proportion to max_m -- in ticks of the 100 MHz wall clock. Only launches of
     // at least four dispatch rounds are staggered.
@@ -264,6 +272,12 @@ int filter_launch(gms_ctx* c, hipStream_t st, const float* d_pts, const int64_t*
         GMS_HIP(gms::launch_filter_scales(p, kpt, n_pairs, st));
     } else if (kpt) {
         GMS_HIP(gms::launch_filter(p, kpt, n_pairs, st));
+        // every sixteenth byte-matrix launch (and the first) is followed by the spatial-order probe of its batch, for later launches
+        if (p.dense && !capturing && (c->dense_launches++ & 15u) == 0u) {
+            void* dflag = nullptr;
+            GMS_HIP(hipHostGetDevicePointer(&dflag, c->order_flag, 0));
+            GMS_HIP(gms::launch_order_probe(p, (uint32_t*)dflag, st));
+        }
     } else if (knobs().band_on) {
         // Large pairs on the LDS kernels, a slice of the batch at a time so that the per-pair workspace (lists, histogram,
         // masks) stays bounded: three bands of rows for the default flags, tiles of left cells with three launches per
@@ -386,6 +400,8 @@ int gms_ctx_create(int device, gms_ctx** out_ctx)
     e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->lane[1].stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ws_event, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipHostMalloc((void**)&c->order_flag, 64, hipHostMallocDefault);
+    if (e == hipSuccess) *c->order_flag = 0;
     if (e == hipSuccess) e = gms::init_filter_kernels();
     if (e == hipSuccess) e = gms::init_band_kernels();
     if (e == hipSuccess) e = gms::init_big_kernels();
@@ -394,6 +410,7 @@ int gms_ctx_create(int device, gms_ctx** out_ctx)
         if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
         if (c->lane[1].stream) (void)hipStreamDestroy(c->lane[1].stream);
         if (c->ws_event) (void)hipEventDestroy(c->ws_event);
+        if (c->order_flag) (void)hipHostFree(c->order_flag);
         delete c;
         return GMS_ERR_HIP;
     }
@@ -415,6 +432,7 @@ int gms_ctx_destroy(gms_ctx* c)
         (void)hipStreamSynchronize(c->lane[1].stream);
         if (c->ws_pending) (void)hipEventSynchronize(c->ws_event);
         DevBuf* bufs[] = {&c->aux, &c->big_ws, &c->band_ws, &c->partial_ws, &c->tab_kp, &c->tab_pts, &c->tab_small};
+        if (c->order_flag) (void)hipHostFree(c->order_flag);
         for (DevBuf* b : bufs) b->release();
         for (Lane& l : c->lane) {
             l.hin.release();

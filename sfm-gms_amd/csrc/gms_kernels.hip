@@ -871,7 +871,7 @@ __device__ __forceinline__ uint32_t dense_nleft_cm(const uint8_t* nfine8, int x,
 }
 
 // false (workgroup-uniform, nothing written to global memory): the pair has to take the general path
-template <int KPT, bool ROT, int NT>
+template <int KPT, bool ROT, int NT, bool DEALT>
 __device__ __forceinline__ bool dense_pair(const FilterParams& p, uint32_t* smem, const int pair_idx, const int tid)
 {
     constexpr int kMcap = KPT * NT;
@@ -880,6 +880,19 @@ __device__ __forceinline__ bool dense_pair(const FilterParams& p, uint32_t* smem
     static_assert(KPT % kChunk == 0, "KPT must be a multiple of the chunk");
     const int lane = tid & 63;
     const int wave = tid >> 6;
+    // Which match a lane's k-th record is. Normally a wave instruction takes 64 consecutive matches (k * NT + tid). Inputs in
+    // spatial order (a detector scanning rows, a per-pixel grid) make consecutive matches share their (left cell, right cell)
+    // entry, and 64 of them in one LDS atomic instruction serialise on one address (1.7x slower on cell-sorted keypoints, DESIGN.md
+    // section 6). When the context's recent launches looked like that (order_probe_kernel; the host picks this instantiation), the
+    // matches are DEALT instead: the wave's eight 8-lane groups take 8 consecutive matches (one 128-byte line of the match array) from eight places
+    // KPT * 128 matches apart. Loads stay whole lines either way; the copy-out below orders 8-match units, which both mappings are
+    // made of. Speed only: either mapping gives the same result.
+    constexpr int kUnitsPerBlock = KPT * (NT / 64);   // dealt: unit (g, k, wave) = g * this + k * 16 + wave for lane group g
+    constexpr bool dealt = DEALT;
+    // either way match k of a lane is base + k * stride: (tid, NT) in list order, (its group's first unit, 128) when dealt
+    const int m_base = dealt ? ((((lane >> 3) * kUnitsPerBlock + wave) << 3) | (lane & 7)) : tid;
+    const int m_stride = dealt ? (NT / 64) * 8 : NT;
+    auto match_of = [&](int k) -> int { return m_base + k * m_stride; };
 
     const gms_pair pr = p.pairs[pair_idx];
     const int m = pr.m;
@@ -935,8 +948,8 @@ __device__ __forceinline__ bool dense_pair(const FilterParams& p, uint32_t* smem
     uint2 qt[kKeepRec ? 1 : KPT];
 #pragma unroll
     for (int k = 0; k < KPT; ++k) {
-        if (kKeepRec) rec[k] = *reinterpret_cast<const uint4*>(&matches[min(k * NT + tid, m - 1)]);
-        else qt[k] = *reinterpret_cast<const uint2*>(&matches[min(k * NT + tid, m - 1)]);
+        if (kKeepRec) rec[k] = *reinterpret_cast<const uint4*>(&matches[min(match_of(k), m - 1)]);
+        else qt[k] = *reinterpret_cast<const uint2*>(&matches[min(match_of(k), m - 1)]);
     }
     auto query_of = [&](int k) -> uint32_t { return kKeepRec ? rec[k].x : qt[k].x; };
     auto train_of = [&](int k) -> uint32_t { return kKeepRec ? rec[k].y : qt[k].y; };
@@ -991,7 +1004,7 @@ __device__ __forceinline__ bool dense_pair(const FilterParams& p, uint32_t* smem
         bool any_bad = false, spill = false;
 #pragma unroll
         for (int k = 0; k < KPT; ++k) {
-            const bool live = k * NT + tid < m;
+            const bool live = match_of(k) < m;
             const uint32_t e0 = cb[k] & kDEMask;  // E(r) of getGridIndexRight on the 20 x 20 grid, 0 = outside it (no bounds test in the reference)
             // parity domain: indices in range, both points inside it, the right cell inside its grid ('&', not '&&': no branches)
             const bool ok = ((int)(query_of(k) < (uint32_t)nA) & (int)(train_of(k) < (uint32_t)nB) & (int)(((ca[k] | cb[k]) & kCodeBad) == 0u) & (int)(e0 != 0u)) != 0;
@@ -1246,49 +1259,97 @@ __device__ __forceinline__ bool dense_pair(const FilterParams& p, uint32_t* smem
     }
     GMS_STAMP(7);  // count + select
 
-    // ---- copy-out: surviving DMatch verbatim, in input order (DLL@0x180048340), from the registers. A chunk is 64
-    //      consecutive matches = one wave's k-th record; chunk (k, wave) sits at position k * 16 + wave of the order.
-    //      Every wave publishes its KPT popcounts, then scans all KPT * 16 of them itself (no further exchange).
+    // ---- copy-out: surviving DMatch verbatim, in input order (DLL@0x180048340), from the registers.
     constexpr int kWaves = NT / 64;
-    constexpr int kScanRegs = (KPT * kWaves + 63) / 64;
-    uint32_t* cnt_tab = smem;  // [KPT * kWaves], in the matrix area
+    uint32_t* cnt_tab = smem;  // in the matrix area
     unsigned long long keep[KPT];
 #pragma unroll
-    for (int k = 0; k < KPT; ++k) {
-        keep[k] = winner >= 0 ? __ballot((code[k] >> (kDAccShift + max(winner, 0))) & 1u) : 0ull;
-        if (lane == 0) cnt_tab[k * kWaves + wave] = (uint32_t)__popcll(keep[k]);
-    }
-    __syncthreads();
-    uint32_t excl[kScanRegs];
-    uint32_t total = 0;
-#pragma unroll
-    for (int v = 0; v < kScanRegs; ++v) {
-        const int idx = v * 64 + lane;
-        const uint32_t c = idx < KPT * kWaves ? cnt_tab[idx] : 0u;
-        uint32_t incl = c;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t t = __shfl_up(incl, d);
-            if (lane >= d) incl += t;
-        }
-        excl[v] = total + incl - c;
-        total += __shfl(incl, 63);
-    }
-    GMS_STAMP(8);  // out scan
+    for (int k = 0; k < KPT; ++k) keep[k] = winner >= 0 ? __ballot((code[k] >> (kDAccShift + max(winner, 0))) & 1u) : 0ull;
     gms_dmatch* __restrict__ out = p.out + pr.match_off;
     uint8_t* mask_out = p.mask ? p.mask + pr.match_off : nullptr;
+    uint32_t total = 0;
+    if (!dealt) {
+        // A chunk is 64 consecutive matches = one wave's k-th record; chunk (k, wave) sits at position k * 16 + wave of the order.
+        // Every wave publishes its KPT popcounts, then scans all KPT * 16 of them itself (one barrier, no further exchange).
+        constexpr int kScanRegs = (KPT * kWaves + 63) / 64;
 #pragma unroll
-    for (int k = 0; k < KPT; ++k) {
-        const int i = k * NT + tid;
-        const int ch = k * kWaves + wave;                      // wave-uniform
-        static_assert(64 % kWaves == 0, "a wave's chunk never straddles two scan registers");
-        const uint32_t base = __shfl(excl[(k * kWaves) >> 6], ch & 63);
-        if (i < m) {
-            const bool in = (keep[k] >> lane) & 1ull;
-            if (mask_out) mask_out[i] = in ? 1 : 0;
-            if (in) {
-                const uint32_t pos = base + (uint32_t)__popcll(keep[k] & ((1ull << lane) - 1ull));
-                *reinterpret_cast<uint4*>(&out[pos]) = kKeepRec ? rec[k] : *reinterpret_cast<const uint4*>(&matches[i]);
+        for (int k = 0; k < KPT; ++k)
+            if (lane == 0) cnt_tab[k * kWaves + wave] = (uint32_t)__popcll(keep[k]);
+        __syncthreads();
+        uint32_t excl[kScanRegs];
+#pragma unroll
+        for (int v = 0; v < kScanRegs; ++v) {
+            const int idx = v * 64 + lane;
+            const uint32_t c = idx < KPT * kWaves ? cnt_tab[idx] : 0u;
+            uint32_t incl = c;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t t = __shfl_up(incl, d);
+                if (lane >= d) incl += t;
+            }
+            excl[v] = total + incl - c;
+            total += __shfl(incl, 63);
+        }
+        GMS_STAMP(8);  // out scan
+#pragma unroll
+        for (int k = 0; k < KPT; ++k) {
+            const int i = k * NT + tid;
+            const int ch = k * kWaves + wave;                      // wave-uniform
+            static_assert(64 % kWaves == 0, "a wave's chunk never straddles two scan registers");
+            const uint32_t base = __shfl(excl[(k * kWaves) >> 6], ch & 63);
+            if (i < m) {
+                const bool in = (keep[k] >> lane) & 1ull;
+                if (mask_out) mask_out[i] = in ? 1 : 0;
+                if (in) {
+                    const uint32_t pos = base + (uint32_t)__popcll(keep[k] & ((1ull << lane) - 1ull));
+                    *reinterpret_cast<uint4*>(&out[pos]) = kKeepRec ? rec[k] : *reinterpret_cast<const uint4*>(&matches[i]);
+                }
+            }
+        }
+    } else {
+        // Dealt matches: the order is that of the 8-match units (see match_of). Every 8-lane group publishes the popcount of its
+        // byte of the wave's ballot, the workgroup scans the KPT * 128 counts (two per thread, two more barriers), and a lane's slot
+        // is its unit's base plus its rank in the byte.
+        constexpr int kUnits = KPT * NT / 8;
+        static_assert(kUnits <= 2 * NT, "two scan entries per thread");
+        uint32_t* wave_tot = misc + 16;
+#pragma unroll
+        for (int k = 0; k < KPT; ++k)
+            if ((lane & 7) == 0) cnt_tab[match_of(k) >> 3] = (uint32_t)__popc((uint32_t)(keep[k] >> (lane & 56)) & 0xFFu);
+        __syncthreads();
+        {
+            const uint32_t c0 = 2 * tid < kUnits ? cnt_tab[2 * tid] : 0u, c1 = 2 * tid + 1 < kUnits ? cnt_tab[2 * tid + 1] : 0u;
+            uint32_t incl = c0 + c1;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t t = __shfl_up(incl, d);
+                if (lane >= d) incl += t;
+            }
+            if (lane == 63) wave_tot[wave] = incl;
+            __syncthreads();
+            uint32_t off = 0;
+#pragma unroll
+            for (int w = 0; w < kWaves; ++w) {
+                const uint32_t tw = wave_tot[w];
+                off += w < wave ? tw : 0u;
+                total += tw;
+            }
+            if (2 * tid < kUnits) cnt_tab[2 * tid] = off + incl - c0 - c1;
+            if (2 * tid + 1 < kUnits) cnt_tab[2 * tid + 1] = off + incl - c1;
+        }
+        __syncthreads();
+        GMS_STAMP(8);  // out scan
+#pragma unroll
+        for (int k = 0; k < KPT; ++k) {
+            const int i = match_of(k);
+            if (i < m) {
+                const uint32_t byte = (uint32_t)(keep[k] >> (lane & 56)) & 0xFFu;  // the unit's survivors
+                const bool in = (byte >> (lane & 7)) & 1u;
+                if (mask_out) mask_out[i] = in ? 1 : 0;
+                if (in) {
+                    const uint32_t pos = cnt_tab[i >> 3] + (uint32_t)__popc(byte & ((1u << (lane & 7)) - 1u));
+                    *reinterpret_cast<uint4*>(&out[pos]) = kKeepRec ? rec[k] : *reinterpret_cast<const uint4*>(&matches[i]);
+                }
             }
         }
     }
@@ -1305,13 +1366,46 @@ __device__ __forceinline__ bool dense_pair(const FilterParams& p, uint32_t* smem
     return true;
 }
 
-template <int KPT, bool ROT, int NT>
+template <int KPT, bool ROT, int NT, bool DEALT>
 __global__ void __launch_bounds__(NT)
 filter_kernel_dense(FilterParams p)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     first_round_stagger(p);
-    if (!dense_pair<KPT, ROT, NT>(p, smem, (int)blockIdx.x, (int)threadIdx.x)) hash_pair<KPT, ROT, NT>(p, smem, (int)blockIdx.x, (int)threadIdx.x);
+    if (!dense_pair<KPT, ROT, NT, DEALT>(p, smem, (int)blockIdx.x, (int)threadIdx.x)) hash_pair<KPT, ROT, NT>(p, smem, (int)blockIdx.x, (int)threadIdx.x);
+}
+
+// Are a batch's matches in spatial order? One small workgroup, launched now and then behind a byte-matrix launch (gms_capi.cpp):
+// sixteen waves look at 64 consecutive matches in the middle of sixteen pairs spread over the batch and count neighbours in the list
+// whose left points share the cell of grid type 1 (random order: 1 in 400; a row-scanning detector or a per-pixel grid: most of them).
+// More than a quarter -> *flag = 1 (a word in pinned host memory the host reads, without waiting, when it picks the DEALT
+// instantiation for later launches). Speed only: either mapping gives the same result.
+__global__ void __launch_bounds__(1024)
+order_probe_kernel(FilterParams p, uint32_t* __restrict__ flag)
+{
+    __shared__ uint32_t s_same, s_seen;
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) s_same = s_seen = 0;
+    __syncthreads();
+    const int pi = (int)(((long long)wave * p.n_pairs) >> 4);
+    const gms_pair pr = p.pairs[pi];
+    if (pr.m >= 128 && pr.frame_a >= 0 && pr.frame_a < p.n_frames) {
+        const int64_t offA = p.frame_off[pr.frame_a];
+        const int nA = (int)(p.frame_off[pr.frame_a + 1] - offA);
+        const uint32_t* __restrict__ lcode = reinterpret_cast<const uint32_t*>(p.pts + p.frame_off[p.n_frames]) + offA;
+        const int start = (pr.m >> 1) & ~63;
+        const uint32_t q = (uint32_t)p.matches[pr.match_off + start + lane].queryIdx;
+        const uint32_t lc = nA > 0 ? lcode[min(q, (uint32_t)(nA - 1))] : kDNever;
+        const uint32_t cell = (lc & kDNever) ? 0x10000u + (uint32_t)lane : (lc >> kDCellShift) & 0x1FFu;  // never binned: equals nobody
+        const uint32_t next = (uint32_t)__shfl_down((int)cell, 1);
+        const unsigned long long same = __ballot(lane < 63 && cell == next);
+        if (lane == 0) {
+            atomicAdd(&s_same, (uint32_t)__popcll(same));
+            atomicAdd(&s_seen, 63u);
+        }
+    }
+    __syncthreads();
+    if (tid == 0 && s_seen != 0) *flag = 4u * s_same > s_seen ? 1u : 0u;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1816,6 +1910,13 @@ int filter_pick_kpt(int max_m)
     return 0;
 }
 
+hipError_t launch_order_probe(const FilterParams& p, uint32_t* flag, hipStream_t stream)
+{
+    if (p.n_pairs <= 0) return hipSuccess;
+    hipLaunchKernelGGL(order_probe_kernel, dim3(1), dim3(1024), 0, stream, p, flag);
+    return hipGetLastError();
+}
+
 hipError_t launch_normalize(const void* d_kp, int kp_stride_bytes, const int64_t* d_frame_off, const int32_t* d_wh,
                             int n_frames, int64_t total_kp, float* d_pts, hipStream_t stream)
 {
@@ -1832,7 +1933,8 @@ static hipError_t launch_filter_t(const FilterParams& p, int n_pairs, size_t lds
 {
     if (p.dense) {
         const size_t lds = lds_bytes > kDenseLdsBytes ? lds_bytes : (size_t)kDenseLdsBytes;
-        hipLaunchKernelGGL((filter_kernel_dense<KPT, ROT, NT>), dim3((unsigned)n_pairs), dim3(NT), lds, stream, p);
+        if (p.dealt) hipLaunchKernelGGL((filter_kernel_dense<KPT, ROT, NT, true>), dim3((unsigned)n_pairs), dim3(NT), lds, stream, p);
+        else hipLaunchKernelGGL((filter_kernel_dense<KPT, ROT, NT, false>), dim3((unsigned)n_pairs), dim3(NT), lds, stream, p);
     } else {
         hipLaunchKernelGGL((filter_kernel<KPT, ROT, NT>), dim3((unsigned)n_pairs), dim3(NT), lds_bytes, stream, p);
     }
@@ -1843,7 +1945,8 @@ template <int KPT, bool ROT, int NT>
 static hipError_t allow_full_lds_t()
 {
     const void* fns[] = {reinterpret_cast<const void*>(filter_kernel<KPT, ROT, NT>),
-                         reinterpret_cast<const void*>(filter_kernel_dense<KPT, ROT, NT>),
+                         reinterpret_cast<const void*>(filter_kernel_dense<KPT, ROT, NT, false>),
+                         reinterpret_cast<const void*>(filter_kernel_dense<KPT, ROT, NT, true>),
                          reinterpret_cast<const void*>(filter_kernel_dense_scales<KPT, ROT, NT>)};
     for (const void* fn : fns) {
         const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes);

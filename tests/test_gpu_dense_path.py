@@ -221,3 +221,42 @@ def test_scales_no_inliers_in_the_first_three_scales(ctx, oracle):
     c = cases.random_pair(77, n=6000, inlier_frac=0.0)
     for rot in (False, True):
         _check(ctx, oracle, c, rot, scale=True)
+
+
+# ---- the dealt lane mapping of the byte-matrix kernel (inputs in spatial order) ------------------------------------------------------
+def test_dealt_mapping_whole_file_again():
+    """GMS_DEAL=1 (read once per process) forces the instantiation that deals the matches to the lanes in 8-match units: everything
+    in this file and the golden fixtures must come out the same."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_dense_path.py"),
+                          os.path.join(root, "tests", "test_golden.py"), os.path.join(root, "tests", "test_gpu_fuzz.py"), "-m", "gpu", "-x", "-q",
+                          "-k", "not whole_file_again"], capture_output=True, text=True, timeout=1200, env=dict(os.environ, GMS_DEAL="1"))
+    assert res.returncode == 0, res.stdout[-3000:]
+
+
+def test_probe_switches_to_dealing_on_ordered_input(pkg, oracle, synth):
+    """Cell-sorted keypoints: the first launch of a fresh context runs in list order and is followed by the probe; later launches deal.
+    Same bytes either way."""
+    import importlib
+    batch = importlib.import_module("sfm-gms_amd.batch")
+    d = importlib.import_module("sfm-gms_amd.dist")
+    size, n_frames, n_kp = (1920, 1080), 6, 10000
+    frames = synth.make_sequence(77, n_frames, size=size, n_kp=n_kp, spatial_order=True)
+    pairs = d.pair_table(n_frames, 0, 15, n_kp)
+    pairs["m"][[3, 7]] = [9999, 5000]
+    matches = np.concatenate([d.synth_matches_host(k, n_kp, 0.5) for k in range(15)])
+    kp_all = np.concatenate(frames)
+    wh = np.array([size] * n_frames, dtype=np.int32).reshape(-1)
+    with pkg.GmsContext(0) as c2:
+        table = batch.FrameTable(c2, frames, [size] * n_frames)
+        failed, wout, wres, wmask = oracle.batch(kp_all, table.frame_off_host, wh, pairs, matches, False, False, 6.0, 8)
+        assert failed == 0
+        for _ in range(3):
+            out, res, mask = batch.filter_pairs(c2, table, pairs, matches)
+            assert res.tobytes() == wres.tobytes() and np.array_equal(mask, wmask)
+            for i in range(len(pairs)):
+                o, k = int(pairs["match_off"][i]), int(res["n_inliers"][i])
+                assert out[o:o + k].tobytes() == wout[o:o + k].tobytes()
