@@ -136,12 +136,13 @@ bf_hamming_kernel(const uint32_t* __restrict__ desc, const int64_t* __restrict__
     }
 }
 
-// ---- NORM_L2: the per-frame tables --------------------------------------------------------------------------------------------
-// One 32-lane group per 128-float row: 16 bytes per lane. Writes the row as bf16, |row|^2, and flags the row's frame when a value
-// is not an integer in [0, 255] (then bf16 and the fp32 sums below 2^24 are no longer exact and the frame's pairs take the loop).
+// ---- the per-frame tables of the matrix-core paths ---------------------------------------------------------------------------------
+// NORM_L2: one 32-lane group per 128-float row (16 bytes per lane). A SIFT-like row (integers 0..255) becomes 128 int8 a' = a - 128
+// with h = floor(sum (a' + 1)^2 / 2) beside it; a row with any other value flags its frame (whose pairs take the
+// loop kernel).
 __global__ void __launch_bounds__(256)
 bf_l2_prepare_kernel(const float4* __restrict__ desc, const int64_t* __restrict__ frame_off, int n_frames, int64_t total,
-                     uint2* __restrict__ rows_bf16, float* __restrict__ norms, uint32_t* __restrict__ frame_bad)
+                     uint32_t* __restrict__ rows_i8, int32_t* __restrict__ h_norms, uint32_t* __restrict__ frame_bad)
 {
     const int64_t row = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 5;
     const int part = (int)(threadIdx.x & 31);
@@ -149,12 +150,13 @@ bf_l2_prepare_kernel(const float4* __restrict__ desc, const int64_t* __restrict_
     const float4 v = desc[row * 32 + part];
     auto is_u8 = [](float x) { return x >= 0.0f && x <= 255.0f && x == floorf(x); };
     const bool bad = !(is_u8(v.x) && is_u8(v.y) && is_u8(v.z) && is_u8(v.w));
-    auto bf = [](float x) { return (uint32_t)(__float_as_uint(x) >> 16); };  // exact for 8-bit integers (the only case it is used for)
-    rows_bf16[row * 32 + part] = make_uint2(bf(v.x) | (bf(v.y) << 16), bf(v.z) | (bf(v.w) << 16));
-    float s = v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    auto shifted = [](float x) { return (int)fminf(fmaxf(x, 0.0f), 255.0f) - 128; };  // (the clamp only matters for a flagged row)
+    const int e0 = shifted(v.x), e1 = shifted(v.y), e2 = shifted(v.z), e3 = shifted(v.w);
+    rows_i8[row * 32 + part] = (uint32_t)(e0 & 255) | ((uint32_t)(e1 & 255) << 8) | ((uint32_t)(e2 & 255) << 16) | ((uint32_t)(e3 & 255) << 24);
+    int w = (e0 + 1) * (e0 + 1) + (e1 + 1) * (e1 + 1) + (e2 + 1) * (e2 + 1) + (e3 + 1) * (e3 + 1);
 #pragma unroll
-    for (int d = 16; d >= 1; d >>= 1) s += __shfl_xor(s, d, 32);
-    if (part == 0) norms[row] = s;
+    for (int d = 16; d >= 1; d >>= 1) w += __shfl_xor(w, d, 32);
+    if (part == 0) h_norms[row] = w >> 1;
     if (__ballot(bad) != 0ull && bad) {
         int lo = 0, hi = n_frames - 1;  // last frame f with frame_off[f] <= row
         while (lo < hi) {
@@ -165,60 +167,119 @@ bf_l2_prepare_kernel(const float4* __restrict__ desc, const int64_t* __restrict_
     }
 }
 
-// ---- NORM_HAMMING: the per-frame tables of the matrix-core path ------------------------------------------------------------------
-// hamming(a, b) = |a| + |b| - 2 a.b over the 256 bits as 0/1 bytes: each row is expanded to 256 int8 (the A / B operands of
-// v_mfma_i32_32x32x32_i8) and its popcount kept beside it. One thread per (row, 16 bits).
+// NORM_HAMMING: each of the 256 bits becomes one FP4 (E2M1) element -- 1.0 (0b0010) or 0 -- so a row is 128 bytes; its popcount
+// is kept beside it as a float. One thread per (row, 16 bits).
 __global__ void __launch_bounds__(256)
-bf_ham_prepare_kernel(const uint16_t* __restrict__ desc, int64_t total, uint4* __restrict__ rows_i8, int32_t* __restrict__ norms)
+bf_ham_prepare_kernel(const uint16_t* __restrict__ desc, int64_t total, uint2* __restrict__ rows_fp4, float* __restrict__ norms)
 {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;  // 16 pieces of 16 bits per row
     if (i >= total * 16) return;
     const uint32_t bits = desc[i];
-    uint32_t w[4];
+    uint32_t w[2] = {0u, 0u};
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const uint32_t n = (bits >> (4 * k)) & 15u;
-        w[k] = (n & 1u) | ((n & 2u) << 7) | ((n & 4u) << 14) | ((n & 8u) << 21);  // bit j of the nibble -> byte j
-    }
-    rows_i8[i] = make_uint4(w[0], w[1], w[2], w[3]);
+    for (int j = 0; j < 16; ++j) w[j >> 3] |= ((bits >> j) & 1u) << (4 * (j & 7) + 1);
+    rows_fp4[i] = make_uint2(w[0], w[1]);
     uint32_t pc = (uint32_t)__builtin_popcount(bits);
 #pragma unroll
     for (int d = 8; d >= 1; d >>= 1) pc += (uint32_t)__shfl_xor((int)pc, d, 16);
-    if ((threadIdx.x & 15) == 0) norms[i >> 4] = (int32_t)pc;
+    if ((threadIdx.x & 15) == 0) norms[i >> 4] = (float)pc;
 }
 
 // ---- both norms on the matrix cores ------------------------------------------------------------------------------------------------
-// One 256-thread workgroup = 256 query rows of one pair (four waves x 64 query columns, the B operands, resident in registers and
-// pre-multiplied by -2) against all train rows of the pair's other frame, streamed through LDS in tiles of 64 rows (the A operands).
-// An accumulator starts from |b|^2 of its row, so after the K loop it holds |b|^2 - 2 a.b: the distance minus the query's own
-// norm. Per tile a lane only keeps the MINIMUM of its 32 values per query column (one v_min3 per two values) and the tile it came
-// from -- tracking the arg-min per value would cost more vector instructions than the tile's MFMAs take. The winning TILE of a
-// query is then searched once more at the end, with the norm's own exact arithmetic, for the first minimal row.
-//   L2:       rows = bf16 x 128 (256 B), v_mfma_f32_32x32x16_bf16, fp32 accumulators; every value an exact integer (see the file header)
-//   Hamming:  rows = int8 x 256 (256 B), v_mfma_i32_32x32x32_i8, int32 accumulators
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+// One 256-thread workgroup = 256 query rows of one pair (four waves x 64 query columns, the B operands, resident in registers)
+// against all train rows of the pair's other frame, streamed through LDS in tiles of 64 rows (the A operands), four tiles per
+// staging step. Per tile a lane only keeps the MINIMUM of its 32 values per query column (one v_min3 per two values) and the tile
+// it came from -- tracking the arg-min per value would cost more vector instructions than the tile's MFMAs take. The winning TILE
+// of a query is then searched once more at the end, in exact integer arithmetic, for the first minimal row.
+//   Hamming  rows = 256 x FP4 (128 B), v_mfma_scale_f32_32x32x64_f8f6f4 with both formats FP4 and unit scales (four per tile and
+//            accumulator, at twice the int8 rate). hamming = |a| + |b| - 2 a.b over 0/1 elements: the B operand is the query row
+//            times -2 (FP4 holds -2 exactly: every nibble 0x2 -> 0xC), the accumulator starts from the train row's popcount, so it
+//            ends as |a| - 2 a.b -- small integers, exact in fp32.
+//   L2       rows = 128 x int8 (128 B), v_mfma_i32_32x32x32_i8 (four per tile and accumulator; the bf16 form needs eight at half the
+//            rate). With a' = a - 128 and the query side as ~b' = 127 - b (a bytewise NOT: both fit int8 for every value 0..255),
+//            a - b = (a' + 1) + ~b', so d^2 = w(a) + 2 a'.~b' + [sum ~b'^2 + 2 sum ~b'] with w(a) = sum (a' + 1)^2; the bracket is
+//            the query's alone. The accumulator starts from h = floor(w / 2) and ends as P = h + a'.~b' = floor((w + 2 a'.~b') / 2):
+//            the row of the smallest d^2 has the smallest P, but two rows whose d^2 differ by one can share it. A query whose
+//            minimal P shows up in more than one tile is therefore flagged, and its final search covers every tile from the first
+//            such one on (exact, rarely needed: d^2 within one of the minimum, in another tile).
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) int i32x4;
+typedef __attribute__((ext_vector_type(8))) int i32x8;
 typedef __attribute__((ext_vector_type(16))) int i32x16;
 
 constexpr int kL2Dim = 128;
 constexpr int kTileRows = 64;                    // train rows per LDS tile
-constexpr uint32_t kRowPitch = 256u + 16u;       // a 256-byte row + 16 B: the 32 rows a ds_read_b128 touches fall on different banks
-constexpr uint32_t kTileBytes = kTileRows * kRowPitch;               // 17 408
-constexpr int kSub = 2;                          // tiles per staging step (one workgroup barrier per step)
-constexpr uint32_t kStepBytes = kSub * kTileBytes;                   // 34 816
+constexpr uint32_t kRowBytes = 128u;             // a prepared row, either kind
+constexpr uint32_t kRowPitch = kRowBytes + 16u;  // + 16 B: the rows a ds_read_b128 touches spread over the banks
+constexpr uint32_t kTileBytes = kTileRows * kRowPitch;               // 9216
+constexpr int kSub = 4;                          // tiles per staging step (one workgroup barrier per step)
+constexpr int kStepRows = kSub * kTileRows;      // 256: one norm per thread
+constexpr uint32_t kStepBytes = kSub * kTileBytes;                   // 36 864
 constexpr uint32_t kNormOff = 2u * kStepBytes;                       // two steps' tiles, then two steps' norms
-constexpr uint32_t kMfmaLdsBytes = kNormOff + 2u * kSub * kTileRows * 4u;   // 70 656: two workgroups per CU
+constexpr uint32_t kMfmaLdsBytes = kNormOff + 2u * kStepRows * 4u;   // 75 776: two workgroups per CU
 constexpr int kQueriesPerBlock = 256;            // 4 waves x 64 query columns
+constexpr int kKSteps = 4;                       // MFMAs per (tile, accumulator): 4 x 32 bytes of a row
+constexpr int kFp4UnitScale = 0x7F7F7F7F;        // E8M0 127 = 2^0 in every byte
+
+__device__ __forceinline__ uint32_t wave_min(uint32_t key)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) key = min(key, (uint32_t)__shfl_xor((int)key, d));
+    return key;
+}
+
+// (distance << 6 | row inside the tile) of the first nearest row of tile t to one query row, the same in every lane.
+// Hamming: one lane per train row, on the raw bits.
+__device__ __forceinline__ uint32_t ham_tile_key(const uint32_t* __restrict__ raw, int64_t q_row, int64_t offB, int nB, int t, int lane)
+{
+    const int r = t * kTileRows + lane, rr = min(r, nB - 1);
+    const uint4* qa = reinterpret_cast<const uint4*>(raw + (size_t)q_row * 8);
+    const uint4* tb4 = reinterpret_cast<const uint4*>(raw + (size_t)(offB + rr) * 8);
+    const uint4 x0 = qa[0], x1 = qa[1], y0 = tb4[0], y1 = tb4[1];
+    const uint32_t d = (uint32_t)(__builtin_popcount(x0.x ^ y0.x) + __builtin_popcount(x0.y ^ y0.y) + __builtin_popcount(x0.z ^ y0.z) +
+                                  __builtin_popcount(x0.w ^ y0.w) + __builtin_popcount(x1.x ^ y1.x) + __builtin_popcount(x1.y ^ y1.y) +
+                                  __builtin_popcount(x1.z ^ y1.z) + __builtin_popcount(x1.w ^ y1.w));
+    return wave_min(r < nB ? (d << 6) | (uint32_t)lane : 0xFFFFFFFFu);
+}
+
+// L2 on the int8 rows: the tile's 64 rows are 8 KB of consecutive memory, read coalesced -- a wave instruction covers eight whole
+// rows, lane = (row of the eight, 16-byte piece of the row). d^2 = sum (a' - b')^2 (the shift by 128 cancels) = a'.a' + b'.b' - 2 a'.b'
+// per piece, four elements per v_dot4_i32_i8, the eight pieces of a row added up across its lanes.
+__device__ __forceinline__ int dot16(const uint4& a, const uint4& b)
+{
+    int d = __builtin_amdgcn_sdot4((int)a.x, (int)b.x, 0, false);
+    d = __builtin_amdgcn_sdot4((int)a.y, (int)b.y, d, false);
+    d = __builtin_amdgcn_sdot4((int)a.z, (int)b.z, d, false);
+    return __builtin_amdgcn_sdot4((int)a.w, (int)b.w, d, false);
+}
+
+__device__ __forceinline__ uint32_t l2_tile_key(const uint4* __restrict__ rows, int64_t q_row, int64_t offB, int nB, int t, int lane)
+{
+    const int piece = lane & 7, rsub = lane >> 3;
+    const uint4 x = rows[(size_t)q_row * 8 + piece];
+    uint4 y[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) y[j] = rows[(size_t)(offB + min(t * kTileRows + 8 * j + rsub, nB - 1)) * 8 + piece];
+    const int xx = dot16(x, x);
+    uint32_t key = 0xFFFFFFFFu;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        int d2 = xx + dot16(y[j], y[j]) - 2 * dot16(x, y[j]);
+#pragma unroll
+        for (int d = 4; d >= 1; d >>= 1) d2 += __shfl_xor(d2, d, 8);
+        const int row = t * kTileRows + 8 * j + rsub;
+        key = min(key, row < nB ? ((uint32_t)d2 << 6) | (uint32_t)(8 * j + rsub) : 0xFFFFFFFFu);   // d^2 <= 128 * 255^2 < 2^23
+    }
+    return wave_min(key);
+}
 
 template <bool HAM>
-__global__ void __launch_bounds__(256)
-bf_mfma_kernel(const uint4* __restrict__ rows, const uint32_t* __restrict__ norms, const uint32_t* __restrict__ frame_bad,
-               const void* __restrict__ raw, const int64_t* __restrict__ frame_off, int n_frames, const gms_pair* __restrict__ pairs,
-               int tiles_per_pair, uint32_t n_tasks, gms_dmatch* __restrict__ matches)
+__global__ void __launch_bounds__(256, 2)
+bf_mfma_kernel(const uint4* __restrict__ rows, const uint32_t* __restrict__ norms, const uint32_t* __restrict__ frame_bad, const void* __restrict__ raw, const int64_t* __restrict__ frame_off, int n_frames,
+               const gms_pair* __restrict__ pairs, int tiles_per_pair, uint32_t n_tasks, gms_dmatch* __restrict__ matches)
 {
-    using Acc = typename std::conditional<HAM, i32x16, f32x16>::type;
-    using Val = typename std::conditional<HAM, int32_t, float>::type;   // an accumulator element / a norm
+    using Acc = typename std::conditional<HAM, f32x16, i32x16>::type;
+    using Val = typename std::conditional<HAM, float, int32_t>::type;   // an accumulator element / a norm
     __shared__ __attribute__((aligned(16))) unsigned char lds[kMfmaLdsBytes];
     const uint32_t task = xcd_task(blockIdx.x, n_tasks);
     const int pair_idx = (int)(task / (uint32_t)tiles_per_pair), tile = (int)(task % (uint32_t)tiles_per_pair);
@@ -229,7 +290,7 @@ bf_mfma_kernel(const uint4* __restrict__ rows, const uint32_t* __restrict__ norm
     if (!HAM && (frame_bad[pr.frame_a] | frame_bad[pr.frame_b])) return;             // the loop kernel owns this pair
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int col = lane & 31, half = lane >> 5;
-    const Val kBig = HAM ? (Val)0x3FFFFFFF : (Val)3.0e38f;
+    const Val kBig = HAM ? (Val)3.0e38f : (Val)0x3FFFFFFF;
     if (f.nB <= 0) {  // nothing to match against: the reference's matcher returns no match for the row
         const int q = q0 + tid;
         if (q < f.m) {
@@ -243,182 +304,205 @@ bf_mfma_kernel(const uint4* __restrict__ rows, const uint32_t* __restrict__ norm
         return;
     }
 
-    // ---- this wave's 64 query columns as B operands, scaled by -2 (exact), resident for the whole kernel:
-    //      bq[c][s] = -2 * Q[32 c + col][bytes 32 s + 16 half .. + 16)
-    uint4 bq[2][8];
+    // ---- this wave's 64 query columns as B operands, resident for the whole kernel:
+    //      bq[c][s] = transformed Q[32 c + col][bytes 32 s + 16 half .. + 16)
+    uint4 bq[2][kKSteps];
     int qrow[2];
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
         qrow[c] = q0 + wave * 64 + c * 32 + col;
-        const uint4* src = rows + (size_t)(f.offA + min(qrow[c], f.m - 1)) * 16;
+        const uint4* src = rows + (size_t)(f.offA + min(qrow[c], f.m - 1)) * (kRowBytes / 16);
 #pragma unroll
-        for (int s = 0; s < 8; ++s) {
+        for (int s = 0; s < kKSteps; ++s) {
             const uint4 r4 = src[2 * s + half];
-            const uint32_t w[4] = {r4.x, r4.y, r4.z, r4.w};
-            uint32_t o[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                if (HAM) {
-                    o[i] = w[i] * 0xFEu;  // bytes 0 / 1 -> 0 / -2 (0xFE): no carries between bytes
-                } else {
-                    const float lo = __uint_as_float(w[i] << 16) * -2.0f, hi = __uint_as_float(w[i] & 0xFFFF0000u) * -2.0f;
-                    o[i] = (__float_as_uint(lo) >> 16) | (__float_as_uint(hi) & 0xFFFF0000u);
-                }
-            }
-            bq[c][s] = make_uint4(o[0], o[1], o[2], o[3]);
+            if (HAM) bq[c][s] = make_uint4(r4.x * 6u, r4.y * 6u, r4.z * 6u, r4.w * 6u);  // nibbles 0x2 -> 0xC (-2.0): no carries
+            else bq[c][s] = make_uint4(~r4.x, ~r4.y, ~r4.z, ~r4.w);
         }
     }
     Val bestv[2] = {kBig, kBig};
     int bestt[2] = {0, 0};
+    bool tied[2] = {false, false};  // L2: the minimal P was seen in a later tile again
 
-    const uint4* __restrict__ trB = rows + (size_t)f.offB * 16;
+    const uint4* __restrict__ trB = rows + (size_t)f.offB * (kRowBytes / 16);
     const uint32_t* __restrict__ nrmB = norms + f.offB;
     const int n_tiles = (f.nB + kTileRows - 1) / kTileRows;
-    // stage step st (kSub tiles = 128 rows x 256 B = 2048 16-byte pieces, eight per thread) into buffer st & 1; rows beyond nB repeat
+    // stage step st (kSub tiles = 256 rows x 128 B = 2048 16-byte pieces, eight per thread) into buffer st & 1; rows beyond nB repeat
     // the last row with a norm that never wins
     const int n_steps = (n_tiles + kSub - 1) / kSub;
-    static_assert(kSub == 2, "eight named staging registers");
+    static_assert(kStepRows * (kRowBytes / 16) == 8 * 256, "eight named staging registers");
     struct Stage { uint4 v0, v1, v2, v3, v4, v5, v6, v7; uint32_t nv; };  // (named members, returned by value: stays in registers)
     auto stage_load = [&](int st) -> Stage {
         Stage sg;
         auto piece = [&](int i) -> uint4 {
             const int pc = i * 256 + tid;
-            return trB[(size_t)min(st * kSub * kTileRows + (pc >> 4), f.nB - 1) * 16 + (pc & 15)];
+            return trB[(size_t)min(st * kStepRows + (pc >> 3), f.nB - 1) * 8 + (pc & 7)];
         };
         sg.v0 = piece(0); sg.v1 = piece(1); sg.v2 = piece(2); sg.v3 = piece(3);
         sg.v4 = piece(4); sg.v5 = piece(5); sg.v6 = piece(6); sg.v7 = piece(7);
-        const int r = st * kSub * kTileRows + (tid & (kSub * kTileRows - 1));
+        const int r = st * kStepRows + tid;
         const Val big = kBig;
-        sg.nv = (tid < kSub * kTileRows) ? (r < f.nB ? nrmB[r] : __builtin_bit_cast(uint32_t, big)) : 0u;
+        sg.nv = r < f.nB ? nrmB[r] : __builtin_bit_cast(uint32_t, big);
         return sg;
     };
     auto stage_store = [&](int st, const Stage& sg) {
         unsigned char* base = lds + (uint32_t)(st & 1) * kStepBytes;
         auto put = [&](int i, const uint4& v) {
             const int pc = i * 256 + tid;
-            *reinterpret_cast<uint4*>(base + (uint32_t)(pc >> 4) * kRowPitch + (uint32_t)(pc & 15) * 16u) = v;
+            *reinterpret_cast<uint4*>(base + (uint32_t)(pc >> 3) * kRowPitch + (uint32_t)(pc & 7) * 16u) = v;
         };
         put(0, sg.v0); put(1, sg.v1); put(2, sg.v2); put(3, sg.v3);
         put(4, sg.v4); put(5, sg.v5); put(6, sg.v6); put(7, sg.v7);
-        if (tid < kSub * kTileRows) reinterpret_cast<uint32_t*>(lds + kNormOff)[(st & 1) * kSub * kTileRows + tid] = sg.nv;
+        reinterpret_cast<uint32_t*>(lds + kNormOff)[(st & 1) * kStepRows + tid] = sg.nv;
     };
-    Stage sv = stage_load(0);
-    stage_store(0, sv);
-    __syncthreads();
-    for (int st = 0; st < n_steps; ++st) {
-        const bool more = st + 1 < n_steps;
-        if (more) sv = stage_load(st + 1);  // in flight during this step's MFMAs
+    // ---- the main loop, scheduled by hand in the source (scheduling barriers keep the compiler from re-ordering it).
+    // A BLOCK = 32 train rows x the wave's 64 query columns = two accumulators (c0: columns 0..31, c1: 32..63), eight MFMAs in four
+    // k-steps. C-in = the norm of the accumulator's row (rows (reg & 3) + 8 (reg >> 2) + 4 half of the block), so after the K loop the
+    // accumulator holds |a| - 2 a.b (Hamming) / h + a'.~b' (L2). The matrix pipe takes an MFMA every 32 cycles and leaves the
+    // vector ALU free for 24 of them, so every k-step's pair of MFMAs is followed by a share of the work on the block BEFORE (`done`):
+    // its minimum per query column (v_min3) and, once per tile, the comparison with the best so far. The LDS reads of the next k-step /
+    // next block are issued a k-step ahead. Every step runs all four tiles: rows past the end carry norms that never win.
+    struct Block { Acc c0, c1; };
+    const uint32_t a_lane = (uint32_t)col * kRowPitch + 16u * (uint32_t)half;   // this lane's A row inside a block + its 16 bytes of a k-step
+    auto lds_a = [&](int st, int blk, int s) -> uint4 {   // blk = 2 * tile + row block
+        return *reinterpret_cast<const uint4*>(lds + (uint32_t)(st & 1) * kStepBytes + (uint32_t)blk * (32u * kRowPitch) + a_lane + 32u * (uint32_t)s);
+    };
+    auto lds_n = [&](int st, int blk, int g) -> uint4 {
+        return *reinterpret_cast<const uint4*>(lds + kNormOff + (uint32_t)(((st & 1) * kSub * 2 + blk) * 32 + 8 * g + 4 * half) * 4u);
+    };
+    auto as_acc = [](const uint4& n0, const uint4& n1, const uint4& n2, const uint4& n3) -> Acc {
+        const uint32_t w[16] = {n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, n3.x, n3.y, n3.z, n3.w};
+        Acc r;
 #pragma unroll
-        for (int u = 0; u < kSub; ++u) {
-        const int t = st * kSub + u;
-        if (t >= n_tiles) break;            // workgroup-uniform
-        const unsigned char* tb = lds + (uint32_t)(st & 1) * kStepBytes + (uint32_t)u * kTileBytes;
-        const uint32_t* nb = reinterpret_cast<const uint32_t*>(lds + kNormOff) + ((st & 1) * kSub + u) * kTileRows;
-        Acc acc[2][2];
-        // C-in = the norm of the accumulator's row: rows (reg & 3) + 8 (reg >> 2) + 4 half of the 32-row block
-#pragma unroll
-        for (int rb = 0; rb < 2; ++rb) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const uint4 n4 = *reinterpret_cast<const uint4*>(nb + rb * 32 + 8 * g + 4 * half);
-                acc[rb][0][4 * g + 0] = __builtin_bit_cast(Val, n4.x); acc[rb][0][4 * g + 1] = __builtin_bit_cast(Val, n4.y);
-                acc[rb][0][4 * g + 2] = __builtin_bit_cast(Val, n4.z); acc[rb][0][4 * g + 3] = __builtin_bit_cast(Val, n4.w);
-            }
-            acc[rb][1] = acc[rb][0];
+        for (int i = 0; i < 16; ++i) r[i] = __builtin_bit_cast(Val, w[i]);
+        return r;
+    };
+    auto mfma = [&](const uint4& a, const uint4& b, const Acc& c) -> Acc {
+        if constexpr (HAM) {
+            auto wide = [](const uint4& v) { return i32x8{(int)v.x, (int)v.y, (int)v.z, (int)v.w, 0, 0, 0, 0}; };
+            // formats: cbsz = blgp = 4 (FP4 E2M1); both scales 2^0
+            return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wide(a), wide(b), c, 4, 4, 0, kFp4UnitScale, 0, kFp4UnitScale);
+        } else {
+            return __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_bit_cast(i32x4, a), __builtin_bit_cast(i32x4, b), c, 0, 0, 0);
         }
+    };
+    Val mn[2] = {kBig, kBig};   // the running minimum of the tile `done` belongs to
+    auto min_regs = [&](const Block& bl, int from, int to) {
 #pragma unroll
-        for (int s = 0; s < 8; ++s) {
-            // A operand: train row (32 rb + col), bytes 32 s + 16 half .. + 16 (the same bytes of the row as the B operand's: the
-            // dot product pairs equal positions whatever order the instruction visits them in)
-            const uint4 a0 = *reinterpret_cast<const uint4*>(tb + (uint32_t)col * kRowPitch + (uint32_t)(32 * s + 16 * half));
-            const uint4 a1 = *reinterpret_cast<const uint4*>(tb + (uint32_t)(32 + col) * kRowPitch + (uint32_t)(32 * s + 16 * half));
-            if constexpr (HAM) {
-                acc[0][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_bit_cast(i32x4, a0), __builtin_bit_cast(i32x4, bq[0][s]), acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_bit_cast(i32x4, a0), __builtin_bit_cast(i32x4, bq[1][s]), acc[0][1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_bit_cast(i32x4, a1), __builtin_bit_cast(i32x4, bq[0][s]), acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_bit_cast(i32x4, a1), __builtin_bit_cast(i32x4, bq[1][s]), acc[1][1], 0, 0, 0);
-            } else {
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a0), __builtin_bit_cast(bf16x8, bq[0][s]), acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a0), __builtin_bit_cast(bf16x8, bq[1][s]), acc[0][1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a1), __builtin_bit_cast(bf16x8, bq[0][s]), acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a1), __builtin_bit_cast(bf16x8, bq[1][s]), acc[1][1], 0, 0, 0);
-            }
+        for (int reg = from; reg < to; ++reg) {
+            mn[0] = min(mn[0], bl.c0[reg]);
+            mn[1] = min(mn[1], bl.c1[reg]);
         }
-        // the tile's minimum per query column (this lane's 32 of the 64 rows), and the first tile that reached it
+    };
+    auto tile_compare = [&](int t) {   // the first tile that reached the minimum stays
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
-            Val mn = acc[0][c][0];
-#pragma unroll
-            for (int reg = 1; reg < 16; ++reg) mn = min(mn, acc[0][c][reg]);
-#pragma unroll
-            for (int reg = 0; reg < 16; ++reg) mn = min(mn, acc[1][c][reg]);
-            const bool lt = mn < bestv[c];
-            bestv[c] = lt ? mn : bestv[c];
+            const bool lt = mn[c] < bestv[c];
+            if constexpr (!HAM) tied[c] = lt ? false : (tied[c] || mn[c] == bestv[c]);
+            bestv[c] = lt ? mn[c] : bestv[c];
             bestt[c] = lt ? t : bestt[c];
+            mn[c] = kBig;
         }
+    };
+    // staging runs two steps ahead: step st + 2 is requested from memory while step st + 1, requested a step ago, goes into the other
+    // LDS buffer (last read before the barrier that ended step st - 1) -- all of it BEFORE the step's products, which then form one
+    // straight piece of code up to the barrier
+    Stage sv = stage_load(0);
+    stage_store(0, sv);
+    if (n_steps > 1) sv = stage_load(1);
+    __syncthreads();
+    Block done;   // at first a dummy that beats nothing
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) done.c0[reg] = done.c1[reg] = kBig;
+    for (int st = 0; st < n_steps; ++st) {
+        if (st + 1 < n_steps) stage_store(st + 1, sv);
+        if (st + 2 < n_steps) sv = stage_load(st + 2);
+        uint4 a_next = lds_a(st, 0, 0);
+        uint4 n0 = lds_n(st, 0, 0), n1 = lds_n(st, 0, 1), n2 = lds_n(st, 0, 2), n3 = lds_n(st, 0, 3);
+#pragma unroll
+        for (int blk = 0; blk < 2 * kSub; ++blk) {
+            Block cur;
+            {   // k-step 0; `done`'s last MFMAs are still in the pipe: the previous tile's comparison goes here
+                const uint4 a = a_next;
+                const Acc nrm = as_acc(n0, n1, n2, n3);
+                cur.c1 = mfma(a, bq[1][0], nrm);
+                cur.c0 = mfma(a, bq[0][0], nrm);
+                a_next = lds_a(st, blk, 1);
+                if ((blk & 1) == 1) tile_compare(st * kSub + (blk >> 1) - 1);   // covers the blocks up to blk - 2
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int s = 1; s < kKSteps; ++s) {
+                const uint4 a = a_next;
+                cur.c0 = mfma(a, bq[0][s], cur.c0);
+                cur.c1 = mfma(a, bq[1][s], cur.c1);
+                if (s + 1 < kKSteps) a_next = lds_a(st, blk, s + 1);
+                else if (blk + 1 < 2 * kSub) a_next = lds_a(st, blk + 1, 0);
+                if (blk + 1 < 2 * kSub) {
+                    if (s == 1) n0 = lds_n(st, blk + 1, 0);
+                    if (s == 2) n1 = lds_n(st, blk + 1, 1);
+                    if (s == 3) { n2 = lds_n(st, blk + 1, 2); n3 = lds_n(st, blk + 1, 3); }
+                }
+                min_regs(done, s == 1 ? 0 : (s == 2 ? 6 : 11), s == 1 ? 6 : (s == 2 ? 11 : 16));
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            done = cur;
         }
-        if (more) stage_store(st + 1, sv);  // the other buffer: last read one barrier ago
         __syncthreads();
     }
+    min_regs(done, 0, 16);
+    tile_compare(n_steps * kSub - 1);
     // ---- the two halves of the wave hold disjoint row sets of the same query: lower value, then earlier tile
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
         const Val ov = __builtin_bit_cast(Val, __shfl_xor(__builtin_bit_cast(int, bestv[c]), 32));
         const int ot = __shfl_xor(bestt[c], 32);
         const bool take = ov < bestv[c] || (ov == bestv[c] && ot < bestt[c]);
+        if constexpr (!HAM) {
+            const bool otied = __shfl_xor((int)tied[c], 32) != 0;
+            tied[c] = ov == bestv[c] ? (tied[c] || otied || ot != bestt[c]) : (ov < bestv[c] ? otied : tied[c]);
+        }
         bestt[c] = take ? ot : bestt[c];
     }
-    // ---- every query's winning tile once more, one lane per train row, in the norm's own arithmetic: the first minimal row
+    // ---- every query's winning tile once more in exact integers: the first minimal row. The search of one query is a chain of
+    //      global-load latencies with little work between them, so several queries are in flight per loop trip.
     gms_dmatch* __restrict__ out = matches + pr.match_off;
-    for (int i = 0; i < 64; ++i) {
-        const int q = q0 + wave * 64 + i;
-        if (q >= f.m) break;                                                          // wave-uniform
-        const int tstar = __shfl(i < 32 ? bestt[0] : bestt[1], i & 31);
-        uint32_t key;
-        if constexpr (HAM) {
-            const int r = tstar * kTileRows + lane, rr = min(r, f.nB - 1);
-            const uint4* qa = reinterpret_cast<const uint4*>(reinterpret_cast<const uint32_t*>(raw) + (size_t)(f.offA + q) * 8);
-            const uint4* tb4 = reinterpret_cast<const uint4*>(reinterpret_cast<const uint32_t*>(raw) + (size_t)(f.offB + rr) * 8);
-            const uint4 x0 = qa[0], x1 = qa[1], y0 = tb4[0], y1 = tb4[1];
-            const uint32_t d = (uint32_t)(__builtin_popcount(x0.x ^ y0.x) + __builtin_popcount(x0.y ^ y0.y) + __builtin_popcount(x0.z ^ y0.z) +
-                                          __builtin_popcount(x0.w ^ y0.w) + __builtin_popcount(x1.x ^ y1.x) + __builtin_popcount(x1.y ^ y1.y) +
-                                          __builtin_popcount(x1.z ^ y1.z) + __builtin_popcount(x1.w ^ y1.w));
-            key = r < f.nB ? (d << 6) | (uint32_t)lane : 0xFFFFFFFFu;
-        } else {
-            // The tile's 64 rows are 16 KB of consecutive memory: read them coalesced -- a wave instruction covers four whole rows,
-            // lane = (row of the four, 16-byte piece of the row) -- and add a row's sixteen partial dot products up across its lanes.
-            // bf16 rows hold the integers exactly, so |a|^2 + |b|^2 - 2 a.b (two elements per v_dot2c_f32_bf16) is made of exact
-            // integers below 2^24 in any order.
-            typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
-            const int piece = lane & 15, rsub = lane >> 4;
-            const uint4 x = rows[(size_t)(f.offA + q) * 16 + piece];
-            const float na = __uint_as_float(norms[f.offA + q]);
-            key = 0xFFFFFFFFu;
-#pragma unroll 4
-            for (int j = 0; j < 16; ++j) {
-                const int row = tstar * kTileRows + 4 * j + rsub;
-                const int rowc = min(row, f.nB - 1);
-                const uint4 y = rows[(size_t)(f.offB + rowc) * 16 + piece];
-                float dot = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, x.x), __builtin_bit_cast(bf16x2, y.x), 0.0f, false);
-                dot = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, x.y), __builtin_bit_cast(bf16x2, y.y), dot, false);
-                dot = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, x.z), __builtin_bit_cast(bf16x2, y.z), dot, false);
-                dot = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, x.w), __builtin_bit_cast(bf16x2, y.w), dot, false);
+    constexpr int kInFlight = HAM ? 4 : 2;
+    for (int i = 0; i < 64; i += kInFlight) {
+        const int qb = q0 + wave * 64 + i;
+        if (qb >= f.m) break;                                                         // wave-uniform
+        uint32_t key[kInFlight];
+        int ts[kInFlight];
 #pragma unroll
-                for (int d = 8; d >= 1; d >>= 1) dot += __shfl_xor(dot, d, 16);
-                const float d2 = (na + __uint_as_float(nrmB[rowc])) - 2.0f * dot;
-                const uint32_t kj = row < f.nB ? ((uint32_t)d2 << 6) | (uint32_t)(4 * j + rsub) : 0xFFFFFFFFu;  // d^2 <= 128 * 255^2 < 2^23
-                key = min(key, kj);
+        for (int u = 0; u < kInFlight; ++u) {
+            const int qc = min(qb + u, f.m - 1);
+            ts[u] = __shfl(i + u < 32 ? bestt[0] : bestt[1], (i + u) & 31);
+            if constexpr (HAM) key[u] = ham_tile_key(reinterpret_cast<const uint32_t*>(raw), f.offA + qc, f.offB, f.nB, ts[u], lane);
+            else key[u] = l2_tile_key(rows, f.offA + qc, f.offB, f.nB, ts[u], lane);
+        }
+        if constexpr (!HAM) {
+#pragma unroll
+            for (int u = 0; u < kInFlight; ++u) {
+                if (__shfl((int)(i + u < 32 ? tied[0] : tied[1]), (i + u) & 31) == 0) continue;   // wave-uniform
+                const int qc = min(qb + u, f.m - 1);
+                for (int t = ts[u] + 1; t < n_tiles; ++t) {
+                    const uint32_t kt = l2_tile_key(rows, f.offA + qc, f.offB, f.nB, t, lane);
+                    if ((kt >> 6) < (key[u] >> 6)) {   // a later tile only wins with a strictly smaller distance
+                        key[u] = kt;
+                        ts[u] = t;
+                    }
+                }
             }
         }
 #pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) key = min(key, (uint32_t)__shfl_xor((int)key, d));
-        if (lane == 0) {
-            gms_dmatch m;
-            m.queryIdx = q;
-            m.trainIdx = f.nB > 0 ? tstar * kTileRows + (int)(key & 63u) : -1;
-            m.imgIdx = 0;
-            m.distance = f.nB > 0 ? (HAM ? (float)(key >> 6) : sqrtf((float)(key >> 6))) : 3.402823466e+38f;
-            *reinterpret_cast<uint4*>(&out[q]) = *reinterpret_cast<const uint4*>(&m);
+        for (int u = 0; u < kInFlight; ++u) {
+            if (lane == 0 && qb + u < f.m) {
+                gms_dmatch m;
+                m.queryIdx = qb + u;
+                m.trainIdx = ts[u] * kTileRows + (int)(key[u] & 63u);
+                m.imgIdx = 0;
+                m.distance = HAM ? (float)(key[u] >> 6) : sqrtf((float)(key[u] >> 6));
+                *reinterpret_cast<uint4*>(&out[qb + u]) = *reinterpret_cast<const uint4*>(&m);
+            }
         }
     }
 }
@@ -489,13 +573,13 @@ bf_l2_loop_kernel(const float* __restrict__ desc, const uint32_t* __restrict__ f
 }  // namespace
 
 // ---- launch helpers ------------------------------------------------------------------------------------------------------------
-// prepared block:  L2       [total][128] bf16 | [total] float norms | [n_frames] u32 "not SIFT-like" flags
-//                  Hamming  [total][256] int8 | [total] int32 popcounts
+// prepared block:  L2       [total][128] int8 (a - 128) | [total] int32 h = floor(sum (a' + 1)^2 / 2) | [n_frames] u32 "not SIFT-like" flags
+//                  Hamming  [total][256] FP4 (128 B)    | [total] float popcounts
 size_t bf_prepared_bytes(int kind, int64_t total, int n_frames)
 {
     if (total < 0 || n_frames < 0) return 0;
-    if (kind == GMS_DESC_L2_F32X128) return ((size_t)total * 260 + (size_t)n_frames * 4 + 15) & ~(size_t)15;
-    if (kind == GMS_DESC_HAMMING256) return ((size_t)total * 260 + 15) & ~(size_t)15;
+    if (kind == GMS_DESC_L2_F32X128) return ((size_t)total * 132 + (size_t)n_frames * 4 + 15) & ~(size_t)15;
+    if (kind == GMS_DESC_HAMMING256) return ((size_t)total * 132 + 15) & ~(size_t)15;
     return 0;
 }
 
@@ -507,15 +591,15 @@ hipError_t launch_bf_prepare(int kind, const void* d_desc, const int64_t* d_fram
     if (kind == GMS_DESC_HAMMING256) {
         const int64_t blocks = (total * 16 + 255) / 256;
         hipLaunchKernelGGL(bf_ham_prepare_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, reinterpret_cast<const uint16_t*>(d_desc), total,
-                           reinterpret_cast<uint4*>(base), reinterpret_cast<int32_t*>(base + (size_t)total * 256));
+                           reinterpret_cast<uint2*>(base), reinterpret_cast<float*>(base + (size_t)total * 128));
         return hipGetLastError();
     }
-    uint32_t* bad = reinterpret_cast<uint32_t*>(base + (size_t)total * 260);
+    uint32_t* bad = reinterpret_cast<uint32_t*>(base + (size_t)total * 132);
     hipError_t e = hipMemsetAsync(bad, 0, (size_t)n_frames * 4, stream);
     if (e != hipSuccess) return e;
     const int64_t blocks = (total * 32 + 255) / 256;
     hipLaunchKernelGGL(bf_l2_prepare_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, reinterpret_cast<const float4*>(d_desc),
-                       d_frame_off, n_frames, total, reinterpret_cast<uint2*>(base), reinterpret_cast<float*>(base + (size_t)total * 256), bad);
+                       d_frame_off, n_frames, total, reinterpret_cast<uint32_t*>(base), reinterpret_cast<int32_t*>(base + (size_t)total * 128), bad);
     return hipGetLastError();
 }
 
@@ -524,7 +608,7 @@ hipError_t launch_bf_match(int kind, const void* d_desc, const void* d_prep, int
 {
     if (n_pairs <= 0 || max_query <= 0) return hipSuccess;
     const char* base = reinterpret_cast<const char*>(d_prep);
-    const uint32_t* norms = reinterpret_cast<const uint32_t*>(base + (size_t)total * 256);
+    const uint32_t* norms = reinterpret_cast<const uint32_t*>(base + (size_t)total * 128);
     const int tiles = (max_query + kQueriesPerBlock - 1) / kQueriesPerBlock;
     const uint32_t n = (uint32_t)tiles * (uint32_t)n_pairs;
     if (kind == GMS_DESC_HAMMING256 && d_prep != nullptr) {
@@ -547,9 +631,9 @@ hipError_t launch_bf_match(int kind, const void* d_desc, const void* d_prep, int
         return hipGetLastError();
     }
     if (kind == GMS_DESC_L2_F32X128) {
-        const uint32_t* bad = reinterpret_cast<const uint32_t*>(base + (size_t)total * 260);
-        hipLaunchKernelGGL(bf_mfma_kernel<false>, dim3(n), dim3(256), 0, stream, reinterpret_cast<const uint4*>(base), norms, bad, d_desc,
-                           d_frame_off, n_frames, d_pairs, tiles, n, d_matches);
+        const uint32_t* bad = reinterpret_cast<const uint32_t*>(base + (size_t)total * 132);
+        hipLaunchKernelGGL(bf_mfma_kernel<false>, dim3(n), dim3(256), 0, stream, reinterpret_cast<const uint4*>(base), norms, bad,
+                           d_desc, d_frame_off, n_frames, d_pairs, tiles, n, d_matches);
         // pairs with a frame that is not SIFT-like (every block of the other pairs returns at once)
         hipLaunchKernelGGL(bf_l2_loop_kernel<kL2Dim>, dim3(n), dim3(256), 0, stream, reinterpret_cast<const float*>(d_desc), bad, d_frame_off,
                            n_frames, d_pairs, tiles, d_matches);

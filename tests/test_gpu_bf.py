@@ -71,8 +71,9 @@ def test_hamming_10k_config2(ctx, pkg, oracle, synth):
 
 def test_l2_sift_like_rows_on_the_matrix_cores(ctx, pkg, oracle, synth):
     rng = np.random.default_rng(4)
-    counts = [1, 31, 64, 65, 257, 1000, 3000]
+    counts = [1, 31, 64, 65, 257, 1000, 3000, 777]
     descs = [np.clip(np.rint(rng.gamma(1.2, 22.0, (n, 128))), 0, 255).astype(np.float32) for n in counts]
+    descs[7] = rng.integers(0, 256, (777, 128)).astype(np.float32)   # every value of the int8 operands' range, both signs
     descs[5][500:520] = descs[5][100:120]        # duplicate train rows
     descs[6][:20] = descs[5][100:120]
     descs[4][:] = 255.0                          # the largest norms and distances that can occur
@@ -82,6 +83,29 @@ def test_l2_sift_like_rows_on_the_matrix_cores(ctx, pkg, oracle, synth):
     pairs = _pairs(pkg, counts, ab)
     got = batch.match_pairs(ctx, dt, pairs)
     _check(oracle, descs, pairs, got, False)
+
+
+def test_l2_distances_one_apart_in_different_tiles(ctx, pkg, oracle, synth):
+    """The matrix-core pass ranks train rows by floor((d^2 - c(query)) / 2): a later tile holding a distance ONE below an earlier
+    tile's minimum can share that value, and must still win (and lose when it is one above)."""
+    rng = np.random.default_rng(6)
+    n_q, n_t = 96, 1500
+    base = rng.integers(40, 200, (n_q, 128)).astype(np.float32)
+    train = rng.integers(0, 256, (n_t, 128)).astype(np.float32)     # far from every query
+    for q in range(n_q):
+        k, first_is_closer = 1 + q % 5, (q // 5) % 2 == 0
+        near, far = base[q].copy(), base[q].copy()
+        near[rng.choice(128, k, replace=False)] += 1.0               # d^2 = k
+        far[rng.choice(128, k + 1, replace=False)] -= 1.0            # d^2 = k + 1
+        r1, r2 = 3 + 7 * q, 700 + 8 * q                              # tiles 0..10 and 10..22
+        train[r1], train[r2] = (near, far) if first_is_closer else (far, near)
+    descs = [base, train]
+    batch, table, dt = _tables(ctx, pkg, synth, descs, pkg.GMS_DESC_L2_F32X128)
+    pairs = _pairs(pkg, [n_q, n_t], [(0, 1)])
+    got = batch.match_pairs(ctx, dt, pairs)
+    _check(oracle, descs, pairs, got, False)
+    want_rows = np.array([(3 + 7 * q) if (q // 5) % 2 == 0 else (700 + 8 * q) for q in range(n_q)])
+    assert (got["trainIdx"][:n_q] == want_rows).all()
 
 
 def test_l2_general_floats_take_the_reference_loop(ctx, pkg, oracle, synth):
