@@ -272,12 +272,12 @@ def bf_gms_leg(ctx, wl, pkg, stream, kind, n_frames=64, n_pairs=1024, steps=3):
         if failed or got_m.tobytes() != want_m.tobytes() or res[i].tobytes() != wres[0].tobytes() or got_o.tobytes() != wout[:k].tobytes():
             bad += 1
     evals = float(n_pairs) * n_kp * n_kp
-    if kind == "orb":  # hamming = |a| + |b| - 2 a.b over the 256 bits as 0/1 bytes on v_mfma_i32_32x32x32_i8: 2 x 256 int8 ops per evaluation
-        roof = {"bound": "mfma", "achieved": evals * 512 / (match_ms * 1e-3) / 1e12, "peak": 5000.0, "unit": "TOP/s (int8)",
-                "note": "int8 dense peak = 2 x the bf16 dense peak (MI355X_MICROARCH.md, Matrix cores); HBM traffic of the matcher is 5 MB per pair"}
-    else:
-        roof = {"bound": "mfma", "achieved": evals * 256 / (match_ms * 1e-3) / 1e12, "peak": 2500.0, "unit": "TFLOP/s",
-                "note": "bf16 dense peak; 2 x 128 flop per distance evaluation"}
+    if kind == "orb":  # hamming = |a| + |b| - 2 a.b over the 256 bits as 0/1 FP4 elements on v_mfma_scale_f32_32x32x64_f8f6f4: 2 x 256 ops per evaluation
+        roof = {"bound": "mfma", "achieved": evals * 512 / (match_ms * 1e-3) / 1e12, "peak": 10000.0, "unit": "TFLOP/s (fp4)",
+                "note": "FP4 dense peak = 4 x the bf16 dense peak (MI355X_MICROARCH.md, Matrix cores); HBM traffic of the matcher is 2.6 MB per pair"}
+    else:  # d^2 = w(a) + 2 a'.~b' + c(b) with the cross term on v_mfma_i32_32x32x32_i8: 2 x 128 int8 ops per evaluation
+        roof = {"bound": "mfma", "achieved": evals * 256 / (match_ms * 1e-3) / 1e12, "peak": 5000.0, "unit": "TOP/s (int8)",
+                "note": "int8 dense peak = 2 x the bf16 dense peak; 2 x 128 ops per distance evaluation"}
     roof["frac"] = roof["achieved"] / roof["peak"]
     roof["kernel_ms_per_launch"] = match_ms
     return {"workload": f"{kind}: descriptors of {n_frames} frames x {n_kp} keypoints resident in HBM -> BFMatcher::match (no cross-check, "

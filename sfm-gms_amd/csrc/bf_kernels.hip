@@ -138,11 +138,11 @@ bf_hamming_kernel(const uint32_t* __restrict__ desc, const int64_t* __restrict__
 
 // ---- the per-frame tables of the matrix-core paths ---------------------------------------------------------------------------------
 // NORM_L2: one 32-lane group per 128-float row (16 bytes per lane). A SIFT-like row (integers 0..255) becomes 128 int8 a' = a - 128
-// with h = floor(sum (a' + 1)^2 / 2) beside it; a row with any other value flags its frame (whose pairs take the
+// with w = sum (a' + 1)^2 beside it; a row with any other value flags its frame (whose pairs take the
 // loop kernel).
 __global__ void __launch_bounds__(256)
 bf_l2_prepare_kernel(const float4* __restrict__ desc, const int64_t* __restrict__ frame_off, int n_frames, int64_t total,
-                     uint32_t* __restrict__ rows_i8, int32_t* __restrict__ h_norms, uint32_t* __restrict__ frame_bad)
+                     uint32_t* __restrict__ rows_i8, int32_t* __restrict__ w_norms, uint32_t* __restrict__ frame_bad)
 {
     const int64_t row = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 5;
     const int part = (int)(threadIdx.x & 31);
@@ -156,7 +156,7 @@ bf_l2_prepare_kernel(const float4* __restrict__ desc, const int64_t* __restrict_
     int w = (e0 + 1) * (e0 + 1) + (e1 + 1) * (e1 + 1) + (e2 + 1) * (e2 + 1) + (e3 + 1) * (e3 + 1);
 #pragma unroll
     for (int d = 16; d >= 1; d >>= 1) w += __shfl_xor(w, d, 32);
-    if (part == 0) h_norms[row] = w >> 1;
+    if (part == 0) w_norms[row] = w;
     if (__ballot(bad) != 0ull && bad) {
         int lo = 0, hi = n_frames - 1;  // last frame f with frame_off[f] <= row
         while (lo < hi) {
@@ -188,20 +188,21 @@ bf_ham_prepare_kernel(const uint16_t* __restrict__ desc, int64_t total, uint2* _
 // ---- both norms on the matrix cores ------------------------------------------------------------------------------------------------
 // One 256-thread workgroup = 256 query rows of one pair (four waves x 64 query columns, the B operands, resident in registers)
 // against all train rows of the pair's other frame, streamed through LDS in tiles of 64 rows (the A operands), four tiles per
-// staging step. Per tile a lane only keeps the MINIMUM of its 32 values per query column (one v_min3 per two values) and the tile
-// it came from -- tracking the arg-min per value would cost more vector instructions than the tile's MFMAs take. The winning TILE
-// of a query is then searched once more at the end, in exact integer arithmetic, for the first minimal row.
-//   Hamming  rows = 256 x FP4 (128 B), v_mfma_scale_f32_32x32x64_f8f6f4 with both formats FP4 and unit scales (four per tile and
+// staging step. Tracking the arg-min per accumulator element would cost more vector instructions than the MFMAs take; a lane only
+// takes the MINIMUM of its 16 values per query column and 32-row block (one v_min3 per two values) and remembers the block.
+//   Hamming  rows = 256 x FP4 (128 B), v_mfma_scale_f32_32x32x64_f8f6f4 with both formats FP4 and unit scales (four per block and
 //            accumulator, at twice the int8 rate). hamming = |a| + |b| - 2 a.b over 0/1 elements: the B operand is the query row
-//            times -2 (FP4 holds -2 exactly: every nibble 0x2 -> 0xC), the accumulator starts from the train row's popcount, so it
-//            ends as |a| - 2 a.b -- small integers, exact in fp32.
-//   L2       rows = 128 x int8 (128 B), v_mfma_i32_32x32x32_i8 (four per tile and accumulator; the bf16 form needs eight at half the
+//            times -2 (FP4 holds -2 exactly: every nibble 0x2 -> 0xC); the accumulator starts from the train row's popcount PLUS
+//            (row inside the block) / 32, so it ends as |a| - 2 a.b + row / 32 -- exact in fp32 -- and the plain minimum already is
+//            "smallest distance, then lowest row": integer part = distance - |b|, fraction = the row. No second pass.
+//   L2       rows = 128 x int8 (128 B), v_mfma_i32_32x32x32_i8 (four per block and accumulator; the bf16 form needs eight at half the
 //            rate). With a' = a - 128 and the query side as ~b' = 127 - b (a bytewise NOT: both fit int8 for every value 0..255),
 //            a - b = (a' + 1) + ~b', so d^2 = w(a) + 2 a'.~b' + [sum ~b'^2 + 2 sum ~b'] with w(a) = sum (a' + 1)^2; the bracket is
-//            the query's alone. The accumulator starts from h = floor(w / 2) and ends as P = h + a'.~b' = floor((w + 2 a'.~b') / 2):
-//            the row of the smallest d^2 has the smallest P, but two rows whose d^2 differ by one can share it. A query whose
-//            minimal P shows up in more than one tile is therefore flagged, and its final search covers every tile from the first
-//            such one on (exact, rarely needed: d^2 within one of the minimum, in another tile).
+//            the query's alone. The accumulator starts from floor(w / 2) and ends as P = floor((w + 2 a'.~b') / 2): the row of
+//            the smallest d^2 has the smallest P, but two rows whose d^2 differ by one can share it. The winning BLOCK of a query
+//            is therefore searched once more at the end, in exact integers, for the first minimal row. A query whose minimal P
+//            shows up in a second block as well (d^2 within one of the minimum, in another block: a few per cent of the queries
+//            that have no true match) gets both searched; in more than two, every block from the first such one on.
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) int i32x4;
 typedef __attribute__((ext_vector_type(8))) int i32x8;
@@ -221,30 +222,11 @@ constexpr int kQueriesPerBlock = 256;            // 4 waves x 64 query columns
 constexpr int kKSteps = 4;                       // MFMAs per (tile, accumulator): 4 x 32 bytes of a row
 constexpr int kFp4UnitScale = 0x7F7F7F7F;        // E8M0 127 = 2^0 in every byte
 
-__device__ __forceinline__ uint32_t wave_min(uint32_t key)
-{
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) key = min(key, (uint32_t)__shfl_xor((int)key, d));
-    return key;
-}
-
-// (distance << 6 | row inside the tile) of the first nearest row of tile t to one query row, the same in every lane.
-// Hamming: one lane per train row, on the raw bits.
-__device__ __forceinline__ uint32_t ham_tile_key(const uint32_t* __restrict__ raw, int64_t q_row, int64_t offB, int nB, int t, int lane)
-{
-    const int r = t * kTileRows + lane, rr = min(r, nB - 1);
-    const uint4* qa = reinterpret_cast<const uint4*>(raw + (size_t)q_row * 8);
-    const uint4* tb4 = reinterpret_cast<const uint4*>(raw + (size_t)(offB + rr) * 8);
-    const uint4 x0 = qa[0], x1 = qa[1], y0 = tb4[0], y1 = tb4[1];
-    const uint32_t d = (uint32_t)(__builtin_popcount(x0.x ^ y0.x) + __builtin_popcount(x0.y ^ y0.y) + __builtin_popcount(x0.z ^ y0.z) +
-                                  __builtin_popcount(x0.w ^ y0.w) + __builtin_popcount(x1.x ^ y1.x) + __builtin_popcount(x1.y ^ y1.y) +
-                                  __builtin_popcount(x1.z ^ y1.z) + __builtin_popcount(x1.w ^ y1.w));
-    return wave_min(r < nB ? (d << 6) | (uint32_t)lane : 0xFFFFFFFFu);
-}
-
-// L2 on the int8 rows: the tile's 64 rows are 8 KB of consecutive memory, read coalesced -- a wave instruction covers eight whole
-// rows, lane = (row of the eight, 16-byte piece of the row). d^2 = sum (a' - b')^2 (the shift by 128 cancels) = a'.a' + b'.b' - 2 a'.b'
-// per piece, four elements per v_dot4_i32_i8, the eight pieces of a row added up across its lanes.
+// L2, the exact search of a 32-row block, eight queries per wave: the eight lanes of a group (lane >> 3) hold the 16-byte pieces
+// (lane & 7) of the group's query and walk the 32 rows of the group's OWN block, so a group's load is one whole 128-byte row.
+// With the query side as nb = ~b' (the B operand of the matrix pass): d^2 = w(a) + 2 a'.nb + [nb.nb + 2 sum nb]; four elements per
+// v_dot4_i32_i8, the eight pieces added up with three DPP adds (the full sum lands in lanes 4..7 of the group, which all keep the
+// same running minimum). Returns (d^2 << 5 | row inside the block) of the block's first nearest row -- valid in lanes 4..7.
 __device__ __forceinline__ int dot16(const uint4& a, const uint4& b)
 {
     int d = __builtin_amdgcn_sdot4((int)a.x, (int)b.x, 0, false);
@@ -253,29 +235,29 @@ __device__ __forceinline__ int dot16(const uint4& a, const uint4& b)
     return __builtin_amdgcn_sdot4((int)a.w, (int)b.w, d, false);
 }
 
-__device__ __forceinline__ uint32_t l2_tile_key(const uint4* __restrict__ rows, int64_t q_row, int64_t offB, int nB, int t, int lane)
+__device__ __forceinline__ uint32_t l2_block_key(const uint4* __restrict__ rows, const uint32_t* __restrict__ w_norms, const uint4& nb,
+                                                 int query_part, int64_t offB, int nB, int blk, int piece)
 {
-    const int piece = lane & 7, rsub = lane >> 3;
-    const uint4 x = rows[(size_t)q_row * 8 + piece];
-    uint4 y[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) y[j] = rows[(size_t)(offB + min(t * kTileRows + 8 * j + rsub, nB - 1)) * 8 + piece];
-    const int xx = dot16(x, x);
     uint32_t key = 0xFFFFFFFFu;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        int d2 = xx + dot16(y[j], y[j]) - 2 * dot16(x, y[j]);
-#pragma unroll
-        for (int d = 4; d >= 1; d >>= 1) d2 += __shfl_xor(d2, d, 8);
-        const int row = t * kTileRows + 8 * j + rsub;
-        key = min(key, row < nB ? ((uint32_t)d2 << 6) | (uint32_t)(8 * j + rsub) : 0xFFFFFFFFu);   // d^2 <= 128 * 255^2 < 2^23
+    for (int r = 0; r < 32; ++r) {   // (all 64 loads in flight together)
+        const int row = blk * 32 + r;
+        const int64_t rr = offB + min(row, nB - 1);
+        const uint4 y = rows[(size_t)rr * 8 + piece];
+        const int w = (int)w_norms[rr];
+        int d2 = 2 * dot16(y, nb) + query_part;
+        d2 += __builtin_amdgcn_update_dpp(0, d2, 0xB1, 0xF, 0xF, true);    // quad_perm [1,0,3,2]
+        d2 += __builtin_amdgcn_update_dpp(0, d2, 0x4E, 0xF, 0xF, true);    // quad_perm [2,3,0,1]: every lane of a quad has the quad's sum
+        d2 += __builtin_amdgcn_update_dpp(0, d2, 0x114, 0xF, 0xF, true);   // row_shr:4: lanes 4..7 add the quad before them
+        d2 += w;
+        key = min(key, row < nB ? ((uint32_t)d2 << 5) | (uint32_t)r : 0xFFFFFFFFu);   // d^2 <= 128 * 255^2 < 2^23
     }
-    return wave_min(key);
+    return key;
 }
 
 template <bool HAM>
 __global__ void __launch_bounds__(256, 2)
-bf_mfma_kernel(const uint4* __restrict__ rows, const uint32_t* __restrict__ norms, const uint32_t* __restrict__ frame_bad, const void* __restrict__ raw, const int64_t* __restrict__ frame_off, int n_frames,
+bf_mfma_kernel(const uint4* __restrict__ rows, const uint32_t* __restrict__ norms, const uint32_t* __restrict__ frame_bad, const int64_t* __restrict__ frame_off, int n_frames,
                const gms_pair* __restrict__ pairs, int tiles_per_pair, uint32_t n_tasks, gms_dmatch* __restrict__ matches)
 {
     using Acc = typename std::conditional<HAM, f32x16, i32x16>::type;
@@ -319,9 +301,11 @@ bf_mfma_kernel(const uint4* __restrict__ rows, const uint32_t* __restrict__ norm
             else bq[c][s] = make_uint4(~r4.x, ~r4.y, ~r4.z, ~r4.w);
         }
     }
-    Val bestv[2] = {kBig, kBig};
-    int bestt[2] = {0, 0};
-    bool tied[2] = {false, false};  // L2: the minimal P was seen in a later tile again
+    Val bestv[2] = {kBig, kBig};    // the smallest block minimum so far (Hamming: with the row fraction) ...
+    Val bestd[2] = {kBig, kBig};    // ... Hamming: its integer part
+    int bestt[2] = {0, 0};          // ... and the block (of 32 train rows) it came from: the first one that reached it
+    int ties[2] = {0, 0};           // L2: in how many later blocks the minimal P was seen again ...
+    int bestt2[2] = {0, 0};         // ... and the last of them
 
     const uint4* __restrict__ trB = rows + (size_t)f.offB * (kRowBytes / 16);
     const uint32_t* __restrict__ nrmB = norms + f.offB;
@@ -340,8 +324,12 @@ bf_mfma_kernel(const uint4* __restrict__ rows, const uint32_t* __restrict__ norm
         sg.v0 = piece(0); sg.v1 = piece(1); sg.v2 = piece(2); sg.v3 = piece(3);
         sg.v4 = piece(4); sg.v5 = piece(5); sg.v6 = piece(6); sg.v7 = piece(7);
         const int r = st * kStepRows + tid;
-        const Val big = kBig;
-        sg.nv = r < f.nB ? nrmB[r] : __builtin_bit_cast(uint32_t, big);
+        Val nv = kBig;
+        if (r < f.nB) {
+            if constexpr (HAM) nv = __uint_as_float(nrmB[r]) + (float)(tid & 31) * (1.0f / 32.0f);   // popcount + row inside the block / 32
+            else nv = (int32_t)nrmB[r] >> 1;                                                          // floor(w / 2)
+        }
+        sg.nv = __builtin_bit_cast(uint32_t, nv);
         return sg;
     };
     auto stage_store = [&](int st, const Stage& sg) {
@@ -359,7 +347,7 @@ bf_mfma_kernel(const uint4* __restrict__ rows, const uint32_t* __restrict__ norm
     // k-steps. C-in = the norm of the accumulator's row (rows (reg & 3) + 8 (reg >> 2) + 4 half of the block), so after the K loop the
     // accumulator holds |a| - 2 a.b (Hamming) / h + a'.~b' (L2). The matrix pipe takes an MFMA every 32 cycles and leaves the
     // vector ALU free for 24 of them, so every k-step's pair of MFMAs is followed by a share of the work on the block BEFORE (`done`):
-    // its minimum per query column (v_min3) and, once per tile, the comparison with the best so far. The LDS reads of the next k-step /
+    // its minimum per query column (v_min3) and then the comparison with the best so far. The LDS reads of the next k-step /
     // next block are issued a k-step ahead. Every step runs all four tiles: rows past the end carry norms that never win.
     struct Block { Acc c0, c1; };
     const uint32_t a_lane = (uint32_t)col * kRowPitch + 16u * (uint32_t)half;   // this lane's A row inside a block + its 16 bytes of a k-step
@@ -385,7 +373,7 @@ bf_mfma_kernel(const uint4* __restrict__ rows, const uint32_t* __restrict__ norm
             return __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_bit_cast(i32x4, a), __builtin_bit_cast(i32x4, b), c, 0, 0, 0);
         }
     };
-    Val mn[2] = {kBig, kBig};   // the running minimum of the tile `done` belongs to
+    Val mn[2] = {kBig, kBig};   // the minimum of `done`
     auto min_regs = [&](const Block& bl, int from, int to) {
 #pragma unroll
         for (int reg = from; reg < to; ++reg) {
@@ -393,13 +381,22 @@ bf_mfma_kernel(const uint4* __restrict__ rows, const uint32_t* __restrict__ norm
             mn[1] = min(mn[1], bl.c1[reg]);
         }
     };
-    auto tile_compare = [&](int t) {   // the first tile that reached the minimum stays
+    auto block_compare = [&](int blk) {   // the first block that reached the minimum stays
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
-            const bool lt = mn[c] < bestv[c];
-            if constexpr (!HAM) tied[c] = lt ? false : (tied[c] || mn[c] == bestv[c]);
-            bestv[c] = lt ? mn[c] : bestv[c];
-            bestt[c] = lt ? t : bestt[c];
+            if constexpr (HAM) {
+                const float d = floorf(mn[c]);   // equal distances: the earlier block holds the lower rows
+                const bool lt = d < bestd[c];
+                bestd[c] = lt ? d : bestd[c];
+                bestv[c] = lt ? mn[c] : bestv[c];
+                bestt[c] = lt ? blk : bestt[c];
+            } else {
+                const bool lt = mn[c] < bestv[c], eq = mn[c] == bestv[c];
+                ties[c] = lt ? 0 : ties[c] + (eq ? 1 : 0);
+                bestt2[c] = eq ? blk : bestt2[c];
+                bestv[c] = lt ? mn[c] : bestv[c];
+                bestt[c] = lt ? blk : bestt[c];
+            }
             mn[c] = kBig;
         }
     };
@@ -421,13 +418,13 @@ bf_mfma_kernel(const uint4* __restrict__ rows, const uint32_t* __restrict__ norm
 #pragma unroll
         for (int blk = 0; blk < 2 * kSub; ++blk) {
             Block cur;
-            {   // k-step 0; `done`'s last MFMAs are still in the pipe: the previous tile's comparison goes here
+            {   // k-step 0; `done`'s last MFMAs are still in the pipe: the comparison of the block before `done` goes here
                 const uint4 a = a_next;
                 const Acc nrm = as_acc(n0, n1, n2, n3);
                 cur.c1 = mfma(a, bq[1][0], nrm);
                 cur.c0 = mfma(a, bq[0][0], nrm);
                 a_next = lds_a(st, blk, 1);
-                if ((blk & 1) == 1) tile_compare(st * kSub + (blk >> 1) - 1);   // covers the blocks up to blk - 2
+                block_compare(st * 2 * kSub + blk - 2);
                 __builtin_amdgcn_sched_barrier(0);
             }
 #pragma unroll
@@ -449,59 +446,89 @@ bf_mfma_kernel(const uint4* __restrict__ rows, const uint32_t* __restrict__ norm
         }
         __syncthreads();
     }
+    block_compare(n_steps * 2 * kSub - 2);
     min_regs(done, 0, 16);
-    tile_compare(n_steps * kSub - 1);
-    // ---- the two halves of the wave hold disjoint row sets of the same query: lower value, then earlier tile
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-        const Val ov = __builtin_bit_cast(Val, __shfl_xor(__builtin_bit_cast(int, bestv[c]), 32));
-        const int ot = __shfl_xor(bestt[c], 32);
-        const bool take = ov < bestv[c] || (ov == bestv[c] && ot < bestt[c]);
-        if constexpr (!HAM) {
-            const bool otied = __shfl_xor((int)tied[c], 32) != 0;
-            tied[c] = ov == bestv[c] ? (tied[c] || otied || ot != bestt[c]) : (ov < bestv[c] ? otied : tied[c]);
-        }
-        bestt[c] = take ? ot : bestt[c];
-    }
-    // ---- every query's winning tile once more in exact integers: the first minimal row. The search of one query is a chain of
-    //      global-load latencies with little work between them, so several queries are in flight per loop trip.
+    block_compare(n_steps * 2 * kSub - 1);
+    // ---- the two halves of the wave hold disjoint row sets of the same query
     gms_dmatch* __restrict__ out = matches + pr.match_off;
-    constexpr int kInFlight = HAM ? 4 : 2;
-    for (int i = 0; i < 64; i += kInFlight) {
-        const int qb = q0 + wave * 64 + i;
-        if (qb >= f.m) break;                                                         // wave-uniform
-        uint32_t key[kInFlight];
-        int ts[kInFlight];
+    if constexpr (HAM) {
+        int rowi[2];
 #pragma unroll
-        for (int u = 0; u < kInFlight; ++u) {
-            const int qc = min(qb + u, f.m - 1);
-            ts[u] = __shfl(i + u < 32 ? bestt[0] : bestt[1], (i + u) & 31);
-            if constexpr (HAM) key[u] = ham_tile_key(reinterpret_cast<const uint32_t*>(raw), f.offA + qc, f.offB, f.nB, ts[u], lane);
-            else key[u] = l2_tile_key(rows, f.offA + qc, f.offB, f.nB, ts[u], lane);
+        for (int c = 0; c < 2; ++c) {   // lower distance, then lower row
+            rowi[c] = bestt[c] * 32 + (int)((bestv[c] - bestd[c]) * 32.0f);
+            const float od = __shfl_xor(bestd[c], 32);
+            const int orow = __shfl_xor(rowi[c], 32);
+            const bool take = od < bestd[c] || (od == bestd[c] && orow < rowi[c]);
+            bestd[c] = take ? od : bestd[c];
+            rowi[c] = take ? orow : rowi[c];
         }
-        if constexpr (!HAM) {
+        const int q = half ? qrow[1] : qrow[0];   // half 0 writes columns 0..31, half 1 columns 32..63: one record per lane
+        if (q < f.m) {
+            gms_dmatch m;
+            m.queryIdx = q;
+            m.trainIdx = half ? rowi[1] : rowi[0];
+            m.imgIdx = 0;
+            m.distance = (half ? bestd[1] : bestd[0]) + __uint_as_float(norms[f.offA + q]);
+            *reinterpret_cast<uint4*>(&out[q]) = *reinterpret_cast<const uint4*>(&m);
+        }
+    } else {
 #pragma unroll
-            for (int u = 0; u < kInFlight; ++u) {
-                if (__shfl((int)(i + u < 32 ? tied[0] : tied[1]), (i + u) & 31) == 0) continue;   // wave-uniform
-                const int qc = min(qb + u, f.m - 1);
-                for (int t = ts[u] + 1; t < n_tiles; ++t) {
-                    const uint32_t kt = l2_tile_key(rows, f.offA + qc, f.offB, f.nB, t, lane);
-                    if ((kt >> 6) < (key[u] >> 6)) {   // a later tile only wins with a strictly smaller distance
-                        key[u] = kt;
-                        ts[u] = t;
+        for (int c = 0; c < 2; ++c) {   // lower value, then earlier block
+            const Val ov = __builtin_bit_cast(Val, __shfl_xor(__builtin_bit_cast(int, bestv[c]), 32));
+            const int ot = __shfl_xor(bestt[c], 32);
+            const int oties = __shfl_xor(ties[c], 32), ot2 = __shfl_xor(bestt2[c], 32);
+            if (ov < bestv[c]) {
+                bestt[c] = ot;
+                bestt2[c] = ot2;
+                ties[c] = oties;
+            } else if (ov == bestv[c]) {   // both halves reached the minimal P: in the same block, in two blocks, or (rare) in more
+                const int lo = min(bestt[c], ot), hi = max(bestt[c], ot);
+                ties[c] = (ties[c] | oties) != 0 ? 2 : (lo != hi ? 1 : 0);
+                bestt[c] = lo;
+                bestt2[c] = hi;
+            }
+        }
+        // every query's winning block once more in exact integers: the first minimal row; eight queries at a time
+        const int n_blocks = (f.nB + 31) / 32;
+        const int piece = lane & 7, grp = lane >> 3;
+        const uint4 ones = make_uint4(0x01010101u, 0x01010101u, 0x01010101u, 0x01010101u);
+        for (int i0 = 0; i0 < 64; i0 += 8) {
+            if (q0 + wave * 64 + i0 >= f.m) break;                                        // wave-uniform
+            const int i = i0 + grp, q = q0 + wave * 64 + i;                               // this group's query: column i of the wave
+            int blk = __shfl(i0 < 32 ? bestt[0] : bestt[1], i & 31);
+            const int nt = __shfl(i0 < 32 ? ties[0] : ties[1], i & 31);
+            const int blk2 = __shfl(i0 < 32 ? bestt2[0] : bestt2[1], i & 31);
+            const uint4 x = rows[(size_t)(f.offA + min(q, f.m - 1)) * 8 + piece];
+            const uint4 nb = make_uint4(~x.x, ~x.y, ~x.z, ~x.w);
+            const int query_part = dot16(nb, nb) + 2 * dot16(nb, ones);                   // this lane's 16 elements of the bracket
+            uint32_t key = l2_block_key(rows, norms, nb, query_part, f.offB, f.nB, blk, piece);
+            if (__ballot(nt == 1) != 0ull) {   // some group's minimal P was seen in a second block (a group without one repeats its own)
+                const int b = nt == 1 ? blk2 : blk;
+                const uint32_t k2 = l2_block_key(rows, norms, nb, query_part, f.offB, f.nB, b, piece);
+                if ((k2 >> 5) < (key >> 5)) {   // a later block only wins with a strictly smaller distance
+                    key = k2;
+                    blk = b;
+                }
+            }
+            if (__ballot(nt >= 2) != 0ull) {   // ... in more than two (rows repeated all over the frame): every block from the first on
+                const int first = blk;   // (untouched so far: the step above leaves groups with nt >= 2 alone)
+                for (int bb = 0; bb < n_blocks; ++bb) {
+                    if (__ballot(nt >= 2 && bb > first) == 0ull) continue;
+                    const int b = (nt >= 2 && bb > first) ? bb : blk;
+                    const uint32_t k2 = l2_block_key(rows, norms, nb, query_part, f.offB, f.nB, b, piece);
+                    if ((k2 >> 5) < (key >> 5)) {
+                        key = k2;
+                        blk = b;
                     }
                 }
             }
-        }
-#pragma unroll
-        for (int u = 0; u < kInFlight; ++u) {
-            if (lane == 0 && qb + u < f.m) {
+            if (piece == 7 && q < f.m) {
                 gms_dmatch m;
-                m.queryIdx = qb + u;
-                m.trainIdx = ts[u] * kTileRows + (int)(key[u] & 63u);
+                m.queryIdx = q;
+                m.trainIdx = blk * 32 + (int)(key & 31u);
                 m.imgIdx = 0;
-                m.distance = HAM ? (float)(key[u] >> 6) : sqrtf((float)(key[u] >> 6));
-                *reinterpret_cast<uint4*>(&out[qb + u]) = *reinterpret_cast<const uint4*>(&m);
+                m.distance = sqrtf((float)(key >> 5));
+                *reinterpret_cast<uint4*>(&out[q]) = *reinterpret_cast<const uint4*>(&m);
             }
         }
     }
@@ -573,7 +600,7 @@ bf_l2_loop_kernel(const float* __restrict__ desc, const uint32_t* __restrict__ f
 }  // namespace
 
 // ---- launch helpers ------------------------------------------------------------------------------------------------------------
-// prepared block:  L2       [total][128] int8 (a - 128) | [total] int32 h = floor(sum (a' + 1)^2 / 2) | [n_frames] u32 "not SIFT-like" flags
+// prepared block:  L2       [total][128] int8 (a - 128) | [total] int32 w = sum (a' + 1)^2 | [n_frames] u32 "not SIFT-like" flags
 //                  Hamming  [total][256] FP4 (128 B)    | [total] float popcounts
 size_t bf_prepared_bytes(int kind, int64_t total, int n_frames)
 {
@@ -613,7 +640,7 @@ hipError_t launch_bf_match(int kind, const void* d_desc, const void* d_prep, int
     const uint32_t n = (uint32_t)tiles * (uint32_t)n_pairs;
     if (kind == GMS_DESC_HAMMING256 && d_prep != nullptr) {
         hipLaunchKernelGGL(bf_mfma_kernel<true>, dim3(n), dim3(256), 0, stream, reinterpret_cast<const uint4*>(base), norms,
-                           (const uint32_t*)nullptr, d_desc, d_frame_off, n_frames, d_pairs, tiles, n, d_matches);
+                           (const uint32_t*)nullptr, d_frame_off, n_frames, d_pairs, tiles, n, d_matches);
         return hipGetLastError();
     }
     if (kind == GMS_DESC_HAMMING256) {
@@ -633,7 +660,7 @@ hipError_t launch_bf_match(int kind, const void* d_desc, const void* d_prep, int
     if (kind == GMS_DESC_L2_F32X128) {
         const uint32_t* bad = reinterpret_cast<const uint32_t*>(base + (size_t)total * 132);
         hipLaunchKernelGGL(bf_mfma_kernel<false>, dim3(n), dim3(256), 0, stream, reinterpret_cast<const uint4*>(base), norms, bad,
-                           d_desc, d_frame_off, n_frames, d_pairs, tiles, n, d_matches);
+                           d_frame_off, n_frames, d_pairs, tiles, n, d_matches);
         // pairs with a frame that is not SIFT-like (every block of the other pairs returns at once)
         hipLaunchKernelGGL(bf_l2_loop_kernel<kL2Dim>, dim3(n), dim3(256), 0, stream, reinterpret_cast<const float*>(d_desc), bad, d_frame_off,
                            n_frames, d_pairs, tiles, d_matches);
