@@ -52,9 +52,10 @@ namespace {
 //   GMS_STAGGER_US=n     spread of the first dispatch round's start times at 10k matches per pair (0 = off)
 //   GMS_BAND_WS_BYTES=n  budget of the large-pair workspace (default 4 GiB); a batch is filtered in slices that fit it
 //   GMS_DEAL=0|1         never / always deal the matches to the lanes of the byte-matrix kernel (default: what the probe saw)
+//   GMS_SCALE_PROBE=0|1  never / always bound the finer scale hypotheses' inlier counts first (default: while it pays, see below)
 struct Knobs {
     bool dense_on = true, band_on = true;
-    int stagger_us = -1, deal = -1;
+    int stagger_us = -1, deal = -1, scale_probe = -1;
     size_t band_ws_budget = (size_t)4 << 30;
 };
 const Knobs& knobs()
@@ -65,6 +66,7 @@ const Knobs& knobs()
         if (const char* e = std::getenv("GMS_BAND")) v.band_on = std::atoi(e) != 0;
         if (const char* e = std::getenv("GMS_STAGGER_US")) v.stagger_us = std::atoi(e);
         if (const char* e = std::getenv("GMS_DEAL")) v.deal = std::atoi(e) != 0 ? 1 : 0;
+        if (const char* e = std::getenv("GMS_SCALE_PROBE")) v.scale_probe = std::atoi(e) != 0 ? 1 : 0;
         if (const char* e = std::getenv("GMS_BAND_WS_BYTES")) {
             const long long b = std::atoll(e);
             if (b > 0) v.band_ws_budget = (size_t)b;
@@ -155,6 +157,12 @@ struct gms_ctx {
     // reads, without waiting, when it picks the byte-matrix kernel's instantiation
     uint32_t* order_flag = nullptr;
     unsigned dense_launches = 0;
+    // Scale hypotheses: the kernels can bound a scale's inlier count before evaluating it (gms_kernels.hip, PROBE) and skip the
+    // scale when it cannot win -- a gain when at least half of the probes let a scale skip, a loss otherwise. The kernels count
+    // both in probe_stats (device); every sixteenth launch with scale hypotheses probes whatever the verdict and is followed by a
+    // one-thread kernel that turns the counts into order_flag[1] ("probing pays"), which the launches in between follow.
+    DevBuf probe_stats;
+    unsigned scale_launches = 0;
     // the workspaces above are shared by every launch of the context: the last launch that used them, and where
     hipEvent_t ws_event = nullptr;
     hipStream_t ws_stream = nullptr;
@@ -266,10 +274,24 @@ int filter_launch(gms_ctx* c, hipStream_t st, const float* d_pts, const int64_t*
 #ifdef GMS_PHASE_TIMING
     p.diag = g_diag;
 #endif
+    p.probe_scales = 0;
+    p.probe_stats = nullptr;
+    if (kpt && with_scale) {
+        // the scales finer than 20 x 20 and the 14 x 14 one are probed (2, 3, 4); the measuring launches are left out of stream captures
+        const bool measuring = knobs().scale_probe < 0 && !capturing && (c->scale_launches++ & 15u) == 0u;
+        const bool on = knobs().scale_probe >= 0 ? knobs().scale_probe != 0 : (measuring || ((volatile uint32_t*)c->order_flag)[1] != 0u);
+        p.probe_scales = on ? 0x1C : 0;
+        p.probe_stats = measuring ? (uint32_t*)c->probe_stats.p : nullptr;
+    }
     if (kpt && with_scale && knobs().dense_on) {
         // scale hypotheses: scales 0..3 on the byte matrix, the last on the hashed path (two launches, one record per pair)
         p.partial = (uint32_t*)c->partial_ws.p;
         GMS_HIP(gms::launch_filter_scales(p, kpt, n_pairs, st));
+        if (p.probe_stats != nullptr) {
+            void* dflag = nullptr;
+            GMS_HIP(hipHostGetDevicePointer(&dflag, c->order_flag, 0));
+            GMS_HIP(gms::launch_probe_verdict(p.probe_stats, (uint32_t*)dflag + 1, st));
+        }
     } else if (kpt) {
         GMS_HIP(gms::launch_filter(p, kpt, n_pairs, st));
         // every sixteenth byte-matrix launch (and the first) is followed by the spatial-order probe of its batch, for later launches
@@ -401,7 +423,12 @@ int gms_ctx_create(int device, gms_ctx** out_ctx)
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->lane[1].stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ws_event, hipEventDisableTiming);
     if (e == hipSuccess) e = hipHostMalloc((void**)&c->order_flag, 64, hipHostMallocDefault);
-    if (e == hipSuccess) *c->order_flag = 0;
+    if (e == hipSuccess) {
+        c->order_flag[0] = 0;
+        c->order_flag[1] = 1;
+    }
+    if (e == hipSuccess) e = c->probe_stats.reserve(64);
+    if (e == hipSuccess) e = hipMemset(c->probe_stats.p, 0, 64);
     if (e == hipSuccess) e = gms::init_filter_kernels();
     if (e == hipSuccess) e = gms::init_band_kernels();
     if (e == hipSuccess) e = gms::init_big_kernels();
@@ -411,6 +438,7 @@ int gms_ctx_create(int device, gms_ctx** out_ctx)
         if (c->lane[1].stream) (void)hipStreamDestroy(c->lane[1].stream);
         if (c->ws_event) (void)hipEventDestroy(c->ws_event);
         if (c->order_flag) (void)hipHostFree(c->order_flag);
+        c->probe_stats.release();
         delete c;
         return GMS_ERR_HIP;
     }
@@ -431,7 +459,7 @@ int gms_ctx_destroy(gms_ctx* c)
         (void)hipStreamSynchronize(c->own_stream);
         (void)hipStreamSynchronize(c->lane[1].stream);
         if (c->ws_pending) (void)hipEventSynchronize(c->ws_event);
-        DevBuf* bufs[] = {&c->aux, &c->big_ws, &c->band_ws, &c->partial_ws, &c->tab_kp, &c->tab_pts, &c->tab_small};
+        DevBuf* bufs[] = {&c->aux, &c->big_ws, &c->band_ws, &c->partial_ws, &c->probe_stats, &c->tab_kp, &c->tab_pts, &c->tab_small};
         if (c->order_flag) (void)hipHostFree(c->order_flag);
         for (DevBuf* b : bufs) b->release();
         for (Lane& l : c->lane) {

@@ -35,6 +35,8 @@ struct FilterParams {
     uint32_t* partial;          // scale hypotheses: per-pair records of the byte-matrix kernel (scales 0..2), or null
     const uint32_t* pair_flags; // large-pair kernel only: when set, it filters just the pairs whose flag word has bit 1 set
     int dealt;                  // byte-matrix kernel: deal the matches to the lanes (inputs in spatial order; see dense_pair)
+    int probe_scales;           // scale hypotheses: bit s set = bound scale s's inlier count first and skip the scale when it cannot win
+    uint32_t* probe_stats;      // optional device counters: [0] scales probed, [1] scales the probe let skip
     int dense;                  // try the byte-matrix path first (no scale hypotheses only); the general path is the fallback
     double threshold_factor;
     int right_w[5], right_h[5]; // setScale (DLL@0x180048c10): cvRound(20 * ratio[s])
@@ -55,6 +57,7 @@ hipError_t launch_normalize(const void* d_kp, int kp_stride_bytes, const int64_t
                             int n_frames, int64_t total_kp, float* d_pts, hipStream_t stream);
 hipError_t launch_filter(const FilterParams& p, int kpt, int n_pairs, hipStream_t stream);
 hipError_t launch_order_probe(const FilterParams& p, uint32_t* flag, hipStream_t stream);  // *flag: pinned host word
+hipError_t launch_probe_verdict(uint32_t* stats, uint32_t* flag, hipStream_t stream);      // FilterParams::probe_stats -> pinned host word
 hipError_t launch_filter_scales(const FilterParams& p, int kpt, int n_pairs, hipStream_t stream);
 // large pairs (gms_kernel_big.hip): code words and table in a per-workgroup HBM slab
 constexpr int kBigMaxMatches = 1 << 22;       // per pair: 4 194 304 (a 2594 x 1131 one-keypoint-per-pixel frame of DisparityUtil.cpp:299 has 2.93 M)

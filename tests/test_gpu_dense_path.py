@@ -260,3 +260,51 @@ def test_probe_switches_to_dealing_on_ordered_input(pkg, oracle, synth):
             for i in range(len(pairs)):
                 o, k = int(pairs["match_off"][i]), int(res["n_inliers"][i])
                 assert out[o:o + k].tobytes() == wout[o:o + k].tobytes()
+
+
+# ---- the scale probe (an upper bound of a scale's inlier count that lets the scale skip) ---------------------------------------------
+@pytest.mark.parametrize("setting", ["0", "1"])
+def test_scale_probe_setting_whole_file_again(setting):
+    """GMS_SCALE_PROBE=0 / 1 (read once per process): never probe / always probe scales 2..4. Skipping a scale whose bound cannot beat
+    the best count must not change a byte: this file, the parity sweep, the golden fixtures and the fuzz cases again."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = [os.path.join(root, "tests", f) for f in ("test_gpu_dense_path.py", "test_gpu_parity.py", "test_golden.py", "test_gpu_fuzz.py")]
+    res = subprocess.run([sys.executable, "-m", "pytest", *files, "-m", "gpu", "-x", "-q", "-k", "not again"], capture_output=True,
+                         text=True, timeout=1500, env=dict(os.environ, GMS_SCALE_PROBE=setting))
+    assert res.returncode == 0, res.stdout[-3000:]
+
+
+def test_scale_probe_verdict_changes_between_launches(pkg, oracle, synth):
+    """A fresh context probes, measures how often the probe lets a scale skip and follows that verdict until it measures again
+    (every sixteenth launch). First 20 launches on pairs whose best hypothesis is one of the probed scales (the right image at half
+    size: the 28 x 28 grid wins, its probe cannot let it skip), then 20 on pairs at scale 1.0 (the probes of scales 3 and 4 do): every
+    launch bit-exact."""
+    import importlib
+    batch = importlib.import_module("sfm-gms_amd.batch")
+    size, n = (1920, 1080), 6000
+    for factor, first_id in ((0.5, 500), (1.0, 520)):
+        made = [synth.make_pair(first_id + i, size1=size, n1=n, inlier_frac=0.6, scale=factor, theta_deg=0.0 if factor == 0.5 else 45.0 * i) for i in range(4)]
+        frames = [kp for kp1, kp2, _ in made for kp in (kp1, kp2)]
+        pairs = np.zeros(4, dtype=pkg.PAIR_DTYPE)
+        for i in range(4):
+            pairs[i] = (2 * i, 2 * i + 1, n, 0, i * n)
+        matches = np.concatenate([m for _, _, m in made])
+        kp_all = np.concatenate(frames)
+        wh = np.array([size] * 8, dtype=np.int32).reshape(-1)
+        if factor == 0.5:
+            c2 = pkg.GmsContext(0)
+        table = batch.FrameTable(c2, frames, [size] * 8)
+        failed, wout, wres, wmask = oracle.batch(kp_all, table.frame_off_host, wh, pairs, matches, True, True, 6.0, 4)
+        assert failed == 0
+        if factor == 0.5:
+            assert (wres["best_scale"] >= 2).all()
+        for _ in range(20):
+            out, res, mask = batch.filter_pairs(c2, table, pairs, matches, True, True)
+            assert res.tobytes() == wres.tobytes() and np.array_equal(mask, wmask)
+            for i in range(4):
+                o, k = i * n, int(res["n_inliers"][i])
+                assert out[o:o + k].tobytes() == wout[o:o + k].tobytes()
+    c2.close()
