@@ -272,7 +272,9 @@ __device__ __forceinline__ void hash_pair(const FilterParams& p, uint32_t* smem,
     // with scale hypotheses the byte-matrix kernel may have evaluated scales 0..2 already (see dense_scales_pair): its
     // record holds the best hypothesis so far, and this kernel continues with scale 3
     const uint32_t* __restrict__ part = p.partial ? p.partial + (size_t)pair_idx * kPartialStrideDw : nullptr;
-    const int scales_done = part != nullptr ? (int)part[0] : 0;  // workgroup-uniform: 0, or the 4 scales of the first kernel
+    const uint32_t part0 = part != nullptr ? part[0] : 0u;       // workgroup-uniform: 0, or what the first kernel decided:
+    const int scales_done = (int)(part0 & 15u);                  //   scales 0..3 (4) or all five (5: its probe bounded scale 4 out)
+    const bool probed4 = (part0 >> 4) != 0;                      //   "scale 4 was probed and cannot be bounded out"
     const bool resumed = scales_done != 0;
     for (int i = tid; i < (kMcap >> 5); i += NT) bestmask[i] = resumed ? part[kPartialHeaderDw + i] : 0u;
     for (int i = tid; i < kFineStride; i += NT) nfine[i] = 0;
@@ -309,6 +311,7 @@ __device__ __forceinline__ void hash_pair(const FilterParams& p, uint32_t* smem,
     }
     __syncthreads();
 
+    if (scales_done < n_scales) {  // (workgroup-uniform; otherwise everything is decided and only the copy-out is left)
     // ---- both sides of every match, scale 0: one 8-byte load of (queryIdx, trainIdx), two gathers.
     //      Loads are unconditional on clamped indices (so that all of a thread's loads are in flight
     //      together); validity is applied to the values afterwards.
@@ -448,7 +451,7 @@ __device__ __forceinline__ void hash_pair(const FilterParams& p, uint32_t* smem,
 
         // probe (see dense_scales_pair): pass 0 only bins and flags the matches that sit in their row's arg-max entry; when
         // their number does not exceed the best count so far the scale is skipped, else pass 1 evaluates it as always
-        const bool probing = ((p.probe_scales >> s) & 1) != 0 && best_count > 0;  // workgroup-uniform
+        const bool probing = ((p.probe_scales >> s) & 1) != 0 && best_count > 0 && !(s == 4 && probed4);  // workgroup-uniform
         bool skip_scale = false;
         for (int pass = probing ? 0 : 1; pass < 2 && !skip_scale; ++pass) {
         const bool probe = pass == 0;
@@ -737,6 +740,7 @@ __device__ __forceinline__ void hash_pair(const FilterParams& p, uint32_t* smem,
         __syncthreads();
         if (tid < 8) misc[tid] = 0;
         GMS_STAMP(7);  // count + select
+    }
     }
     __syncthreads();
 
@@ -1476,6 +1480,7 @@ __device__ __forceinline__ bool dense_scales_pair(const FilterParams& p, uint32_
         return false;
     constexpr uint32_t kSEMask = 0x3FFu;   // E(r) = nr + 3 - r needs 10 bits at 28 x 28 right cells (bits 8..17 of the code word)
     constexpr int kSAccShift = 18;         // rotation bits 18..25
+    constexpr int kSProbeBit = 26;         // PROBE: "sits in its row's arg-max entry under some grid type"
     const int64_t offA = p.frame_off[pr.frame_a], offB = p.frame_off[pr.frame_b];
     const int nA = (int)(p.frame_off[pr.frame_a + 1] - offA), nB = (int)(p.frame_off[pr.frame_b + 1] - offB);
     if (nA <= 0 || nB <= 0) return false;
@@ -1525,7 +1530,8 @@ __device__ __forceinline__ bool dense_scales_pair(const FilterParams& p, uint32_
     GMS_STAMP(4);  // records and frame B landed
     // code word as in dense_pair (E = E(r) of the current scale, 10 bits); cell1 = left cell under grid type 1; rs = the
     // right cells of scales 1, 2 and 3 (bits 0..7, 8..15, 16..25)
-    uint32_t code[KPT], aux[KPT];  // aux = left cell under grid type 1 : 9 | right cell on the 20 x 20 grid : 9 | on the 28 x 28 grid : 10
+    uint32_t code[KPT], aux[KPT];  // aux = left cell under grid type 1 : 9 | right cell on the 20 x 20 grid : 9 | on the 28 x 28 grid : 10 |
+                                   //       low bit of the 40 x 40 cell's x, y : 2 (the rest of it is twice the 20 x 20 cell's)
     {
         float2 a[KPT], b[KPT];
 #pragma unroll
@@ -1566,7 +1572,8 @@ __device__ __forceinline__ bool dense_scales_pair(const FilterParams& p, uint32_
             const uint32_t edge = ((hx + 25u) & kDEdgeX) | ((hy + 89u) & kDEdgeY);
             code[k] = binned ? (q | edge | ((403u - r[0]) << kDEShift)) : kDNever;
             // (the 10 x 10 and 14 x 14 cells follow from the 20 x 20 and 28 x 28 ones: fl(10 n) = fl(20 n) / 2 exactly, and 14 / 28 alike)
-            aux[k] = binned ? ((__umul24(hy >> 1, (uint32_t)kLeftW) + (hx >> 1)) | (r[0] << 9) | (r[3] << 18)) : 0u;
+            const uint32_t odd40 = ((uint32_t)(int)(40.0f * b[k].x) & 1u) | (((uint32_t)(int)(40.0f * b[k].y) & 1u) << 1);
+            aux[k] = binned ? ((__umul24(hy >> 1, (uint32_t)kLeftW) + (hx >> 1)) | (r[0] << 9) | (r[3] << 18) | (odd40 << 28)) : 0u;
         }
         if (any_bad) misc[8] = 1;
         if (spill) misc[13] = 1;  // (not misc[11]: that one is written again while slower waves may still be reading this)
@@ -1614,18 +1621,23 @@ __device__ __forceinline__ bool dense_scales_pair(const FilterParams& p, uint32_
         const uint32_t wr = (uint32_t)p.right_w[s], nr = wr * wr;
         const uint32_t stride = 4u + nr;                 // header dword + one byte per right cell
         const uint32_t wr_magic = 65535u / wr + 1u;      // j / wr == (j * magic) >> 16 for j * wr < 65536
+        // scale 4 (probe only): E(r) up to 1603 takes 11 bits and reaches into the rotation bits, which a probe does not use
+        const uint32_t emask = (PROBE && s == 4) ? 0x7FFu : kSEMask;
         if (s > 0) {
 #pragma unroll
             for (int k = 0; k < KPT; ++k) {
                 uint32_t r;
                 if (s == 3) {
-                    r = aux[k] >> 18;
+                    r = (aux[k] >> 18) & 0x3FFu;
+                } else if (s == 4) {  // double the 20 x 20 cell's coordinates and add the stored low bits: fl(40 n) = 2 fl(20 n) + bit
+                    const uint32_t c20 = (aux[k] >> 9) & 0x1FFu, cy = (c20 * 3277u) >> 16, cx = c20 - cy * 20u;
+                    r = (2u * cy + ((aux[k] >> 29) & 1u)) * 40u + 2u * cx + ((aux[k] >> 28) & 1u);
                 } else {  // halve the finer grid's cell coordinates: 20 -> 10 (s == 1), 28 -> 14 (s == 2)
-                    const uint32_t fine = s == 1 ? (aux[k] >> 9) & 0x1FFu : aux[k] >> 18, wf = s == 1 ? 20u : 28u;
+                    const uint32_t fine = s == 1 ? (aux[k] >> 9) & 0x1FFu : (aux[k] >> 18) & 0x3FFu, wf = s == 1 ? 20u : 28u;
                     const uint32_t fy = (fine * (s == 1 ? 3277u : 2341u)) >> 16, fx = fine - fy * wf;  // fine / wf for fine < 784
                     r = (fy >> 1) * (wf >> 1) + (fx >> 1);
                 }
-                if (!(code[k] & kDNever)) code[k] = (code[k] & ~(kSEMask << kDEShift)) | ((nr + 3u - r) << kDEShift);
+                if (!(code[k] & kDNever)) code[k] = (code[k] & ~(emask << kDEShift)) | ((nr + 3u - r) << kDEShift);
             }
         }
         int status = 0;
@@ -1648,15 +1660,18 @@ __device__ __forceinline__ bool dense_scales_pair(const FilterParams& p, uint32_
                     if ((cw & out_mask) == 0) atomicAdd(&nl32cur[l >> 1], 1u << ((l & 1u) << 4));
                 }
             }
-            constexpr int kBandRows = 8;
-            for (int band = 0; band < (BANDED ? (kLeftH + kBandRows - 1) / kBandRows : 1); ++band) {
-                const int lo = BANDED ? band * kBandRows : 0, hi = BANDED ? min(lo + kBandRows, kLeftH) : kLeftH;  // own rows
-                const int blo = BANDED ? max(lo - 1, 0) : 0, bhi = BANDED ? min(hi + 1, kLeftH) : kLeftH;          // rows held
+            // bands: 8 own rows + a halo row on either side (verify reads the neighbour rows); a probe needs no neighbours, so its
+            // bands are as many whole rows as fit: 10 at 28 x 28 right cells, 4 at 40 x 40 (below the best mask)
+            const int band_rows = PROBE ? (s == 4 ? 4 : 10) : 8, halo = PROBE ? 0 : 1;
+            const int n_bands = BANDED ? (kLeftH + band_rows - 1) / band_rows : 1;
+            for (int band = 0; band < n_bands; ++band) {
+                const int lo = BANDED ? band * band_rows : 0, hi = BANDED ? min(lo + band_rows, kLeftH) : kLeftH;      // own rows
+                const int blo = BANDED ? max(lo - halo, 0) : 0, bhi = BANDED ? min(hi + halo, kLeftH) : kLeftH;        // rows held
                 const uint32_t cell0 = (uint32_t)(blo * kLeftW), n_held = (uint32_t)((bhi - blo) * kLeftW);
                 const uint32_t own0 = (uint32_t)(lo * kLeftW), n_own = (uint32_t)((hi - lo) * kLeftW);
                 // arg-max keys carry (grid type, band) in their top bits: every binning pass outranks what the previous one
                 // left in the headers (a cellPairs word, below 2^19), so headers are never reset inside a scale
-                const uint32_t key_tag = (uint32_t)(BANDED ? g * 3 + band : g) << kDTagShift;
+                const uint32_t key_tag = (uint32_t)(BANDED ? g * n_bands + band : g) << kDTagShift;
 
                 // ---- assignMatchPairs
 #pragma unroll
@@ -1669,7 +1684,7 @@ __device__ __forceinline__ bool dense_scales_pair(const FilterParams& p, uint32_
                         const uint32_t l = (aux[k0 + c] & 0x1FFu) + (cw & q_mask) - cell0;
                         in[c] = (cw & out_mask) == 0 && (!BANDED || l < n_held);
                         row[c] = __umul24(l, stride);
-                        at[c] = row[c] + ((cw >> kDEShift) & kSEMask);
+                        at[c] = row[c] + ((cw >> kDEShift) & emask);
                         old[c] = 0;
                         if (in[c]) old[c] = atomicAdd(lds_at(smem, at[c] & ~3u), 1u << ((at[c] << 3) & 31u));
                     }
@@ -1678,7 +1693,7 @@ __device__ __forceinline__ bool dense_scales_pair(const FilterParams& p, uint32_
                     for (int c = 0; c < kChunk; ++c) {
                         const uint32_t before = (old[c] >> ((at[c] << 3) & 31u)) & 255u;
                         if (CROWDED && in[c] && before == 255u) misc[12] = 1;  // the entry's byte has just wrapped
-                        if (in[c]) atomicMax(lds_at(smem, row[c]), key_tag | (before << 11) | ((code[k0 + c] >> kDEShift) & kSEMask));
+                        if (in[c]) atomicMax(lds_at(smem, row[c]), key_tag | (before << 11) | ((code[k0 + c] >> kDEShift) & emask));
                     }
                 }
                 GMS_STAMP(3);  // insert
@@ -1788,14 +1803,14 @@ __device__ __forceinline__ bool dense_scales_pair(const FilterParams& p, uint32_
                         cr[k] = 0xFFFFFFFFu;
                         if ((cw & out_mask) == 0 && (!BANDED || l - cell0 < n_held)) {
                             if (!BANDED || l - own0 < n_own) cr[k] = smem[row >> 2];
-                            const uint32_t at = row + ((cw >> kDEShift) & kSEMask);
+                            const uint32_t at = row + ((cw >> kDEShift) & emask);
                             reinterpret_cast<uint8_t*>(smem)[at] = 0;  // (every reader of the entry is past the barrier: see dense_pair)
                         }
                     }
 #pragma unroll
                     for (int k = 0; k < KPT; ++k) {
                         if constexpr (PROBE) {  // the header still holds the arg-max key: [tag | count - 1 | E(j*)]; (a row not owned reads as E = 2047)
-                            if ((cr[k] & 0x7FFu) == ((code[k] >> kDEShift) & kSEMask)) code[k] |= 1u << kSAccShift;
+                            if ((cr[k] & 0x7FFu) == ((code[k] >> kDEShift) & emask)) code[k] |= 1u << kSProbeBit;
                         } else {
                             const uint32_t x = cr[k] ^ (code[k] & (kSEMask << kDEShift));
                             if (x < 256u) code[k] |= x << kSAccShift;
@@ -1810,17 +1825,17 @@ __device__ __forceinline__ bool dense_scales_pair(const FilterParams& p, uint32_
         if (status != 0) return status;
         // the next scale lays its rows out differently: no header of this one may survive as a count byte
         for (uint32_t c = tid; c < (uint32_t)kLeftN; c += NT)
-            if (!BANDED || c < 10u * kLeftW) smem[c * (stride >> 2)] = 0;
+            if (!BANDED || c < (uint32_t)((PROBE ? (s == 4 ? 4 : 10) : 10) * kLeftW)) smem[c * (stride >> 2)] = 0;
 
         if constexpr (PROBE) {  // ---- how many matches could be inliers at this scale at all
             uint32_t c0 = 0;
 #pragma unroll
-            for (int k = 0; k < KPT; ++k) c0 += (uint32_t)__popcll(__ballot((code[k] >> kSAccShift) & 1u));
+            for (int k = 0; k < KPT; ++k) c0 += (uint32_t)__popcll(__ballot((code[k] >> kSProbeBit) & 1u));
             if (lane == 0 && c0) atomicAdd(&misc[0], c0);
             __syncthreads();  // count complete; headers zeroed
             const uint32_t bound = misc[0];
 #pragma unroll
-            for (int k = 0; k < KPT; ++k) code[k] &= ~(0xFFu << kSAccShift);
+            for (int k = 0; k < KPT; ++k) code[k] &= ~(1u << kSProbeBit);
             __syncthreads();
             if (tid < 8) misc[tid] = 0;
             if (tid == 0 && p.probe_stats != nullptr) atomicAdd(&p.probe_stats[bound > best_count ? 0 : 1], 1u);
@@ -1883,9 +1898,11 @@ __device__ __forceinline__ bool dense_scales_pair(const FilterParams& p, uint32_
         return run_scale(banded_c, crowded_c, std::false_type{}, s);
     };
     int status = spilled ? 1 : 0;
+    bool crowded_mode = false;
     for (int s = 0; s < 3 && status == 0; ++s) status = eval_scale(std::false_type{}, std::false_type{}, s);
     if (status == 0) status = eval_scale(std::true_type{}, std::false_type{}, 3);
     if (status == 1) {
+        crowded_mode = true;
         // crowded (dense_pair has the same mode): everything again on a clean matrix, nLeft counted into 16-bit counters and
         // every returned entry count checked; the cell populations do not depend on the scale, so this shows at scale 0
         __syncthreads();
@@ -1905,14 +1922,25 @@ __device__ __forceinline__ bool dense_scales_pair(const FilterParams& p, uint32_
         for (int s = 0; s < 3 && status == 0; ++s) status = eval_scale(std::false_type{}, std::true_type{}, s);
         if (status == 0) status = eval_scale(std::true_type{}, std::true_type{}, 3);
     }
+    // Scale 4 (40 x 40: 400 rows of 1604 bytes) is the hashed kernel's to evaluate -- but its probe runs here, on five bands of the
+    // byte matrix: when it bounds the scale out, the record says all five scales are decided and the hashed kernel only copies out;
+    // when it does not, the record says so and the hashed kernel does not probe again.
+    uint32_t decided = 4u;
+    if (status == 0 && ((p.probe_scales >> 4) & 1) != 0 && best_count > 0 && p.right_w[4] == 40 && p.right_h[4] == 40) {
+        const int pr = crowded_mode ? run_scale(std::true_type{}, std::true_type{}, std::true_type{}, 4)
+                                    : run_scale(std::true_type{}, std::false_type{}, std::true_type{}, 4);
+        if (pr == 3) decided = 5u;
+        else if (pr == 0) decided = 4u | 16u;
+        else status = pr;
+    }
     if (status != 0) {
         __syncthreads();
         return false;
     }
     __syncthreads();
-    // the record the hashed kernel continues from: scales 0..3 are decided
+    // the record the hashed kernel continues from: scales 0..3 (or all five) are decided
     if (tid == 0) {
-        part[0] = 4u;
+        part[0] = decided;
         part[1] = best_count;
         part[2] = (uint32_t)best_scale;
         part[3] = (uint32_t)best_rot;
