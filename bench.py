@@ -364,10 +364,10 @@ def main():
             line["gpu_vs_cpu"] = value / line["cpu_baseline"]["value"]
         if not args.no_extra and world == 1:
             # the reference's SfM call-site flags on the head of the same chunks
-            n_sub = min(wl.n_pairs, 512)
+            n_sub = min(wl.n_pairs, 2048)
             w2, k2 = timed_steps(ctx, wl, stream, 8, 2, True, True, None, n_pairs=n_sub)
             used = sorted({(2 + s) % n_res for s in range(8)})
-            c2, b2 = check_parity(wl, pkg, used, True, True, sample={c: list(range(0, n_sub, 97)) for c in used})
+            c2, b2 = check_parity(wl, pkg, used, True, True, sample={c: list(range(0, n_sub, 389)) for c in used})
             kept2 = np.mean([int(wl.chunks[c]["d_res"][:n_sub, 0].sum().item()) for c in used])
             alg2 = 32.0 * n_kp * n_sub + 16.0 * kept2
             extra = {"workload": "head of the same chunks, matchGMS(withRotation=true, withScale=true, 6.0) "
