@@ -166,12 +166,11 @@ constexpr int kDCellShift = 18;                      // without rotation only, b
 // here, once per frame (a frame of a sequence is filtered against hundreds of others): two code words per keypoint.
 //   lcode  the keypoint as a LEFT point: the dense code word's left part (see kDNever .. kDCellShift below) -- half-cell parities
 //          q, the "x / y >= 20 under the shifted grid" edge bits, the cell under grid type 1 -- or kDNever when it is never binned;
-//   rcode  the keypoint as a RIGHT point: E(r) = 403 - r of scale 0 (0 = outside the 20 x 20 grid), its cell coordinates on the
-//          40 x 40 and 28 x 28 grids (fl(40 n) = 2 fl(20 n) and fl(20 n) = 2 fl(10 n) exactly, likewise 28 / 14: the five right
-//          grids of setScale are these two families; a coordinate at or above the field's grid size = outside that family's grids).
-// Bit 31 of either: the point is outside the parity domain (negative, non-finite or >= 2^20 after normalisation).
+//   rcode  the keypoint as a RIGHT point, 16 bits: E(r) = 403 - r of scale 0 (0 = outside the 20 x 20 grid).
+// Top bit of either: the point is outside the parity domain (negative, non-finite or >= 2^20 after normalisation).
 constexpr uint32_t kCodeBad = 1u << 31;
-__device__ __forceinline__ void keypoint_codes(float2 n, uint32_t& lcode, uint32_t& rcode)
+constexpr uint32_t kRCodeBad = 1u << 15;
+__device__ __forceinline__ void keypoint_codes(float2 n, uint32_t& lcode, uint16_t& rcode)
 {
     const bool bad = max(__float_as_uint(n.x), __float_as_uint(n.y)) >= 0x49800000u;
     const float x = bad ? 0.0f : n.x, y = bad ? 0.0f : n.y;
@@ -183,9 +182,7 @@ __device__ __forceinline__ void keypoint_codes(float2 n, uint32_t& lcode, uint32
     lcode = (max(hx, hy) < 40u ? (q | edge | (l1 << kDCellShift)) : kDNever) | (bad ? kCodeBad : 0u);
     const uint32_t r0x = (uint32_t)(int)fx, r0y = (uint32_t)(int)fy;              // getGridIndexRight, 20 x 20 (DLL@0x180047d60)
     const uint32_t e0 = (r0x < 20u && r0y < 20u) ? 403u - (r0y * 20u + r0x) : 0u;
-    const uint32_t r4x = min((uint32_t)(int)(40.0f * x), 63u), r4y = min((uint32_t)(int)(40.0f * y), 63u);
-    const uint32_t r3x = min((uint32_t)(int)(28.0f * x), 31u), r3y = min((uint32_t)(int)(28.0f * y), 31u);
-    rcode = e0 | (r4x << 9) | (r4y << 15) | (r3x << 21) | (r3y << 26) | (bad ? kCodeBad : 0u);
+    rcode = (uint16_t)(e0 | (bad ? kRCodeBad : 0u));
 }
 
 __global__ void __launch_bounds__(256)
@@ -193,7 +190,7 @@ normalize_kernel(const char* __restrict__ kp, int kp_stride, const int64_t* __re
                  const int32_t* __restrict__ wh, int n_frames, int64_t total, float2* __restrict__ pts)
 {
     uint32_t* __restrict__ lcode = reinterpret_cast<uint32_t*>(pts + total);
-    uint32_t* __restrict__ rcode = lcode + total;
+    uint16_t* __restrict__ rcode = reinterpret_cast<uint16_t*>(lcode + total);
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (; i < total; i += stride) {
@@ -208,7 +205,8 @@ normalize_kernel(const char* __restrict__ kp, int kp_stride, const int64_t* __re
         o.x = p[0] / w + 0.0f;  // IEEE fp32 divide (divss)
         o.y = p[1] / h + 0.0f;
         pts[i] = o;
-        uint32_t lc, rc;
+        uint32_t lc;
+        uint16_t rc;
         keypoint_codes(o, lc, rc);
         lcode[i] = lc;
         rcode[i] = rc;
@@ -943,7 +941,7 @@ __device__ __forceinline__ bool dense_pair(const FilterParams& p, uint32_t* smem
     // the frame table's code words (written by normalize_kernel behind the points): frame A's left codes, frame B's right codes
     const int64_t total_kp = p.frame_off[p.n_frames];
     const uint32_t* __restrict__ lcodeA = reinterpret_cast<const uint32_t*>(p.pts + total_kp) + offA;
-    const uint32_t* __restrict__ rcodeB = reinterpret_cast<const uint32_t*>(p.pts + total_kp) + total_kp + offB;
+    const uint16_t* __restrict__ rcodeB = reinterpret_cast<const uint16_t*>(reinterpret_cast<const uint32_t*>(p.pts + total_kp) + total_kp) + offB;
 
     const uint8_t* dense8 = reinterpret_cast<const uint8_t*>(smem);
     uint32_t* nfine32 = smem + kDenseFineOff / 4;   // half-cell histogram: one dword per cell of grid type 1, a byte per half cell
@@ -964,12 +962,12 @@ __device__ __forceinline__ bool dense_pair(const FilterParams& p, uint32_t* smem
     //      a frame starts anywhere in the table, so the copy keeps the source's phase and look-ups add it), then the pair's DMatch
     //      records, whole (they stay in registers until copy-out). Loads return in order: the staged codes are complete -- and the
     //      barrier passed -- while the later records are still on their way.
-    const uint32_t phA = (uint32_t)(reinterpret_cast<uintptr_t>(lcodeA) >> 2) & 3u, phB = (uint32_t)(reinterpret_cast<uintptr_t>(rcodeB) >> 2) & 3u;
-    const uint32_t qA = (phA + (uint32_t)nA + 3u) >> 2, qB = (phB + (uint32_t)nB + 3u) >> 2;  // uint4s of either copy
-    const bool staged = (qA + qB) * 16u <= kDenseBytes;  // workgroup-uniform: both fit (20 200 keypoints a frame, say)
+    const uint32_t phA = (uint32_t)(reinterpret_cast<uintptr_t>(lcodeA) >> 2) & 3u, phB = (uint32_t)(reinterpret_cast<uintptr_t>(rcodeB) >> 1) & 7u;
+    const uint32_t qA = (phA + (uint32_t)nA + 3u) >> 2, qB = (phB + (uint32_t)nB + 7u) >> 3;  // uint4s of either copy (4 / 8 codes each)
+    const bool staged = (qA + qB) * 16u <= kDenseBytes;  // workgroup-uniform: both fit (26 900 keypoints a frame, say)
     const uint4* __restrict__ srcA = reinterpret_cast<const uint4*>(lcodeA - phA);
     const uint4* __restrict__ srcB = reinterpret_cast<const uint4*>(rcodeB - phB);
-    constexpr int kStageRegs = 5;  // 20 480 code words through registers; larger frames finish in a plain loop
+    constexpr int kStageRegs = 4;  // 64 KB of codes (10 900 keypoints a frame) through registers; larger frames finish in a plain loop
     uint4 tb[kStageRegs];
 #pragma unroll
     for (int i = 0; i < kStageRegs; ++i) {  // (unconditional: a pair too large to stage just reads a few code words it does not use)
@@ -1005,7 +1003,7 @@ __device__ __forceinline__ bool dense_pair(const FilterParams& p, uint32_t* smem
         for (uint32_t j = kStageRegs * NT + tid; j < qA + qB; j += NT) d4[j] = *(j < qA ? srcA + j : srcB + (j - qA));
     }
     const uint32_t* ldsA = smem + phA;            // left code of frame A's keypoint q at ldsA[q]
-    const uint32_t* ldsB = smem + 4u * qA + phB;  // right code of frame B's keypoint t at ldsB[t]
+    const uint16_t* ldsB = reinterpret_cast<const uint16_t*>(smem + 4u * qA) + phB;  // right code of frame B's keypoint t at ldsB[t]
     __syncthreads();
 #ifdef GMS_PHASE_TIMING
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1044,7 +1042,7 @@ __device__ __forceinline__ bool dense_pair(const FilterParams& p, uint32_t* smem
             const bool live = match_of(k) < m;
             const uint32_t e0 = cb[k] & kDEMask;  // E(r) of getGridIndexRight on the 20 x 20 grid, 0 = outside it (no bounds test in the reference)
             // parity domain: indices in range, both points inside it, the right cell inside its grid ('&', not '&&': no branches)
-            const bool ok = ((int)(query_of(k) < (uint32_t)nA) & (int)(train_of(k) < (uint32_t)nB) & (int)(((ca[k] | cb[k]) & kCodeBad) == 0u) & (int)(e0 != 0u)) != 0;
+            const bool ok = ((int)(query_of(k) < (uint32_t)nA) & (int)(train_of(k) < (uint32_t)nB) & (int)(((ca[k] & kCodeBad) | (cb[k] & kRCodeBad)) == 0u) & (int)(e0 != 0u)) != 0;
             const bool binned = live & ok & ((ca[k] & kDNever) == 0u);
             // half-cell histogram: dword = the cell under grid type 1, byte = (hx & 1) + 2 (hy & 1); q = (hx & 1) + 20 (hy & 1)
             const uint32_t cell = (ca[k] >> kDCellShift) & 0x1FFu, sh = ((ca[k] & 1u) << 3) | ((ca[k] & 4u) << 2);
