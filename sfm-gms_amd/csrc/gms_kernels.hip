@@ -163,23 +163,25 @@ constexpr int kDCellShift = 18;                      // without rotation only, b
                                                      // (with rotation it has a register of its own, as a row offset)
 
 // Besides the normalised point, everything about a keypoint that does not depend on the pair it is matched in is worked out
-// here, once per frame (a frame of a sequence is filtered against hundreds of others): two code words per keypoint.
-//   lcode  the keypoint as a LEFT point: the dense code word's left part (see kDNever .. kDCellShift below) -- half-cell parities
-//          q, the "x / y >= 20 under the shifted grid" edge bits, the cell under grid type 1 -- or kDNever when it is never binned;
-//   rcode  the keypoint as a RIGHT point, 16 bits: E(r) = 403 - r of scale 0 (0 = outside the 20 x 20 grid).
-// Top bit of either: the point is outside the parity domain (negative, non-finite or >= 2^20 after normalisation).
-constexpr uint32_t kCodeBad = 1u << 31;
+// here, once per frame (a frame of a sequence is filtered against hundreds of others): two 16-bit codes per keypoint.
+//   lcode  the keypoint as a LEFT point: [q : 5 | x >= 20 under the x-shifted grid types : 1 | y likewise : 1 | cell under grid
+//          type 1 : 9] -- q and the edge bits are the low bits of the dense code word as they stand (kDEdgeX / kDEdgeY one place
+//          up). Cell values above the grid: kLCellNever (the point is binned under no grid type), kLCellBad (outside the parity
+//          domain: negative, non-finite or >= 2^20 after normalisation);
+//   rcode  the keypoint as a RIGHT point: E(r) = 403 - r of scale 0 (0 = outside the 20 x 20 grid); top bit: outside the domain.
+constexpr uint32_t kLCellShift = 7, kLCellNever = 510u, kLCellBad = 511u;
 constexpr uint32_t kRCodeBad = 1u << 15;
-__device__ __forceinline__ void keypoint_codes(float2 n, uint32_t& lcode, uint16_t& rcode)
+__device__ __forceinline__ void keypoint_codes(float2 n, uint16_t& lcode, uint16_t& rcode)
 {
     const bool bad = max(__float_as_uint(n.x), __float_as_uint(n.y)) >= 0x49800000u;
     const float x = bad ? 0.0f : n.x, y = bad ? 0.0f : n.y;
     const float fx = 20.0f * x, fy = 20.0f * y;                                  // mulss, rounded to fp32 (DLL@0x180047bc0)
     const uint32_t hx = (uint32_t)(int)(fx + fx), hy = (uint32_t)(int)(fy + fy);  // floor(2 f): carries all four grid types
     const uint32_t q = (hx & 1u) + 20u * (hy & 1u);
-    const uint32_t edge = (hx == 39u ? kDEdgeX : 0u) | (hy == 39u ? kDEdgeY : 0u);
+    const uint32_t edge = (hx == 39u ? 1u << 5 : 0u) | (hy == 39u ? 1u << 6 : 0u);
     const uint32_t l1 = (hy >> 1) * (uint32_t)kLeftW + (hx >> 1);
-    lcode = (max(hx, hy) < 40u ? (q | edge | (l1 << kDCellShift)) : kDNever) | (bad ? kCodeBad : 0u);
+    const bool never = max(hx, hy) >= 40u;
+    lcode = (uint16_t)(bad ? kLCellBad << kLCellShift : (never ? kLCellNever << kLCellShift : (q | edge | (l1 << kLCellShift))));
     const uint32_t r0x = (uint32_t)(int)fx, r0y = (uint32_t)(int)fy;              // getGridIndexRight, 20 x 20 (DLL@0x180047d60)
     const uint32_t e0 = (r0x < 20u && r0y < 20u) ? 403u - (r0y * 20u + r0x) : 0u;
     rcode = (uint16_t)(e0 | (bad ? kRCodeBad : 0u));
@@ -189,8 +191,8 @@ __global__ void __launch_bounds__(256)
 normalize_kernel(const char* __restrict__ kp, int kp_stride, const int64_t* __restrict__ frame_off,
                  const int32_t* __restrict__ wh, int n_frames, int64_t total, float2* __restrict__ pts)
 {
-    uint32_t* __restrict__ lcode = reinterpret_cast<uint32_t*>(pts + total);
-    uint16_t* __restrict__ rcode = reinterpret_cast<uint16_t*>(lcode + total);
+    uint16_t* __restrict__ lcode = reinterpret_cast<uint16_t*>(pts + total);
+    uint16_t* __restrict__ rcode = lcode + total;
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (; i < total; i += stride) {
@@ -205,8 +207,7 @@ normalize_kernel(const char* __restrict__ kp, int kp_stride, const int64_t* __re
         o.x = p[0] / w + 0.0f;  // IEEE fp32 divide (divss)
         o.y = p[1] / h + 0.0f;
         pts[i] = o;
-        uint32_t lc;
-        uint16_t rc;
+        uint16_t lc, rc;
         keypoint_codes(o, lc, rc);
         lcode[i] = lc;
         rcode[i] = rc;
@@ -940,8 +941,8 @@ __device__ __forceinline__ bool dense_pair(const FilterParams& p, uint32_t* smem
     const gms_dmatch* __restrict__ matches = p.matches + pr.match_off;
     // the frame table's code words (written by normalize_kernel behind the points): frame A's left codes, frame B's right codes
     const int64_t total_kp = p.frame_off[p.n_frames];
-    const uint32_t* __restrict__ lcodeA = reinterpret_cast<const uint32_t*>(p.pts + total_kp) + offA;
-    const uint16_t* __restrict__ rcodeB = reinterpret_cast<const uint16_t*>(reinterpret_cast<const uint32_t*>(p.pts + total_kp) + total_kp) + offB;
+    const uint16_t* __restrict__ lcodeA = reinterpret_cast<const uint16_t*>(p.pts + total_kp) + offA;
+    const uint16_t* __restrict__ rcodeB = reinterpret_cast<const uint16_t*>(p.pts + total_kp) + total_kp + offB;
 
     const uint8_t* dense8 = reinterpret_cast<const uint8_t*>(smem);
     uint32_t* nfine32 = smem + kDenseFineOff / 4;   // half-cell histogram: one dword per cell of grid type 1, a byte per half cell
@@ -962,12 +963,12 @@ __device__ __forceinline__ bool dense_pair(const FilterParams& p, uint32_t* smem
     //      a frame starts anywhere in the table, so the copy keeps the source's phase and look-ups add it), then the pair's DMatch
     //      records, whole (they stay in registers until copy-out). Loads return in order: the staged codes are complete -- and the
     //      barrier passed -- while the later records are still on their way.
-    const uint32_t phA = (uint32_t)(reinterpret_cast<uintptr_t>(lcodeA) >> 2) & 3u, phB = (uint32_t)(reinterpret_cast<uintptr_t>(rcodeB) >> 1) & 7u;
-    const uint32_t qA = (phA + (uint32_t)nA + 3u) >> 2, qB = (phB + (uint32_t)nB + 7u) >> 3;  // uint4s of either copy (4 / 8 codes each)
-    const bool staged = (qA + qB) * 16u <= kDenseBytes;  // workgroup-uniform: both fit (26 900 keypoints a frame, say)
+    const uint32_t phA = (uint32_t)(reinterpret_cast<uintptr_t>(lcodeA) >> 1) & 7u, phB = (uint32_t)(reinterpret_cast<uintptr_t>(rcodeB) >> 1) & 7u;
+    const uint32_t qA = (phA + (uint32_t)nA + 7u) >> 3, qB = (phB + (uint32_t)nB + 7u) >> 3;  // uint4s of either copy (8 codes each)
+    const bool staged = (qA + qB) * 16u <= kDenseBytes;  // workgroup-uniform: both fit (40 400 keypoints a frame, say)
     const uint4* __restrict__ srcA = reinterpret_cast<const uint4*>(lcodeA - phA);
     const uint4* __restrict__ srcB = reinterpret_cast<const uint4*>(rcodeB - phB);
-    constexpr int kStageRegs = 4;  // 64 KB of codes (10 900 keypoints a frame) through registers; larger frames finish in a plain loop
+    constexpr int kStageRegs = 3;  // 48 KB of codes (12 288 keypoints a frame) through registers; larger frames finish in a plain loop
     uint4 tb[kStageRegs];
 #pragma unroll
     for (int i = 0; i < kStageRegs; ++i) {  // (unconditional: a pair too large to stage just reads a few code words it does not use)
@@ -1002,7 +1003,7 @@ __device__ __forceinline__ bool dense_pair(const FilterParams& p, uint32_t* smem
             if ((uint32_t)(i * NT + tid) < qA + qB) d4[i * NT + tid] = tb[i];
         for (uint32_t j = kStageRegs * NT + tid; j < qA + qB; j += NT) d4[j] = *(j < qA ? srcA + j : srcB + (j - qA));
     }
-    const uint32_t* ldsA = smem + phA;            // left code of frame A's keypoint q at ldsA[q]
+    const uint16_t* ldsA = reinterpret_cast<const uint16_t*>(smem) + phA;  // left code of frame A's keypoint q at ldsA[q]
     const uint16_t* ldsB = reinterpret_cast<const uint16_t*>(smem + 4u * qA) + phB;  // right code of frame B's keypoint t at ldsB[t]
     __syncthreads();
 #ifdef GMS_PHASE_TIMING
@@ -1042,14 +1043,16 @@ __device__ __forceinline__ bool dense_pair(const FilterParams& p, uint32_t* smem
             const bool live = match_of(k) < m;
             const uint32_t e0 = cb[k] & kDEMask;  // E(r) of getGridIndexRight on the 20 x 20 grid, 0 = outside it (no bounds test in the reference)
             // parity domain: indices in range, both points inside it, the right cell inside its grid ('&', not '&&': no branches)
-            const bool ok = ((int)(query_of(k) < (uint32_t)nA) & (int)(train_of(k) < (uint32_t)nB) & (int)(((ca[k] & kCodeBad) | (cb[k] & kRCodeBad)) == 0u) & (int)(e0 != 0u)) != 0;
-            const bool binned = live & ok & ((ca[k] & kDNever) == 0u);
+            const uint32_t cell = ca[k] >> kLCellShift;  // under grid type 1; kLCellNever / kLCellBad above the grid
+            const bool ok = ((int)(query_of(k) < (uint32_t)nA) & (int)(train_of(k) < (uint32_t)nB) & (int)(cell != kLCellBad) & (int)((cb[k] & kRCodeBad) == 0u) & (int)(e0 != 0u)) != 0;
+            const bool binned = live & ok & (cell < kLCellNever);
             // half-cell histogram: dword = the cell under grid type 1, byte = (hx & 1) + 2 (hy & 1); q = (hx & 1) + 20 (hy & 1)
-            const uint32_t cell = (ca[k] >> kDCellShift) & 0x1FFu, sh = ((ca[k] & 1u) << 3) | ((ca[k] & 4u) << 2);
+            const uint32_t sh = ((ca[k] & 1u) << 3) | ((ca[k] & 4u) << 2);
             const uint32_t old = atomicAdd(binned ? &nfine32[cell] : &trash[lane & 7], 1u << sh);
             spill |= binned & (((old >> sh) & 255u) == 255u);  // the byte wrapped: > 255 in one half cell
             any_bad |= live & !ok;
-            const uint32_t cw = (ca[k] & (0xFFu | (kPackCell ? 0x1FFu << kDCellShift : 0u))) | (e0 << kDEShift);
+            // the dense code word: q as it stands, the edge bits one place up, E(r), and (without rotation) the cell
+            const uint32_t cw = (ca[k] & 31u) | ((ca[k] & 0x60u) << 1) | (e0 << kDEShift) | (kPackCell ? cell << kDCellShift : 0u);
             code[k] = binned ? cw : kDNever;
             if (!kPackCell) row1[k] = binned ? __umul24(cell, kDenseRow) : 0u;
         }
@@ -1427,11 +1430,11 @@ order_probe_kernel(FilterParams p, uint32_t* __restrict__ flag)
     if (pr.m >= 128 && pr.frame_a >= 0 && pr.frame_a < p.n_frames) {
         const int64_t offA = p.frame_off[pr.frame_a];
         const int nA = (int)(p.frame_off[pr.frame_a + 1] - offA);
-        const uint32_t* __restrict__ lcode = reinterpret_cast<const uint32_t*>(p.pts + p.frame_off[p.n_frames]) + offA;
+        const uint16_t* __restrict__ lcode = reinterpret_cast<const uint16_t*>(p.pts + p.frame_off[p.n_frames]) + offA;
         const int start = (pr.m >> 1) & ~63;
         const uint32_t q = (uint32_t)p.matches[pr.match_off + start + lane].queryIdx;
-        const uint32_t lc = nA > 0 ? lcode[min(q, (uint32_t)(nA - 1))] : kDNever;
-        const uint32_t cell = (lc & kDNever) ? 0x10000u + (uint32_t)lane : (lc >> kDCellShift) & 0x1FFu;  // never binned: equals nobody
+        const uint32_t lc = nA > 0 ? (uint32_t)lcode[min(q, (uint32_t)(nA - 1))] >> kLCellShift : kLCellNever;
+        const uint32_t cell = lc >= kLCellNever ? 0x10000u + (uint32_t)lane : lc;  // never binned: equals nobody
         const uint32_t next = (uint32_t)__shfl_down((int)cell, 1);
         const unsigned long long same = __ballot(lane < 63 && cell == next);
         if (lane == 0) {
