@@ -164,11 +164,11 @@ int gms_filter_host_batch(gms_ctx* ctx, const gms_keypoint* kp, const int64_t* f
  * one match per query row -- {queryIdx = i, trainIdx = first minimum over the train rows, imgIdx = 0, distance} for
  * i < min(d_pairs[p].m, n(frame_a)) -- written at d_matches[match_off + i]: the array gms_filter_device reads next.
  *   GMS_DESC_HAMMING256    rows of 32 bytes (ORB), NORM_HAMMING, distance = popcount as float. With a prepared block the
- *                          cross term runs on the matrix cores (int8 MFMA over the bits); with d_prepared = NULL on the
- *                          vector ALUs straight from the raw rows. Same results.
+ *                          cross term runs on the matrix cores (the bits as FP4 elements, exact); with d_prepared = NULL on
+ *                          the vector ALUs straight from the raw rows. Same results.
  *   GMS_DESC_L2_F32X128    rows of 128 floats (SIFT), NORM_L2, distance = sqrtf(sum of squared differences in fp32); needs
  *                          the prepared block. Frames whose values are all integers 0..255 (what SIFT emits) run on the
- *                          matrix cores with exact arithmetic; any other frame is matched by the reference's fp32 loop.
+ *                          matrix cores (as int8, exact arithmetic); any other frame is matched by the reference's fp32 loop.
  * gms_bf_prepare_device builds the per-frame tables (gms_bf_prepared_bytes bytes, caller-allocated) once per frame table.
  * Stream-ordered on the context's stream, no allocation, no synchronisation. A frame may hold at most 2^22 rows. */
 #define GMS_DESC_NONE      (-1)
