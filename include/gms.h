@@ -222,6 +222,22 @@ int gms_triangulate_device(gms_ctx* ctx, const double camera[4], const double di
                            const float* d_coords1, const float* d_coords2, const int32_t* d_n_matches, int max_matches,
                            double* d_points3d, gms_triangulation_stats* d_stats);
 
+/* gms_recover_pose_device: cv::recoverPose(E, points1, points2, cameraMatrix, R, t, mask) as SfMUtil.cpp:45 calls it (OpenCV 4.5.2:
+ * distance threshold 50) for the gathered points: the four (R, t) the essential matrix decomposes into, each tried on every
+ * correspondence by triangulation in normalised coordinates (positive depth below the threshold in both cameras); the first of
+ * (R1, t), (R2, t), (R1, -t), (R2, -t) with the most such points wins. E (3 x 3 row-major) and camera = (fx, fy, cx, cy) are HOST
+ * pointers; d_in_mask (optional: findEssentialMat's inlier mask, non-zero = use) and everything else device pointers.
+ * *d_pose receives R, t, the winner's point count and its index; d_out_mask (optional) 255 / 0 per correspondence.
+ * Stream-ordered; the context keeps the max_matches + 40 bytes of scratch. fp64, agrees with OpenCV to rounding (R1 / R2 and the
+ * sign of t may be numbered differently than by another SVD: `which` is informational). */
+typedef struct gms_pose {
+    double  R[9], t[3];
+    int32_t n_good, which;
+} gms_pose;
+int gms_recover_pose_device(gms_ctx* ctx, const double E[9], const double camera[4], const float* d_coords1, const float* d_coords2,
+                            const int32_t* d_n_matches, int max_matches, const uint8_t* d_in_mask, gms_pose* d_pose,
+                            uint8_t* d_out_mask);
+
 /* ---- ingest format -----------------------------------------------------------------------------------------
  * The reference keeps detector and matcher output in process (std::vector<cv::KeyPoint>, cv::Mat descriptors,
  * std::vector<cv::DMatch>: FeatureMatchUtil.cpp:9-12,58-68; DisparityUtil.cpp:108,137-143) and has no on-disk form. One

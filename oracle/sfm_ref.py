@@ -1,5 +1,6 @@
 """oracle/sfm_ref.py -- TEST INFRASTRUCTURE, NOT PRODUCT. numpy (fp64) restatement of the tail of the reference's two-view pipeline,
-SfM-GMS/SfM-GMS/SfMUtil.cpp:76-82 and 128-143: cv::undistortPoints -> cv::triangulatePoints -> division by the fourth coordinate.
+SfM-GMS/SfM-GMS/SfMUtil.cpp:45 (cv::recoverPose), 76-82 and 128-143: cv::undistortPoints -> cv::triangulatePoints -> division by the
+fourth coordinate.
 undistortPoints and triangulatePoints live in opencv_world452 (calib3d), which the reference vendors as a Windows import library
 only: parity unpinned; restated from the published algorithms (five fixed-point iterations of the distortion model; per point the
 right singular vector of the smallest singular value of the 4 x 4 DLT matrix). Floating point: compared at a stated tolerance."""
@@ -40,3 +41,51 @@ def reprojection_sums(P1, P2, xy1, xy2, pts):
     e1 = ((a[:, :2] / a[:, 2:3] - xy1) ** 2).sum(axis=1)
     e2 = ((b[:, :2] / b[:, 2:3] - xy2) ** 2).sum(axis=1)
     return float(e1.sum()), float(e2.sum()), int(((a[:, 2] <= 0) | (b[:, 2] <= 0)).sum())
+
+
+def decompose_essential(E):
+    """cv::decomposeEssentialMat: (R1, R2, t) with det U = det Vt = +1, W = [0 1 0; -1 0 0; 0 0 1]."""
+    U, _, Vt = np.linalg.svd(np.asarray(E, dtype=np.float64).reshape(3, 3))
+    if np.linalg.det(U) < 0:
+        U = -U
+    if np.linalg.det(Vt) < 0:
+        Vt = -Vt
+    W = np.array([[0.0, 1.0, 0.0], [-1.0, 0.0, 0.0], [0.0, 0.0, 1.0]])
+    return U @ W @ Vt, U @ W.T @ Vt, U[:, 2].copy()
+
+
+def recover_pose(E, uv1, uv2, camera, in_mask=None, dist_thresh=50.0):
+    """cv::recoverPose(E, points1, points2, cameraMatrix, R, t, mask) of OpenCV 4.5.2 (SfMUtil.cpp:45): returns
+    (R, t, n_good, mask uint8 255 / 0). Points are normalised with the camera matrix only; each of the four candidate poses is
+    tried by triangulation (positive depth below dist_thresh in both cameras); the first with the most points wins."""
+    fx, fy, cx, cy = camera
+    uv1, uv2 = np.asarray(uv1, dtype=np.float64), np.asarray(uv2, dtype=np.float64)
+    x1 = np.stack([(uv1[:, 0] - cx) / fx, (uv1[:, 1] - cy) / fy], axis=1)
+    x2 = np.stack([(uv2[:, 0] - cx) / fx, (uv2[:, 1] - cy) / fy], axis=1)
+    R1, R2, t = decompose_essential(E)
+    P0 = np.hstack([np.eye(3), np.zeros((3, 1))])
+    masks, poses = [], [(R1, t), (R2, t), (R1, -t), (R2, -t)]
+    for R, tt in poses:
+        P = np.hstack([R, tt.reshape(3, 1)])
+        m = np.zeros(len(x1), dtype=bool)
+        for i in range(len(x1)):
+            A = np.stack([x1[i, 0] * P0[2] - P0[0], x1[i, 1] * P0[2] - P0[1], x2[i, 0] * P[2] - P[0], x2[i, 1] * P[2] - P[1]])
+            Q = np.linalg.svd(A)[2][3]
+            ok = Q[2] * Q[3] > 0
+            q = Q[:3] / Q[3]
+            ok = ok and q[2] < dist_thresh
+            z2 = P[2, :3] @ q + P[2, 3]
+            m[i] = ok and 0 < z2 < dist_thresh
+        if in_mask is not None:
+            m &= np.asarray(in_mask) != 0
+        masks.append(m)
+    good = [int(m.sum()) for m in masks]
+    if good[0] >= good[1] and good[0] >= good[2] and good[0] >= good[3]:
+        w = 0
+    elif good[1] >= good[0] and good[1] >= good[2] and good[1] >= good[3]:
+        w = 1
+    elif good[2] >= good[0] and good[2] >= good[1] and good[2] >= good[3]:
+        w = 2
+    else:
+        w = 3
+    return poses[w][0], poses[w][1], good[w], (masks[w] * 255).astype(np.uint8)

@@ -163,6 +163,13 @@ class GmsContext:
                                                 p2.ctypes.data, d_coords1, d_coords2, d_n_matches, int(max_matches), d_points3d,
                                                 d_stats), self._lib, "gms_triangulate_device")
 
+    def recover_pose_device(self, E, camera, d_coords1, d_coords2, d_n_matches, max_matches, d_in_mask, d_pose, d_out_mask):
+        """gms_recover_pose_device: E 3 x 3 and camera = (fx, fy, cx, cy) are host values; d_pose receives a POSE_DTYPE record."""
+        e = np.ascontiguousarray(E, dtype=np.float64).reshape(9)
+        cam = np.ascontiguousarray(camera, dtype=np.float64).reshape(4)
+        _check(self._lib.gms_recover_pose_device(self._h, e.ctypes.data, cam.ctypes.data, d_coords1, d_coords2, d_n_matches,
+                                                 int(max_matches), d_in_mask, d_pose, d_out_mask), self._lib, "gms_recover_pose_device")
+
     def selftest_threshold(self, T, n, score, factor):
         T = np.ascontiguousarray(T, dtype=np.int32)
         n = np.ascontiguousarray(n, dtype=np.int32)

@@ -133,6 +133,68 @@ __device__ inline void undistort_point(const CameraModel& c, double u, double v,
     yo = y;
 }
 
+// cv::triangulatePoints for one correspondence: the homogeneous X with x1 ~ Pa X, x2 ~ Pb X -- the right singular vector of the
+// smallest singular value of the 4 x 4 DLT matrix, as the eigenvector of the smallest eigenvalue of A^T A (cyclic Jacobi, fp64).
+__device__ inline void dlt_point(const double* Pa, const double* Pb, double x1, double y1, double x2, double y2, double X[4])
+{
+    double A[4][4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        A[0][k] = x1 * Pa[8 + k] - Pa[k];
+        A[1][k] = y1 * Pa[8 + k] - Pa[4 + k];
+        A[2][k] = x2 * Pb[8 + k] - Pb[k];
+        A[3][k] = y2 * Pb[8 + k] - Pb[4 + k];
+    }
+    double S[4][4], V[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            S[a][b] = A[0][a] * A[0][b] + A[1][a] * A[1][b] + A[2][a] * A[2][b] + A[3][a] * A[3][b];
+            V[a][b] = a == b ? 1.0 : 0.0;
+        }
+    for (int sweep = 0; sweep < 12; ++sweep) {
+        double off = 0.0;
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = a + 1; b < 4; ++b) off += S[a][b] * S[a][b];
+        if (off < 1e-300) break;
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int q = p + 1; q < 4; ++q) {
+                if (S[p][q] == 0.0) continue;
+                const double theta = (S[q][q] - S[p][p]) / (2.0 * S[p][q]);
+                const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                const double cs = 1.0 / sqrt(t * t + 1.0), sn = t * cs;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {  // S <- S J (columns p, q)
+                    const double skp = S[k][p], skq = S[k][q];
+                    S[k][p] = cs * skp - sn * skq;
+                    S[k][q] = sn * skp + cs * skq;
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {  // S <- J^T S (rows p, q)
+                    const double spk = S[p][k], sqk = S[q][k];
+                    S[p][k] = cs * spk - sn * sqk;
+                    S[q][k] = sn * spk + cs * sqk;
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const double vkp = V[k][p], vkq = V[k][q];
+                    V[k][p] = cs * vkp - sn * vkq;
+                    V[k][q] = sn * vkp + cs * vkq;
+                }
+            }
+    }
+    int best = 0;
+#pragma unroll
+    for (int k = 1; k < 4; ++k) best = S[k][k] < S[best][best] ? k : best;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) X[k] = best == 0 ? V[k][0] : best == 1 ? V[k][1] : best == 2 ? V[k][2] : V[k][3];
+}
+
 __global__ void __launch_bounds__(256)
 triangulate_kernel(CameraModel cam, const float2* __restrict__ coords1, const float2* __restrict__ coords2,
                    const int32_t* __restrict__ n_matches, int cap, double* __restrict__ points3d, gms_triangulation_stats* __restrict__ stats)
@@ -145,63 +207,8 @@ triangulate_kernel(CameraModel cam, const float2* __restrict__ coords1, const fl
         double x1, y1, x2, y2;
         undistort_point(cam, (double)coords1[i].x, (double)coords1[i].y, x1, y1);
         undistort_point(cam, (double)coords2[i].x, (double)coords2[i].y, x2, y2);
-        double A[4][4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            A[0][k] = x1 * cam.P1[8 + k] - cam.P1[k];
-            A[1][k] = y1 * cam.P1[8 + k] - cam.P1[4 + k];
-            A[2][k] = x2 * cam.P2[8 + k] - cam.P2[k];
-            A[3][k] = y2 * cam.P2[8 + k] - cam.P2[4 + k];
-        }
-        double S[4][4], V[4][4];
-#pragma unroll
-        for (int a = 0; a < 4; ++a)
-#pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                S[a][b] = A[0][a] * A[0][b] + A[1][a] * A[1][b] + A[2][a] * A[2][b] + A[3][a] * A[3][b];
-                V[a][b] = a == b ? 1.0 : 0.0;
-            }
-        for (int sweep = 0; sweep < 12; ++sweep) {
-            double off = 0.0;
-#pragma unroll
-            for (int a = 0; a < 4; ++a)
-#pragma unroll
-                for (int b = a + 1; b < 4; ++b) off += S[a][b] * S[a][b];
-            if (off < 1e-300) break;
-#pragma unroll
-            for (int p = 0; p < 3; ++p)
-#pragma unroll
-                for (int q = p + 1; q < 4; ++q) {
-                    if (S[p][q] == 0.0) continue;
-                    const double theta = (S[q][q] - S[p][p]) / (2.0 * S[p][q]);
-                    const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
-                    const double cs = 1.0 / sqrt(t * t + 1.0), sn = t * cs;
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {  // S <- S J (columns p, q)
-                        const double skp = S[k][p], skq = S[k][q];
-                        S[k][p] = cs * skp - sn * skq;
-                        S[k][q] = sn * skp + cs * skq;
-                    }
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {  // S <- J^T S (rows p, q)
-                        const double spk = S[p][k], sqk = S[q][k];
-                        S[p][k] = cs * spk - sn * sqk;
-                        S[q][k] = sn * spk + cs * sqk;
-                    }
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const double vkp = V[k][p], vkq = V[k][q];
-                        V[k][p] = cs * vkp - sn * vkq;
-                        V[k][q] = sn * vkp + cs * vkq;
-                    }
-                }
-        }
-        int best = 0;
-#pragma unroll
-        for (int k = 1; k < 4; ++k) best = S[k][k] < S[best][best] ? k : best;
         double X[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) X[k] = best == 0 ? V[k][0] : best == 1 ? V[k][1] : best == 2 ? V[k][2] : V[k][3];
+        dlt_point(cam.P1, cam.P2, x1, y1, x2, y2, X);
         const double px = X[0] / X[3], py = X[1] / X[3], pz = X[2] / X[3];  // SfMUtil.cpp:134-137
         points3d[3 * (size_t)i] = px;
         points3d[3 * (size_t)i + 1] = py;
@@ -236,7 +243,97 @@ triangulate_kernel(CameraModel cam, const float2* __restrict__ coords1, const fl
     }
 }
 
+// ---- cv::recoverPose (SfMUtil.cpp:45) -----------------------------------------------------------------------------------------------
+// The four (R, t) an essential matrix decomposes into (the host does the 3 x 3 decomposition: gms_capi.cpp) are tried on every
+// correspondence as OpenCV 4.5.2 does: triangulate with P0 = [I|0] and P = [R|t] in normalised coordinates ((x - cx) / fx, no
+// distortion model), keep the point if its depth is positive and below the distance threshold in both cameras. One byte of four
+// vote bits per correspondence, four counters; pose_pick_kernel then takes the first hypothesis with the most votes in the order
+// (R1, t), (R2, t), (R1, -t), (R2, -t) and writes the mask (255 / 0, as cv::Mat comparisons do).
+struct PoseModel {
+    double fx, fy, cx, cy, dist_thresh;
+    double P[4][12];
+};
+
+__global__ void __launch_bounds__(256)
+pose_votes_kernel(PoseModel pm, const float2* __restrict__ coords1, const float2* __restrict__ coords2, const int32_t* __restrict__ n_matches,
+                  int cap, const uint8_t* __restrict__ in_mask, uint8_t* __restrict__ votes, unsigned long long* __restrict__ counts)
+{
+    const int n = min(*n_matches, cap);
+    const int i = (int)(blockIdx.x * 256u + threadIdx.x);
+    uint32_t bits = 0;
+    if (i < n && (in_mask == nullptr || in_mask[i] != 0)) {
+        const double x1 = ((double)coords1[i].x - pm.cx) / pm.fx, y1 = ((double)coords1[i].y - pm.cy) / pm.fy;
+        const double x2 = ((double)coords2[i].x - pm.cx) / pm.fx, y2 = ((double)coords2[i].y - pm.cy) / pm.fy;
+        const double P0[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+        for (int h = 0; h < 4; ++h) {
+            const double* P = pm.P[h];
+            double Q[4];
+            dlt_point(P0, P, x1, y1, x2, y2, Q);
+            bool ok = Q[2] * Q[3] > 0.0;
+            const double qx = Q[0] / Q[3], qy = Q[1] / Q[3], qz = Q[2] / Q[3];
+            ok = ok && qz < pm.dist_thresh;
+            const double z2 = P[8] * qx + P[9] * qy + P[10] * qz + P[11];
+            ok = ok && z2 > 0.0 && z2 < pm.dist_thresh;
+            bits |= ok ? 1u << h : 0u;
+        }
+    }
+    if (i < n) votes[i] = (uint8_t)bits;
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+        const unsigned long long c = (unsigned long long)__popcll(__ballot((bits >> h) & 1u));
+        if ((threadIdx.x & 63) == 0 && c) atomicAdd(&counts[h], c);
+    }
+}
+
+__global__ void __launch_bounds__(256)
+pose_pick_kernel(PoseModel pm, const int32_t* __restrict__ n_matches, int cap, const uint8_t* __restrict__ votes,
+                 const unsigned long long* __restrict__ counts, gms_pose* __restrict__ pose, uint8_t* __restrict__ out_mask)
+{
+    const unsigned long long g0 = counts[0], g1 = counts[1], g2 = counts[2], g3 = counts[3];
+    int w;  // recoverPose's chain of comparisons
+    if (g0 >= g1 && g0 >= g2 && g0 >= g3) w = 0;
+    else if (g1 >= g0 && g1 >= g2 && g1 >= g3) w = 1;
+    else if (g2 >= g0 && g2 >= g1 && g2 >= g3) w = 2;
+    else w = 3;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        for (int r = 0; r < 3; ++r) {
+            for (int c = 0; c < 3; ++c) pose->R[3 * r + c] = pm.P[w][4 * r + c];
+            pose->t[r] = pm.P[w][4 * r + 3];
+        }
+        pose->n_good = (int32_t)(w == 0 ? g0 : w == 1 ? g1 : w == 2 ? g2 : g3);
+        pose->which = w;
+    }
+    if (out_mask != nullptr) {
+        const int n = min(*n_matches, cap);
+        const int i = (int)(blockIdx.x * 256u + threadIdx.x);
+        if (i < n) out_mask[i] = ((votes[i] >> w) & 1u) ? 255 : 0;
+    }
+}
+
 }  // namespace
+
+// d_work: max_matches vote bytes, then (8-byte aligned) four 64-bit counters
+hipError_t launch_recover_pose(const double* camera, const double P[4][12], double dist_thresh, const float* d_coords1, const float* d_coords2,
+                               const int32_t* d_n_matches, int max_matches, const uint8_t* d_in_mask, gms_pose* d_pose, uint8_t* d_out_mask,
+                               void* d_work, hipStream_t stream)
+{
+    PoseModel pm;
+    pm.fx = camera[0]; pm.fy = camera[1]; pm.cx = camera[2]; pm.cy = camera[3];
+    pm.dist_thresh = dist_thresh;
+    for (int h = 0; h < 4; ++h)
+        for (int k = 0; k < 12; ++k) pm.P[h][k] = P[h][k];
+    uint8_t* votes = reinterpret_cast<uint8_t*>(d_work);
+    unsigned long long* counts = reinterpret_cast<unsigned long long*>(votes + (((size_t)max_matches + 7) & ~(size_t)7));
+    hipError_t e = hipMemsetAsync(counts, 0, 4 * sizeof(unsigned long long), stream);
+    if (e != hipSuccess) return e;
+    const unsigned blocks = (unsigned)((max_matches + 255) / 256);
+    if (max_matches > 0)
+        hipLaunchKernelGGL(pose_votes_kernel, dim3(blocks), dim3(256), 0, stream, pm, reinterpret_cast<const float2*>(d_coords1),
+                           reinterpret_cast<const float2*>(d_coords2), d_n_matches, max_matches, d_in_mask, votes, counts);
+    hipLaunchKernelGGL(pose_pick_kernel, dim3(blocks ? blocks : 1u), dim3(256), 0, stream, pm, d_n_matches, max_matches, votes, counts, d_pose,
+                       max_matches > 0 ? d_out_mask : nullptr);
+    return hipGetLastError();
+}
 
 hipError_t launch_triangulate(const double* camera, const double* dist, const double* P1, const double* P2, const float* d_coords1,
                               const float* d_coords2, const int32_t* d_n_matches, int max_matches, double* d_points3d,

@@ -152,7 +152,7 @@ struct gms_ctx {
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     std::mutex mu;  // every entry point that touches the context's buffers holds it
-    DevBuf aux, big_ws, band_ws, partial_ws;
+    DevBuf aux, big_ws, band_ws, partial_ws, pose_ws;
     // "recent batches came in spatial order": a word in pinned host memory that order_probe_kernel writes now and then and the host
     // reads, without waiting, when it picks the byte-matrix kernel's instantiation
     uint32_t* order_flag = nullptr;
@@ -459,7 +459,7 @@ int gms_ctx_destroy(gms_ctx* c)
         (void)hipStreamSynchronize(c->own_stream);
         (void)hipStreamSynchronize(c->lane[1].stream);
         if (c->ws_pending) (void)hipEventSynchronize(c->ws_event);
-        DevBuf* bufs[] = {&c->aux, &c->big_ws, &c->band_ws, &c->partial_ws, &c->probe_stats, &c->tab_kp, &c->tab_pts, &c->tab_small};
+        DevBuf* bufs[] = {&c->aux, &c->big_ws, &c->band_ws, &c->partial_ws, &c->pose_ws, &c->probe_stats, &c->tab_kp, &c->tab_pts, &c->tab_small};
         if (c->order_flag) (void)hipHostFree(c->order_flag);
         for (DevBuf* b : bufs) b->release();
         for (Lane& l : c->lane) {
@@ -846,6 +846,113 @@ int gms_triangulate_device(gms_ctx* c, const double camera[4], const double dist
     std::lock_guard<std::mutex> lock(c->mu);
     GMS_HIP(hipSetDevice(c->device));
     GMS_HIP(gms::launch_triangulate(camera, dist, P1, P2, d_coords1, d_coords2, d_n_matches, max_matches, d_points3d, d_stats, c->stream));
+    return GMS_OK;
+}
+
+// cv::decomposeEssentialMat: E = U diag(s, s, 0) V^T with det U = det V = +1, R1 = U W V^T, R2 = U W^T V^T, t = U's last column.
+// V and the singular values come from the eigen-decomposition of E^T E (cyclic Jacobi, fp64), U's first two columns from E v / s,
+// its third as their cross product (so det U = +1 by construction).
+static bool decompose_essential(const double E[9], double R1[9], double R2[9], double t[3])
+{
+    double S[3][3], V[3][3];
+    for (int a = 0; a < 3; ++a)
+        for (int b = 0; b < 3; ++b) {
+            S[a][b] = E[a] * E[b] + E[3 + a] * E[3 + b] + E[6 + a] * E[6 + b];
+            V[a][b] = a == b ? 1.0 : 0.0;
+        }
+    for (int sweep = 0; sweep < 30; ++sweep) {
+        const double off = S[0][1] * S[0][1] + S[0][2] * S[0][2] + S[1][2] * S[1][2];
+        if (off < 1e-300) break;
+        for (int p = 0; p < 2; ++p)
+            for (int q = p + 1; q < 3; ++q) {
+                if (S[p][q] == 0.0) continue;
+                const double theta = (S[q][q] - S[p][p]) / (2.0 * S[p][q]);
+                const double tt = (theta >= 0.0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
+                const double cs = 1.0 / std::sqrt(tt * tt + 1.0), sn = tt * cs;
+                for (int k = 0; k < 3; ++k) {
+                    const double a = S[k][p], b = S[k][q];
+                    S[k][p] = cs * a - sn * b;
+                    S[k][q] = sn * a + cs * b;
+                }
+                for (int k = 0; k < 3; ++k) {
+                    const double a = S[p][k], b = S[q][k];
+                    S[p][k] = cs * a - sn * b;
+                    S[q][k] = sn * a + cs * b;
+                }
+                for (int k = 0; k < 3; ++k) {
+                    const double a = V[k][p], b = V[k][q];
+                    V[k][p] = cs * a - sn * b;
+                    V[k][q] = sn * a + cs * b;
+                }
+            }
+    }
+    int ord[3] = {0, 1, 2};  // eigenvalues descending
+    for (int a = 0; a < 3; ++a)
+        for (int b = a + 1; b < 3; ++b)
+            if (S[ord[b]][ord[b]] > S[ord[a]][ord[a]]) std::swap(ord[a], ord[b]);
+    double v[3][3];  // v[j] = j-th right singular vector
+    for (int j = 0; j < 3; ++j)
+        for (int k = 0; k < 3; ++k) v[j][k] = V[k][ord[j]];
+    const double det = v[0][0] * (v[1][1] * v[2][2] - v[1][2] * v[2][1]) - v[0][1] * (v[1][0] * v[2][2] - v[1][2] * v[2][0]) +
+                       v[0][2] * (v[1][0] * v[2][1] - v[1][1] * v[2][0]);
+    if (det < 0.0)
+        for (int k = 0; k < 3; ++k) v[2][k] = -v[2][k];  // (the null direction: E v2 = 0 either way)
+    double u[3][3];
+    for (int j = 0; j < 2; ++j) {
+        double n2 = 0.0;
+        for (int r = 0; r < 3; ++r) {
+            u[j][r] = E[3 * r] * v[j][0] + E[3 * r + 1] * v[j][1] + E[3 * r + 2] * v[j][2];
+            n2 += u[j][r] * u[j][r];
+        }
+        if (!(n2 > 0.0)) return false;  // rank below two: not an essential matrix
+        const double inv = 1.0 / std::sqrt(n2);
+        for (int r = 0; r < 3; ++r) u[j][r] *= inv;
+    }
+    {   // re-orthogonalise u1 against u0 (the two singular values of an estimated E differ slightly: E v / |E v| is orthogonal only
+        // to rounding of the eigenvectors), then u2 = u0 x u1
+        double d = u[0][0] * u[1][0] + u[0][1] * u[1][1] + u[0][2] * u[1][2], n2 = 0.0;
+        for (int r = 0; r < 3; ++r) {
+            u[1][r] -= d * u[0][r];
+            n2 += u[1][r] * u[1][r];
+        }
+        const double inv = 1.0 / std::sqrt(n2);
+        for (int r = 0; r < 3; ++r) u[1][r] *= inv;
+    }
+    u[2][0] = u[0][1] * u[1][2] - u[0][2] * u[1][1];
+    u[2][1] = u[0][2] * u[1][0] - u[0][0] * u[1][2];
+    u[2][2] = u[0][0] * u[1][1] - u[0][1] * u[1][0];
+    // W = [0 1 0; -1 0 0; 0 0 1]: U W = [-u1, u0, u2], U W^T = [u1, -u0, u2] (columns); R1 = U W V^T, R2 = U W^T V^T
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) {
+            R1[3 * r + c] = -u[1][r] * v[0][c] + u[0][r] * v[1][c] + u[2][r] * v[2][c];
+            R2[3 * r + c] = u[1][r] * v[0][c] - u[0][r] * v[1][c] + u[2][r] * v[2][c];
+        }
+    for (int r = 0; r < 3; ++r) t[r] = u[2][r];
+    return true;
+}
+
+int gms_recover_pose_device(gms_ctx* c, const double E[9], const double camera[4], const float* d_coords1, const float* d_coords2,
+                            const int32_t* d_n_matches, int max_matches, const uint8_t* d_in_mask, gms_pose* d_pose, uint8_t* d_out_mask)
+{
+    if (!c || !E || !camera || !d_n_matches || !d_pose || max_matches < 0) return GMS_ERR_BAD_ARG;
+    if (max_matches > 0 && (!d_coords1 || !d_coords2)) return GMS_ERR_BAD_ARG;
+    if (camera[0] == 0.0 || camera[1] == 0.0) return GMS_ERR_BAD_ARG;
+    double R1[9], R2[9], t[3];
+    if (!decompose_essential(E, R1, R2, t)) return GMS_ERR_BAD_ARG;
+    double P[4][12];
+    for (int h = 0; h < 4; ++h) {
+        const double* R = (h & 1) ? R2 : R1;
+        const double sg = h < 2 ? 1.0 : -1.0;
+        for (int r = 0; r < 3; ++r) {
+            for (int k = 0; k < 3; ++k) P[h][4 * r + k] = R[3 * r + k];
+            P[h][4 * r + 3] = sg * t[r];
+        }
+    }
+    std::lock_guard<std::mutex> lock(c->mu);
+    GMS_HIP(hipSetDevice(c->device));
+    GMS_HIP(c->pose_ws.reserve((size_t)max_matches + 48));
+    GMS_HIP(gms::launch_recover_pose(camera, P, 50.0, d_coords1, d_coords2, d_n_matches, max_matches, d_in_mask, d_pose, d_out_mask,
+                                     c->pose_ws.p, c->stream));
     return GMS_OK;
 }
 

@@ -88,6 +88,9 @@ hipError_t launch_gather_points(const gms_keypoint* d_kp1, int n1, const gms_key
 hipError_t launch_triangulate(const double* camera, const double* dist, const double* P1, const double* P2, const float* d_coords1,
                               const float* d_coords2, const int32_t* d_n_matches, int max_matches, double* d_points3d,
                               gms_triangulation_stats* d_stats, hipStream_t stream);
+hipError_t launch_recover_pose(const double* camera, const double P[4][12], double dist_thresh, const float* d_coords1, const float* d_coords2,
+                               const int32_t* d_n_matches, int max_matches, const uint8_t* d_in_mask, gms_pose* d_pose, uint8_t* d_out_mask,
+                               void* d_work, hipStream_t stream);
 hipError_t launch_threshold(const int32_t* d_T, const int32_t* d_n, const int32_t* d_score, double factor,
                             int count, uint8_t* d_out, hipStream_t stream);
 

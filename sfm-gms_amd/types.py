@@ -29,3 +29,5 @@ GMS_DESC_HAMMING256, GMS_DESC_L2_F32X128 = 0, 1
 DISPARITY_STATS_DTYPE = np.dtype([("count", "<i8"), ("sum_sq", "<i8"), ("max_abs", "<i4"), ("status", "<i4")])
 assert DISPARITY_STATS_DTYPE.itemsize == 24
 TRIANGULATION_STATS_DTYPE = np.dtype([("sum_sq_err1", "<f8"), ("sum_sq_err2", "<f8"), ("count", "<i8"), ("behind", "<i8")])
+POSE_DTYPE = np.dtype([("R", "<f8", (3, 3)), ("t", "<f8", (3,)), ("n_good", "<i4"), ("which", "<i4")])
+assert POSE_DTYPE.itemsize == 104

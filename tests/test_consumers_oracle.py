@@ -45,3 +45,23 @@ def test_gather_known_answers(oracle, synth, pkg):
     m["trainIdx"] = [2, 0, 1]
     rc, c1, c2 = oracle.gather(kp1, kp2, m)
     assert rc == 0 and c1.tolist() == [[3.25, 4.0], [1.5, 2.5], [3.25, 4.0]] and c2.tolist() == [[5.0, 4.0], [9.0, 8.0], [7.0, 6.5]]
+
+
+def test_recover_pose_oracle_finds_the_camera_motion():
+    """oracle/sfm_ref.recover_pose on exact correspondences of a known motion: the rotation, the direction of the translation, every
+    point in front of both cameras."""
+    import sfm_ref
+    rng = np.random.default_rng(3)
+    camera = (1400.0, 1380.0, 960.0, 540.0)
+    ang = np.deg2rad(-9.0)
+    R = np.array([[np.cos(ang), 0, np.sin(ang)], [0, 1, 0], [-np.sin(ang), 0, np.cos(ang)]])
+    t = np.array([0.5, -0.05, 0.1])
+    X = np.stack([rng.uniform(-2, 2, 300), rng.uniform(-1, 1, 300), rng.uniform(4, 9, 300)], axis=1)
+    K = np.array([[camera[0], 0, camera[2]], [0, camera[1], camera[3]], [0, 0, 1.0]])
+    p1 = X @ K.T
+    p2 = (X @ R.T + t) @ K.T
+    uv1, uv2 = p1[:, :2] / p1[:, 2:3], p2[:, :2] / p2[:, 2:3]
+    tx = np.array([[0, -t[2], t[1]], [t[2], 0, -t[0]], [-t[1], t[0], 0]])
+    Rr, tr, good, mask = sfm_ref.recover_pose(tx @ R, uv1, uv2, camera)
+    assert good == 300 and (mask == 255).all()
+    assert np.allclose(Rr, R, atol=1e-9) and np.allclose(tr, t / np.linalg.norm(t), atol=1e-9)

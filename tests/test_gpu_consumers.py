@@ -196,3 +196,48 @@ def test_two_view_loop_on_synthetic_cameras(ctx, pkg, oracle, synth):
     # the survivors that are true correspondences reconstruct the scene: reprojection error at the level of the fp32 pixel rounding
     Xk = X[ok][want["queryIdx"]]
     assert np.abs(got[true] - Xk[true]).max() < 2e-2
+
+
+def test_recover_pose_against_the_oracle(ctx, pkg, synth):
+    """gms_recover_pose_device (SfMUtil.cpp:45) on noisy correspondences, a third of them wrong, with and without an input mask:
+    rotation and translation to 1e-9, the count and the 255 / 0 mask exactly (the votes are decided far from their thresholds
+    for all but a handful of points; those are allowed to differ -- none does here)."""
+    import torch
+    import sfm_ref
+    types = importlib.import_module("sfm-gms_amd.types")
+    rng = np.random.default_rng(21)
+    n = 4000
+    camera = (1400.0, 1380.0, 960.0, 540.0)
+    ang = np.deg2rad(7.0)
+    R = np.array([[np.cos(ang), 0, np.sin(ang)], [0, 1, 0], [-np.sin(ang), 0, np.cos(ang)]]) @ \
+        np.array([[1, 0, 0], [0, np.cos(0.03), -np.sin(0.03)], [0, np.sin(0.03), np.cos(0.03)]])
+    t = np.array([-0.6, 0.02, 0.05])
+    X = np.stack([rng.uniform(-2.2, 2.2, n), rng.uniform(-1.2, 1.2, n), rng.uniform(4.0, 9.0, n)], axis=1)
+    K = np.array([[camera[0], 0, camera[2]], [0, camera[1], camera[3]], [0, 0, 1.0]])
+    p1, p2 = X @ K.T, (X @ R.T + t) @ K.T
+    uv1 = (p1[:, :2] / p1[:, 2:3] + rng.normal(0, 0.3, (n, 2))).astype(np.float32)
+    uv2 = (p2[:, :2] / p2[:, 2:3] + rng.normal(0, 0.3, (n, 2))).astype(np.float32)
+    wrong = rng.uniform(size=n) < 0.33
+    uv2[wrong] = np.stack([rng.uniform(0, 1920, int(wrong.sum())), rng.uniform(0, 1080, int(wrong.sum()))], axis=1).astype(np.float32)
+    tx = np.array([[0, -t[2], t[1]], [t[2], 0, -t[0]], [-t[1], t[0], 0]])
+    E = (tx @ R) * 3.7                                             # any scale
+    dev = torch.device("cuda", 0)
+    d_c1 = torch.from_numpy(uv1.reshape(-1).copy()).to(dev)
+    d_c2 = torch.from_numpy(uv2.reshape(-1).copy()).to(dev)
+    d_n = torch.tensor([n - 5], dtype=torch.int32, device=dev)      # the last five are not part of the call
+    in_mask = (rng.uniform(size=n) < 0.9).astype(np.uint8)
+    d_in = torch.from_numpy(in_mask).to(dev)
+    for use_mask in (False, True):
+        d_pose = torch.zeros(types.POSE_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+        d_out = torch.full((n,), 7, dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize()
+        ctx.recover_pose_device(E, camera, d_c1.data_ptr(), d_c2.data_ptr(), d_n.data_ptr(), n, d_in.data_ptr() if use_mask else None,
+                                d_pose.data_ptr(), d_out.data_ptr())
+        ctx.synchronize()
+        pose = d_pose.cpu().numpy().view(types.POSE_DTYPE)[0]
+        Rr, tr, good, mask = sfm_ref.recover_pose(E, uv1[:n - 5], uv2[:n - 5], camera, in_mask[:n - 5] if use_mask else None)
+        assert np.allclose(pose["R"], Rr, atol=1e-9) and np.allclose(pose["t"], tr, atol=1e-9)
+        assert np.allclose(pose["R"], R, atol=1e-2) and np.allclose(pose["t"], t / np.linalg.norm(t), atol=2e-2)
+        got = d_out.cpu().numpy()
+        assert int(pose["n_good"]) == good and np.array_equal(got[:n - 5], mask) and (got[n - 5:] == 7).all()
+        assert good > 0.6 * (in_mask[:n - 5].sum() if use_mask else n - 5)
