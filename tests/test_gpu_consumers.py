@@ -176,10 +176,19 @@ def test_two_view_loop_on_synthetic_cameras(ctx, pkg, oracle, synth):
     kpb = types.KEYPOINT_DTYPE.itemsize
     ctx.gather_points_device(table.d_kp.data_ptr(), n, table.d_kp.data_ptr() + n * kpb, n, d_out.data_ptr(), d_res.data_ptr(), n,
                              d_c1.data_ptr(), d_c2.data_ptr(), d_st.data_ptr())
+    # SfMUtil.cpp:45 on the survivors (the essential matrix of the true motion stands in for findEssentialMat's estimate): the pose
+    # the reference would build P2 from; the loop below goes on with the exact one
+    tvec = t.reshape(3)
+    tx = np.array([[0, -tvec[2], tvec[1]], [tvec[2], 0, -tvec[0]], [-tvec[1], tvec[0], 0]])
+    d_pose = torch.zeros(types.POSE_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+    ctx.recover_pose_device(tx @ R, camera, d_c1.data_ptr(), d_c2.data_ptr(), d_res.data_ptr(), n, None, d_pose.data_ptr(), None)
     ctx.triangulate_device(camera, dist, P1, P2, d_c1.data_ptr(), d_c2.data_ptr(), d_res.data_ptr(), n, d_pts.data_ptr(),
                            d_stats.data_ptr())
     ctx.synchronize()
     k = int(d_res.cpu().numpy().view(np.int32)[0])
+    pose = d_pose.cpu().numpy().view(types.POSE_DTYPE)[0]
+    assert np.allclose(pose["R"], R, atol=1e-9) and np.allclose(pose["t"], tvec / np.linalg.norm(tvec), atol=1e-9)
+    assert int(pose["n_good"]) > 0.85 * k                                               # the true correspondences are in front of both cameras
     rc, want, _, _ = oracle.match(size, size, kp1, kp2, matches, True, True, 6.0)
     assert rc == 0 and k == len(want) and d_out.cpu().numpy().view(pkg.DMATCH_DTYPE)[:k].tobytes() == want.tobytes()
     assert k > 0.8 * (~wrong).sum() and (want["queryIdx"] == want["trainIdx"]).mean() > 0.9
