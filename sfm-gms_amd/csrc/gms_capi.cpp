@@ -153,14 +153,15 @@ struct gms_ctx {
     hipStream_t stream = nullptr;
     std::mutex mu;  // every entry point that touches the context's buffers holds it
     DevBuf aux, big_ws, band_ws, partial_ws, pose_ws;
-    // "recent batches came in spatial order": a word in pinned host memory that order_probe_kernel writes now and then and the host
-    // reads, without waiting, when it picks the byte-matrix kernel's instantiation
-    uint32_t* order_flag = nullptr;
+    // What recent launches saw, as words in pinned host memory that small kernels write now and then and the host reads without
+    // waiting: verdict[0] "recent batches came in spatial order" (order_probe_kernel; picks the byte-matrix kernel's instantiation),
+    // verdict[1] "probing scale hypotheses pays" (probe_verdict_kernel, below)
+    uint32_t* verdict = nullptr;
     unsigned dense_launches = 0;
     // Scale hypotheses: the kernels can bound a scale's inlier count before evaluating it (gms_kernels.hip, PROBE) and skip the
     // scale when it cannot win -- a gain when at least half of the probes let a scale skip, a loss otherwise. The kernels count
     // both in probe_stats (device); every sixteenth launch with scale hypotheses probes whatever the verdict and is followed by a
-    // one-thread kernel that turns the counts into order_flag[1] ("probing pays"), which the launches in between follow.
+    // one-thread kernel that turns the counts into verdict[1], which the launches in between follow.
     DevBuf probe_stats;
     unsigned scale_launches = 0;
     // the workspaces above are shared by every launch of the context: the last launch that used them, and where
@@ -262,7 +263,7 @@ int filter_launch(gms_ctx* c, hipStream_t st, const float* d_pts, const int64_t*
     // the byte-matrix path is tried first whenever there are no scale hypotheses (the reference's default flags,
     // DisparityUtil.cpp:149,299)
     p.dense = (knobs().dense_on && !with_scale) ? 1 : 0;
-    p.dealt = (p.dense && kpt && (knobs().deal >= 0 ? knobs().deal != 0 : *(volatile uint32_t*)c->order_flag != 0u)) ? 1 : 0;
+    p.dealt = (p.dense && kpt && (knobs().deal >= 0 ? knobs().deal != 0 : ((volatile uint32_t*)c->verdict)[0] != 0u)) ? 1 : 0;
     // First-round stagger: the spread is about one pair's duration on the path the launch will mostly take -- 26 us (byte
     // matrix) / 72 us (hashed) at 10k matches, in proportion to max_m -- in ticks of the 100 MHz wall clock. Only launches of
     // at least four dispatch rounds are staggered.
@@ -279,7 +280,7 @@ int filter_launch(gms_ctx* c, hipStream_t st, const float* d_pts, const int64_t*
     if (kpt && with_scale) {
         // the scales finer than 20 x 20 and the 14 x 14 one are probed (2, 3, 4); the measuring launches are left out of stream captures
         const bool measuring = knobs().scale_probe < 0 && !capturing && (c->scale_launches++ & 15u) == 0u;
-        const bool on = knobs().scale_probe >= 0 ? knobs().scale_probe != 0 : (measuring || ((volatile uint32_t*)c->order_flag)[1] != 0u);
+        const bool on = knobs().scale_probe >= 0 ? knobs().scale_probe != 0 : (measuring || ((volatile uint32_t*)c->verdict)[1] != 0u);
         p.probe_scales = on ? 0x1C : 0;
         p.probe_stats = measuring ? (uint32_t*)c->probe_stats.p : nullptr;
     }
@@ -289,7 +290,7 @@ int filter_launch(gms_ctx* c, hipStream_t st, const float* d_pts, const int64_t*
         GMS_HIP(gms::launch_filter_scales(p, kpt, n_pairs, st));
         if (p.probe_stats != nullptr) {
             void* dflag = nullptr;
-            GMS_HIP(hipHostGetDevicePointer(&dflag, c->order_flag, 0));
+            GMS_HIP(hipHostGetDevicePointer(&dflag, c->verdict, 0));
             GMS_HIP(gms::launch_probe_verdict(p.probe_stats, (uint32_t*)dflag + 1, st));
         }
     } else if (kpt) {
@@ -297,7 +298,7 @@ int filter_launch(gms_ctx* c, hipStream_t st, const float* d_pts, const int64_t*
         // every sixteenth byte-matrix launch (and the first) is followed by the spatial-order probe of its batch, for later launches
         if (p.dense && !capturing && (c->dense_launches++ & 15u) == 0u) {
             void* dflag = nullptr;
-            GMS_HIP(hipHostGetDevicePointer(&dflag, c->order_flag, 0));
+            GMS_HIP(hipHostGetDevicePointer(&dflag, c->verdict, 0));
             GMS_HIP(gms::launch_order_probe(p, (uint32_t*)dflag, st));
         }
     } else if (knobs().band_on) {
@@ -422,10 +423,10 @@ int gms_ctx_create(int device, gms_ctx** out_ctx)
     e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->lane[1].stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ws_event, hipEventDisableTiming);
-    if (e == hipSuccess) e = hipHostMalloc((void**)&c->order_flag, 64, hipHostMallocDefault);
+    if (e == hipSuccess) e = hipHostMalloc((void**)&c->verdict, 64, hipHostMallocDefault);
     if (e == hipSuccess) {
-        c->order_flag[0] = 0;
-        c->order_flag[1] = 1;
+        c->verdict[0] = 0;
+        c->verdict[1] = 1;
     }
     if (e == hipSuccess) e = c->probe_stats.reserve(64);
     if (e == hipSuccess) e = hipMemset(c->probe_stats.p, 0, 64);
@@ -437,7 +438,7 @@ int gms_ctx_create(int device, gms_ctx** out_ctx)
         if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
         if (c->lane[1].stream) (void)hipStreamDestroy(c->lane[1].stream);
         if (c->ws_event) (void)hipEventDestroy(c->ws_event);
-        if (c->order_flag) (void)hipHostFree(c->order_flag);
+        if (c->verdict) (void)hipHostFree(c->verdict);
         c->probe_stats.release();
         delete c;
         return GMS_ERR_HIP;
@@ -460,7 +461,7 @@ int gms_ctx_destroy(gms_ctx* c)
         (void)hipStreamSynchronize(c->lane[1].stream);
         if (c->ws_pending) (void)hipEventSynchronize(c->ws_event);
         DevBuf* bufs[] = {&c->aux, &c->big_ws, &c->band_ws, &c->partial_ws, &c->pose_ws, &c->probe_stats, &c->tab_kp, &c->tab_pts, &c->tab_small};
-        if (c->order_flag) (void)hipHostFree(c->order_flag);
+        if (c->verdict) (void)hipHostFree(c->verdict);
         for (DevBuf* b : bufs) b->release();
         for (Lane& l : c->lane) {
             l.hin.release();
