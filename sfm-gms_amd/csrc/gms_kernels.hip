@@ -1449,13 +1449,14 @@ order_probe_kernel(FilterParams p, uint32_t* __restrict__ flag)
 // ------------------------------------------------------------------------------------------------
 // Scale hypotheses on the byte matrix (dense_scales_pair): the right grids of scales 0, 1 and 2 are 20 x 20,
 // 10 x 10 and 14 x 14, so their motion matrices (400 x 400, 400 x 100, 400 x 196 bytes) fit the LDS like the default
-// case; scale 3 (28 x 28: 400 rows of 788 bytes) fits in three bands of left rows; scale 4 (40 x 40) does not pay. With scale hypotheses a launch therefore runs two kernels: this
-// one evaluates scales 0..3 (all rotations) and leaves the best hypothesis so far -- count, (scale, rotation), the
-// inlier bit of every match -- in a per-pair workspace record; filter_kernel then picks the record up, evaluates
-// scale 4 on the hashed path, and selects and copies out as always (getInlierMask's order is scale-outer,
-// rotation-inner with strict '>', so "best of 0..3, then 4" is the same comparison sequence). A pair this kernel
-// cannot take (a cell above 255 matches, inputs outside the parity domain) gets an empty record and the hashed path
-// evaluates all five scales.
+// case; scale 3 (28 x 28: 400 rows of 788 bytes) fits in three bands of left rows; scale 4 (40 x 40: 1604-byte rows) would
+// need seven. With scale hypotheses a launch therefore runs two kernels: this one evaluates scales 0..3 (all rotations),
+// bounds scale 4 (the probe below, five halo-free bands) and leaves the best hypothesis so far -- count, (scale, rotation),
+// the inlier bit of every match -- in a per-pair workspace record together with what is decided; filter_kernel then picks
+// the record up, evaluates scale 4 on the hashed path unless the probe bounded it out, and selects and copies out as always
+// (getInlierMask's order is scale-outer, rotation-inner with strict '>', so "best of 0..3, then 4" is the same comparison
+// sequence). A pair this kernel cannot take (a cell above 255 matches, inputs outside the parity domain) gets an empty record
+// and the hashed path evaluates all five scales.
 // Everything is dense_pair() with a runtime row stride; the records are not kept (nothing is copied out here).
 // ------------------------------------------------------------------------------------------------
 constexpr uint32_t kDenseBestMaskOff = 157696u;  // best mask so far (2 KB): above every scale >= 1 matrix and every scale-3 band
