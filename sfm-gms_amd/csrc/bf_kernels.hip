@@ -235,12 +235,16 @@ __device__ __forceinline__ int dot16(const uint4& a, const uint4& b)
     return __builtin_amdgcn_sdot4((int)a.w, (int)b.w, d, false);
 }
 
+// ROWS = 32: the whole block. ROWS = 16: only the rows whose accumulators sat in lane half `hsel` of the matrix pass -- rows
+// (reg & 3) + 8 (reg >> 2) + 4 hsel -- when the minimum is known to have come from that half.
+template <int ROWS>
 __device__ __forceinline__ uint32_t l2_block_key(const uint4* __restrict__ rows, const uint32_t* __restrict__ w_norms, const uint4& nb,
-                                                 int query_part, int64_t offB, int nB, int blk, int piece)
+                                                 int query_part, int64_t offB, int nB, int blk, int piece, int hsel)
 {
     uint32_t key = 0xFFFFFFFFu;
 #pragma unroll
-    for (int r = 0; r < 32; ++r) {   // (all 64 loads in flight together)
+    for (int i = 0; i < ROWS; ++i) {   // (all loads in flight together)
+        const int r = ROWS == 32 ? i : 8 * (i >> 2) + 4 * hsel + (i & 3);
         const int row = blk * 32 + r;
         const int64_t rr = offB + min(row, nB - 1);
         const uint4 y = rows[(size_t)rr * 8 + piece];
@@ -306,6 +310,7 @@ bf_mfma_kernel(const uint4* __restrict__ rows, const uint32_t* __restrict__ norm
     int bestt[2] = {0, 0};          // ... and the block (of 32 train rows) it came from: the first one that reached it
     int ties[2] = {0, 0};           // L2: in how many later blocks the minimal P was seen again ...
     int bestt2[2] = {0, 0};         // ... and the last of them
+    int whalf[2] = {half, half};    // L2: which lane half's rows of the winning block hold the minimum (2 = either)
 
     const uint4* __restrict__ trB = rows + (size_t)f.offB * (kRowBytes / 16);
     const uint32_t* __restrict__ nrmB = norms + f.offB;
@@ -481,9 +486,11 @@ bf_mfma_kernel(const uint4* __restrict__ rows, const uint32_t* __restrict__ norm
                 bestt[c] = ot;
                 bestt2[c] = ot2;
                 ties[c] = oties;
+                whalf[c] = half ^ 1;
             } else if (ov == bestv[c]) {   // both halves reached the minimal P: in the same block, in two blocks, or (rare) in more
                 const int lo = min(bestt[c], ot), hi = max(bestt[c], ot);
                 ties[c] = (ties[c] | oties) != 0 ? 2 : (lo != hi ? 1 : 0);
+                whalf[c] = lo == hi ? 2 : (bestt[c] == lo ? half : half ^ 1);
                 bestt[c] = lo;
                 bestt2[c] = hi;
             }
@@ -498,13 +505,16 @@ bf_mfma_kernel(const uint4* __restrict__ rows, const uint32_t* __restrict__ norm
             int blk = __shfl(i0 < 32 ? bestt[0] : bestt[1], i & 31);
             const int nt = __shfl(i0 < 32 ? ties[0] : ties[1], i & 31);
             const int blk2 = __shfl(i0 < 32 ? bestt2[0] : bestt2[1], i & 31);
+            const int hsel = __shfl(i0 < 32 ? whalf[0] : whalf[1], i & 31);
             const uint4 x = rows[(size_t)(f.offA + min(q, f.m - 1)) * 8 + piece];
             const uint4 nb = make_uint4(~x.x, ~x.y, ~x.z, ~x.w);
             const int query_part = dot16(nb, nb) + 2 * dot16(nb, ones);                   // this lane's 16 elements of the bracket
-            uint32_t key = l2_block_key(rows, norms, nb, query_part, f.offB, f.nB, blk, piece);
+            uint32_t key;
+            if (__ballot(hsel == 2) == 0ull) key = l2_block_key<16>(rows, norms, nb, query_part, f.offB, f.nB, blk, piece, hsel);
+            else key = l2_block_key<32>(rows, norms, nb, query_part, f.offB, f.nB, blk, piece, 0);
             if (__ballot(nt == 1) != 0ull) {   // some group's minimal P was seen in a second block (a group without one repeats its own)
                 const int b = nt == 1 ? blk2 : blk;
-                const uint32_t k2 = l2_block_key(rows, norms, nb, query_part, f.offB, f.nB, b, piece);
+                const uint32_t k2 = l2_block_key<32>(rows, norms, nb, query_part, f.offB, f.nB, b, piece, 0);
                 if ((k2 >> 5) < (key >> 5)) {   // a later block only wins with a strictly smaller distance
                     key = k2;
                     blk = b;
@@ -515,7 +525,7 @@ bf_mfma_kernel(const uint4* __restrict__ rows, const uint32_t* __restrict__ norm
                 for (int bb = 0; bb < n_blocks; ++bb) {
                     if (__ballot(nt >= 2 && bb > first) == 0ull) continue;
                     const int b = (nt >= 2 && bb > first) ? bb : blk;
-                    const uint32_t k2 = l2_block_key(rows, norms, nb, query_part, f.offB, f.nB, b, piece);
+                    const uint32_t k2 = l2_block_key<32>(rows, norms, nb, query_part, f.offB, f.nB, b, piece, 0);
                     if ((k2 >> 5) < (key >> 5)) {
                         key = k2;
                         blk = b;
