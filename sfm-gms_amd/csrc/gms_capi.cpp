@@ -281,7 +281,7 @@ int filter_launch(gms_ctx* c, hipStream_t st, const float* d_pts, const int64_t*
         // the scales finer than 20 x 20 and the 14 x 14 one are probed (2, 3, 4); the measuring launches are left out of stream captures
         const bool measuring = knobs().scale_probe < 0 && !capturing && (c->scale_launches++ & 15u) == 0u;
         const bool on = knobs().scale_probe >= 0 ? knobs().scale_probe != 0 : (measuring || ((volatile uint32_t*)c->verdict)[1] != 0u);
-        p.probe_scales = on ? 0x1C : 0;
+        p.probe_scales = on ? 0x1D : 0;  // every scale but 1, which the byte-matrix kernel evaluates first
         p.probe_stats = measuring ? (uint32_t*)c->probe_stats.p : nullptr;
     }
     if (kpt && with_scale && knobs().dense_on) {

@@ -1451,7 +1451,7 @@ order_probe_kernel(FilterParams p, uint32_t* __restrict__ flag)
 // 10 x 10 and 14 x 14, so their motion matrices (400 x 400, 400 x 100, 400 x 196 bytes) fit the LDS like the default
 // case; scale 3 (28 x 28: 400 rows of 788 bytes) fits in three bands of left rows; scale 4 (40 x 40: 1604-byte rows) would
 // need seven. With scale hypotheses a launch therefore runs two kernels: this one evaluates scales 0..3 (all rotations),
-// bounds scale 4 (the probe below, five halo-free bands) and leaves the best hypothesis so far -- count, (scale, rotation),
+// bounds scale 4 (the probe below, four halo-free bands) and leaves the best hypothesis so far -- count, (scale, rotation),
 // the inlier bit of every match -- in a per-pair workspace record together with what is decided; filter_kernel then picks
 // the record up, evaluates scale 4 on the hashed path unless the probe bounded it out, and selects and copies out as always
 // (getInlierMask's order is scale-outer, rotation-inner with strict '>', so "best of 0..3, then 4" is the same comparison
@@ -1459,7 +1459,6 @@ order_probe_kernel(FilterParams p, uint32_t* __restrict__ flag)
 // and the hashed path evaluates all five scales.
 // Everything is dense_pair() with a runtime row stride; the records are not kept (nothing is copied out here).
 // ------------------------------------------------------------------------------------------------
-constexpr uint32_t kDenseBestMaskOff = 157696u;  // best mask so far (2 KB): above every scale >= 1 matrix and every scale-3 band
 
 template <int KPT, bool ROT, int NT>
 __device__ __forceinline__ bool dense_scales_pair(const FilterParams& p, uint32_t* smem, const int pair_idx, const int tid,
@@ -1497,7 +1496,6 @@ __device__ __forceinline__ bool dense_scales_pair(const FilterParams& p, uint32_
     uint8_t* nleft8 = reinterpret_cast<uint8_t*>(smem) + kDenseNleftOff;
     uint32_t* misc = smem + kDenseMiscOff / 4;
     uint32_t* trash = smem + kDenseTrashOff / 4;
-    uint32_t* bestmask = smem + kDenseBestMaskOff / 4;
 
     GMS_STAMP_DECL
     if (tid < 32) misc[tid] = 0;
@@ -1596,7 +1594,7 @@ __device__ __forceinline__ bool dense_scales_pair(const FilterParams& p, uint32_
 
     const bool thr_fast = threshold_fast_ok(p.threshold_factor);
     const uint32_t f2i = dense_factor_sq(p.threshold_factor);
-    uint32_t best_count = 0;
+    uint32_t best_count = 0, bestbits = 0;
     int best_scale = -1, best_rot = -1;
 
     // One scale hypothesis. BANDED (scale 3, 28 x 28 right cells: 400 rows of 788 bytes do not fit): the left grid's rows
@@ -1625,11 +1623,13 @@ __device__ __forceinline__ bool dense_scales_pair(const FilterParams& p, uint32_
         const uint32_t wr_magic = 65535u / wr + 1u;      // j / wr == (j * magic) >> 16 for j * wr < 65536
         // scale 4 (probe only): E(r) up to 1603 takes 11 bits and reaches into the rotation bits, which a probe does not use
         const uint32_t emask = (PROBE && s == 4) ? 0x7FFu : kSEMask;
-        if (s > 0) {
+        {   // the code words' E(r) for this scale (scale 0 too: it is not the first one evaluated)
 #pragma unroll
             for (int k = 0; k < KPT; ++k) {
                 uint32_t r;
-                if (s == 3) {
+                if (s == 0) {
+                    r = (aux[k] >> 9) & 0x1FFu;
+                } else if (s == 3) {
                     r = (aux[k] >> 18) & 0x3FFu;
                 } else if (s == 4) {  // double the 20 x 20 cell's coordinates and add the stored low bits: fl(40 n) = 2 fl(20 n) + bit
                     const uint32_t c20 = (aux[k] >> 9) & 0x1FFu, cy = (c20 * 3277u) >> 16, cx = c20 - cy * 20u;
@@ -1663,8 +1663,8 @@ __device__ __forceinline__ bool dense_scales_pair(const FilterParams& p, uint32_
                 }
             }
             // bands: 8 own rows + a halo row on either side (verify reads the neighbour rows); a probe needs no neighbours, so its
-            // bands are as many whole rows as fit: 10 at 28 x 28 right cells, 4 at 40 x 40 (below the best mask)
-            const int band_rows = PROBE ? (s == 4 ? 4 : 10) : 8, halo = PROBE ? 0 : 1;
+            // bands are as many whole rows as fit: 10 at 28 x 28 right cells, 5 at 40 x 40
+            const int band_rows = PROBE ? (s == 4 ? 5 : 10) : 8, halo = PROBE ? 0 : 1;
             const int n_bands = BANDED ? (kLeftH + band_rows - 1) / band_rows : 1;
             for (int band = 0; band < n_bands; ++band) {
                 const int lo = BANDED ? band * band_rows : 0, hi = BANDED ? min(lo + band_rows, kLeftH) : kLeftH;      // own rows
@@ -1827,7 +1827,7 @@ __device__ __forceinline__ bool dense_scales_pair(const FilterParams& p, uint32_
         if (status != 0) return status;
         // the next scale lays its rows out differently: no header of this one may survive as a count byte
         for (uint32_t c = tid; c < (uint32_t)kLeftN; c += NT)
-            if (!BANDED || c < (uint32_t)((PROBE ? (s == 4 ? 4 : 10) : 10) * kLeftW)) smem[c * (stride >> 2)] = 0;
+            if (!BANDED || c < (uint32_t)((PROBE ? (s == 4 ? 5 : 10) : 10) * kLeftW)) smem[c * (stride >> 2)] = 0;
 
         if constexpr (PROBE) {  // ---- how many matches could be inliers at this scale at all
             uint32_t c0 = 0;
@@ -1840,9 +1840,11 @@ __device__ __forceinline__ bool dense_scales_pair(const FilterParams& p, uint32_
             for (int k = 0; k < KPT; ++k) code[k] &= ~(1u << kSProbeBit);
             __syncthreads();
             if (tid < 8) misc[tid] = 0;
-            if (tid == 0 && p.probe_stats != nullptr) atomicAdd(&p.probe_stats[bound > best_count ? 0 : 1], 1u);
+            // (a scale that comes BEFORE the best one in the reference's order would also win a tie)
+            const bool can_win = bound > best_count || (bound == best_count && s < best_scale);
+            if (tid == 0 && p.probe_stats != nullptr) atomicAdd(&p.probe_stats[can_win ? 0 : 1], 1u);
             GMS_STAMP(7);
-            return bound > best_count ? 0 : 3;
+            return can_win ? 0 : 3;
         }
         // ---- run() return value per rotation of this scale, getInlierMask's strict '>'
         {
@@ -1861,27 +1863,24 @@ __device__ __forceinline__ bool dense_scales_pair(const FilterParams& p, uint32_
             }
         }
         __syncthreads();  // counts complete; headers zeroed
+        // getInlierMask walks scale-outer, rotation-inner and keeps on strict '>': the first hypothesis with the largest count wins.
+        // Scale 1 is evaluated before scale 0 here (below), so a count that TIES the best replaces it when this scale comes
+        // before the best one's.
         int winner = -1;
 #pragma unroll
         for (int r = 0; r < kNRot; ++r) {
             const uint32_t c = misc[r];
-            if (c > best_count) {
+            if (c > best_count || (c == best_count && c != 0 && s < best_scale)) {
                 best_count = c;
                 best_scale = s;
                 best_rot = r + 1;
                 winner = r;
             }
         }
-        if (winner >= 0) {
+        if (winner >= 0) {  // the best hypothesis' inliers: one bit per match of the thread (a register -- scale 0's matrix fills the LDS)
+            bestbits = 0;
 #pragma unroll
-            for (int k = 0; k < KPT; ++k) {
-                const unsigned long long bsel = __ballot((code[k] >> (kSAccShift + winner)) & 1u);
-                if (lane == 0) {
-                    const int ch = k * (NT / 64) + wave;  // chunk of 64 consecutive matches
-                    bestmask[2 * ch] = (uint32_t)bsel;
-                    bestmask[2 * ch + 1] = (uint32_t)(bsel >> 32);
-                }
-            }
+            for (int k = 0; k < KPT; ++k) bestbits |= ((code[k] >> (kSAccShift + winner)) & 1u) << k;
         }
 #pragma unroll
         for (int k = 0; k < KPT; ++k) code[k] &= ~(0xFFu << kSAccShift);
@@ -1899,14 +1898,17 @@ __device__ __forceinline__ bool dense_scales_pair(const FilterParams& p, uint32_
         }
         return run_scale(banded_c, crowded_c, std::false_type{}, s);
     };
+    // Order: scale 1 first (the 10 x 10 grid collects at least as many matches per cell pair as the 20 x 20 one and usually has the
+    // largest count), then 0, 2, 3: whichever comes first sets the count the probes of the others are measured against, so with the
+    // usual winner first scale 0 can be bounded out as well.
     int status = spilled ? 1 : 0;
     bool crowded_mode = false;
-    for (int s = 0; s < 3 && status == 0; ++s) status = eval_scale(std::false_type{}, std::false_type{}, s);
+    for (int i = 0; i < 3 && status == 0; ++i) status = eval_scale(std::false_type{}, std::false_type{}, i == 0 ? 1 : (i == 1 ? 0 : 2));
     if (status == 0) status = eval_scale(std::true_type{}, std::false_type{}, 3);
     if (status == 1) {
         crowded_mode = true;
         // crowded (dense_pair has the same mode): everything again on a clean matrix, nLeft counted into 16-bit counters and
-        // every returned entry count checked; the cell populations do not depend on the scale, so this shows at scale 0
+        // every returned entry count checked; the cell populations do not depend on the scale, so this shows at the first scale
         __syncthreads();
         {
             const uint4 z4 = make_uint4(0, 0, 0, 0);
@@ -1916,15 +1918,15 @@ __device__ __forceinline__ bool dense_scales_pair(const FilterParams& p, uint32_
             if (tid < 8) misc[tid] = 0;
         }
 #pragma unroll
-        for (int k = 0; k < KPT; ++k) code[k] &= ~(0xFFu << kSAccShift);  // (the code words still hold scale 0's right cell: the check trips there)
-        best_count = 0;
+        for (int k = 0; k < KPT; ++k) code[k] &= ~(0xFFu << kSAccShift);
+        best_count = bestbits = 0;
         best_scale = best_rot = -1;
         __syncthreads();
         status = 0;
-        for (int s = 0; s < 3 && status == 0; ++s) status = eval_scale(std::false_type{}, std::true_type{}, s);
+        for (int i = 0; i < 3 && status == 0; ++i) status = eval_scale(std::false_type{}, std::true_type{}, i == 0 ? 1 : (i == 1 ? 0 : 2));
         if (status == 0) status = eval_scale(std::true_type{}, std::true_type{}, 3);
     }
-    // Scale 4 (40 x 40: 400 rows of 1604 bytes) is the hashed kernel's to evaluate -- but its probe runs here, on five bands of the
+    // Scale 4 (40 x 40: 400 rows of 1604 bytes) is the hashed kernel's to evaluate -- but its probe runs here, on four bands of the
     // byte matrix: when it bounds the scale out, the record says all five scales are decided and the hashed kernel only copies out;
     // when it does not, the record says so and the hashed kernel does not probe again.
     uint32_t decided = 4u;
@@ -1947,7 +1949,15 @@ __device__ __forceinline__ bool dense_scales_pair(const FilterParams& p, uint32_
         part[2] = (uint32_t)best_scale;
         part[3] = (uint32_t)best_rot;
     }
-    for (int i = tid; i < (kMcap >> 5); i += NT) part[kPartialHeaderDw + i] = best_count ? bestmask[i] : 0u;
+#pragma unroll
+    for (int k = 0; k < KPT; ++k) {  // the inlier bit of match k * NT + tid: chunk of 64 consecutive matches = one ballot
+        const unsigned long long bsel = __ballot((bestbits >> k) & 1u);
+        if (lane == 0) {
+            const int ch = k * (NT / 64) + wave;
+            part[kPartialHeaderDw + 2 * ch] = (uint32_t)bsel;
+            part[kPartialHeaderDw + 2 * ch + 1] = (uint32_t)(bsel >> 32);
+        }
+    }
     GMS_STAMP(9);  // record written
     GMS_STAMP_FLUSH;
     return true;
