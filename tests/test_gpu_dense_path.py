@@ -316,7 +316,7 @@ def test_scale_hypotheses_that_tie_keep_the_reference_order(ctx, oracle, rot, ji
     """Every match of an identity lattice is an inlier under more than one scale hypothesis: the counts tie at M, and the reference
     keeps the FIRST hypothesis with that count (scale 0). The kernel evaluates scale 1 before scale 0: the tie must go back to 0."""
     block = [y * 20 + x for y in range(4, 16) for x in range(4, 16)]
-    c = cases.lattice([(lc, lc, 12) for lc in block], jitter=jitter)
+    c = cases.lattice([(lc, lc, 40) for lc in block], jitter=jitter)   # (40 per cell: scales 0 and 1 both keep all 5760; 12 would not tie)
     got, res = ctx.match(c["size1"], c["size2"], c["kp1"], c["kp2"], c["matches"], rot, True, 6.0, return_result=True)
     assert len(got) == len(c["matches"]) and res["best_scale"] == 0 and res["best_rot"] == 1
     _check(ctx, oracle, c, rot, scale=True)
