@@ -285,3 +285,14 @@ def test_more_matches_in_one_cell_than_a_slot_counts(ctx, pkg):
     with pytest.raises(pkg.GmsError) as e:
         ctx.match((640, 480), (640, 480), kp, kp.copy(), m)
     assert e.value.code == -5
+
+
+def test_slab_kernel_alone_whole_file_again():
+    """GMS_BAND=0 (read once per process): large pairs skip the LDS band / tile kernels and run on the HBM-slab kernel alone. Same
+    bytes for everything in this file."""
+    import os
+    import subprocess
+    import sys
+    res = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-x", "-q", "-k", "not again"],
+                         capture_output=True, text=True, timeout=1500, env=dict(os.environ, GMS_BAND="0"))
+    assert res.returncode == 0, res.stdout[-3000:]

@@ -263,17 +263,18 @@ def test_probe_switches_to_dealing_on_ordered_input(pkg, oracle, synth):
 
 
 # ---- the scale probe (an upper bound of a scale's inlier count that lets the scale skip) ---------------------------------------------
-@pytest.mark.parametrize("setting", ["0", "1"])
+@pytest.mark.parametrize("setting", ["GMS_SCALE_PROBE=0", "GMS_SCALE_PROBE=1", "GMS_DENSE=0"])
 def test_scale_probe_setting_whole_file_again(setting):
-    """GMS_SCALE_PROBE=0 / 1 (read once per process): never probe / always probe scales 2..4. Skipping a scale whose bound cannot beat
-    the best count must not change a byte: this file, the parity sweep, the golden fixtures and the fuzz cases again."""
+    """GMS_SCALE_PROBE=0 / 1 (read once per process): never probe / always probe the scale hypotheses; GMS_DENSE=0: every pair on the
+    hashed kernel (which probes and evaluates in the reference's order). None of it may change a byte: this file, the parity sweep,
+    the golden fixtures and the fuzz cases again."""
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     files = [os.path.join(root, "tests", f) for f in ("test_gpu_dense_path.py", "test_gpu_parity.py", "test_golden.py", "test_gpu_fuzz.py")]
     res = subprocess.run([sys.executable, "-m", "pytest", *files, "-m", "gpu", "-x", "-q", "-k", "not again"], capture_output=True,
-                         text=True, timeout=1500, env=dict(os.environ, GMS_SCALE_PROBE=setting))
+                         text=True, timeout=1500, env=dict(os.environ, **dict([setting.split("=")])))
     assert res.returncode == 0, res.stdout[-3000:]
 
 
