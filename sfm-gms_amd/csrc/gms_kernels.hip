@@ -1600,10 +1600,10 @@ __device__ __forceinline__ bool dense_scales_pair(const FilterParams& p, uint32_
     // One scale hypothesis. BANDED (scale 3, 28 x 28 right cells: 400 rows of 788 bytes do not fit): the left grid's rows
     // are taken 8 at a time, each band with one halo row on either side in LDS (at most 10 rows = 157 600 bytes); per
     // grid type a band bins the matches of the rows it holds, verifies and marks its own rows' cells and takes every
-    // increment back before the next band.
-    // With rotation a lane verifies four of the eight rotations of its cell (two lanes per cell: item & 1 == tid & 1 picks
-    // rotations 0..3 or 4..7; the left side of the nine neighbour pairs is shared by the four). Where a rotation pattern sends the
-    // eight outer neighbours is a compile-time word (rotation_pack): the lane selects its four at the point of use.
+    // increment back before the next band. (Probes band differently: no halo, as many rows as fit; scale 4 only exists as a probe.)
+    // With rotation a lane verifies two of the eight rotations of its cell (four lanes per cell: sub = item & 3 picks rotations
+    // 2 sub, 2 sub + 1; the left side of the nine neighbour pairs is shared by the two). Where a rotation pattern sends the
+    // eight outer neighbours is a compile-time word (rotation_pack): the lane selects its two at the point of use.
 
     // PROBE: an upper bound of the scale's inlier count instead of the count itself. A match can only be an inlier of a
     // (scale, rotation) hypothesis if, under some grid type, its right cell IS the arg-max of its left cell's row -- whatever the
