@@ -348,7 +348,7 @@ void run_copy_jobs(const std::vector<CopyJob>& jobs)
     size_t total = 0;
     for (const CopyJob& j : jobs) total += j.bytes;
     unsigned hw = std::thread::hardware_concurrency();
-    const unsigned n_thr = (unsigned)std::min<size_t>(std::min<size_t>(hw ? hw : 4, 8), total / ((size_t)2 << 20) + 1);  // >= 2 MB per thread
+    const unsigned n_thr = (unsigned)std::min<size_t>(std::min<size_t>(hw ? hw : 4, 16), total / ((size_t)2 << 20) + 1);  // >= 2 MB per thread
     auto work = [&](unsigned t) {
         // thread t takes the byte range [t, t + 1) * total / n_thr of the concatenated jobs
         const size_t lo = total * t / n_thr, hi = total * (t + 1) / n_thr;
@@ -729,13 +729,13 @@ int gms_filter_host_batch(gms_ctx* c, const gms_keypoint* kp, const int64_t* fra
 
     // ---- the pipeline: chunk k rides lane k & 1 (upload -> filter -> download, stream-ordered); the host stages chunk k + 1
     //      into the other lane's pinned block meanwhile, and hands chunk k - 1's survivors to the caller's arrays
-    auto drain = [&](const Chunk& ch, Lane& L) -> int {
+    //      (the copies out of a lane's pinned block and the copies of the next chunk into it run as one batch of jobs)
+    std::vector<CopyJob> jobs;
+    auto drain = [&](const Chunk& ch, Lane& L) -> int {   // appends the chunk's copy-out jobs
         GMS_HIP(hipStreamSynchronize(L.stream));
         const gms_pair_result* res = (const gms_pair_result*)L.hout.p;
         const gms_dmatch* o = (const gms_dmatch*)((const char*)L.hout.p + out_res_bytes);
         size_t local = 0;
-        std::vector<CopyJob> jobs;
-        jobs.reserve((size_t)ch.count);
         for (int i = 0; i < ch.count; ++i) {
             const gms_pair& pr = pairs[ch.first + i];
             results[ch.first + i] = res[i];
@@ -743,19 +743,17 @@ int gms_filter_host_batch(gms_ctx* c, const gms_keypoint* kp, const int64_t* fra
                 jobs.push_back(CopyJob{out + pr.match_off, o + local, (size_t)res[i].n_inliers * sizeof(gms_dmatch)});
             local += (size_t)pr.m;
         }
-        run_copy_jobs(jobs);
         return GMS_OK;
     };
     for (size_t k = 0; k < chunks.size(); ++k) {
         const Chunk& ch = chunks[k];
         Lane& L = c->lane[k & 1];
+        jobs.clear();
         if (k >= 2) GMS_TRY(drain(chunks[k - 2], L));
         gms_pair* hp = (gms_pair*)L.hin.p;
         gms_dmatch* hm = (gms_dmatch*)((char*)L.hin.p + in_pairs_bytes);
         size_t local = 0;
         int chunk_max_m = 0;
-        std::vector<CopyJob> jobs;
-        jobs.reserve((size_t)ch.count);
         for (int i = 0; i < ch.count; ++i) {
             const gms_pair& pr = pairs[ch.first + i];
             hp[i] = gms_pair{pr.frame_a, pr.frame_b, pr.m, 0, (int64_t)local};
@@ -770,7 +768,9 @@ int gms_filter_host_batch(gms_ctx* c, const gms_keypoint* kp, const int64_t* fra
                               threshold_factor, (gms_dmatch*)((char*)L.dout.p + out_res_bytes), (gms_pair_result*)L.dout.p, nullptr));
         GMS_HIP(hipMemcpyAsync(L.hout.p, L.dout.p, out_res_bytes + local * sizeof(gms_dmatch), hipMemcpyDeviceToHost, L.stream));
     }
+    jobs.clear();
     for (size_t k = chunks.size() >= 2 ? chunks.size() - 2 : 0; k < chunks.size(); ++k) GMS_TRY(drain(chunks[k], c->lane[k & 1]));
+    run_copy_jobs(jobs);
     return GMS_OK;
 }
 
