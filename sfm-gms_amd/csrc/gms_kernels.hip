@@ -168,10 +168,15 @@ constexpr int kDCellShift = 18;                      // without rotation only, b
 //          type 1 : 9] -- q and the edge bits are the low bits of the dense code word as they stand (kDEdgeX / kDEdgeY one place
 //          up). Cell values above the grid: kLCellNever (the point is binned under no grid type), kLCellBad (outside the parity
 //          domain: negative, non-finite or >= 2^20 after normalisation);
-//   rcode  the keypoint as a RIGHT point: E(r) = 403 - r of scale 0 (0 = outside the 20 x 20 grid); top bit: outside the domain.
+//   rcode  the keypoint as a RIGHT point: E(r) = 403 - r of scale 0 (0 = outside the 20 x 20 grid); top bit: outside the domain;
+//   scode  the keypoint as a RIGHT point under scale hypotheses, 32 bits: [cell on the 20 x 20 grid : 9 | cell on the 28 x 28
+//          grid : 10 | low bit of the 40 x 40 cell's x, y : 2] -- the 10 x 10, 14 x 14 and 40 x 40 cells follow from these
+//          (fl(10 n) = fl(20 n) / 2, fl(14 n) = fl(28 n) / 2, fl(40 n) = 2 fl(20 n) + bit, exactly); kSCodeBad: outside the domain or
+//          outside one of the grids coordinate-wise (the reference has no bounds test there: such a pair takes the general path).
 constexpr uint32_t kLCellShift = 7, kLCellNever = 510u, kLCellBad = 511u;
 constexpr uint32_t kRCodeBad = 1u << 15;
-__device__ __forceinline__ void keypoint_codes(float2 n, uint16_t& lcode, uint16_t& rcode)
+constexpr uint32_t kSCodeBad = 1u << 31;
+__device__ __forceinline__ void keypoint_codes(float2 n, uint16_t& lcode, uint16_t& rcode, uint32_t& scode)
 {
     const bool bad = max(__float_as_uint(n.x), __float_as_uint(n.y)) >= 0x49800000u;
     const float x = bad ? 0.0f : n.x, y = bad ? 0.0f : n.y;
@@ -185,6 +190,10 @@ __device__ __forceinline__ void keypoint_codes(float2 n, uint16_t& lcode, uint16
     const uint32_t r0x = (uint32_t)(int)fx, r0y = (uint32_t)(int)fy;              // getGridIndexRight, 20 x 20 (DLL@0x180047d60)
     const uint32_t e0 = (r0x < 20u && r0y < 20u) ? 403u - (r0y * 20u + r0x) : 0u;
     rcode = (uint16_t)(e0 | (bad ? kRCodeBad : 0u));
+    const uint32_t r3x = (uint32_t)(int)(28.0f * x), r3y = (uint32_t)(int)(28.0f * y);
+    const uint32_t odd40 = ((uint32_t)(int)(40.0f * x) & 1u) | (((uint32_t)(int)(40.0f * y) & 1u) << 1);
+    const bool in_grids = r0x < 20u && r0y < 20u && r3x < 28u && r3y < 28u;
+    scode = (bad || !in_grids) ? kSCodeBad : ((r0y * 20u + r0x) | ((r3y * 28u + r3x) << 9) | (odd40 << 19));
 }
 
 __global__ void __launch_bounds__(256)
@@ -193,6 +202,7 @@ normalize_kernel(const char* __restrict__ kp, int kp_stride, const int64_t* __re
 {
     uint16_t* __restrict__ lcode = reinterpret_cast<uint16_t*>(pts + total);
     uint16_t* __restrict__ rcode = lcode + total;
+    uint32_t* __restrict__ scode = reinterpret_cast<uint32_t*>(rcode + total);
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (; i < total; i += stride) {
@@ -208,9 +218,11 @@ normalize_kernel(const char* __restrict__ kp, int kp_stride, const int64_t* __re
         o.y = p[1] / h + 0.0f;
         pts[i] = o;
         uint16_t lc, rc;
-        keypoint_codes(o, lc, rc);
+        uint32_t sc;
+        keypoint_codes(o, lc, rc, sc);
         lcode[i] = lc;
         rcode[i] = rc;
+        scode[i] = sc;
     }
 }
 
@@ -1485,13 +1497,14 @@ __device__ __forceinline__ bool dense_scales_pair(const FilterParams& p, uint32_
     const int64_t offA = p.frame_off[pr.frame_a], offB = p.frame_off[pr.frame_b];
     const int nA = (int)(p.frame_off[pr.frame_a + 1] - offA), nB = (int)(p.frame_off[pr.frame_b + 1] - offB);
     if (nA <= 0 || nB <= 0) return false;
-    const bool stage_b = (uint32_t)nB * 8u <= kDenseBytes;  // workgroup-uniform
-    const float2* __restrict__ ptsA = p.pts + offA;
-    const float2* __restrict__ ptsB = p.pts + offB;
     const gms_dmatch* __restrict__ matches = p.matches + pr.match_off;
+    // the frame table's code words (normalize_kernel): frame A's left codes (16 bits), frame B's scale codes (32 bits)
+    const int64_t total_kp = p.frame_off[p.n_frames];
+    const uint16_t* __restrict__ lcodeA = reinterpret_cast<const uint16_t*>(p.pts + total_kp) + offA;
+    const uint32_t* __restrict__ scodeB = reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint16_t*>(p.pts + total_kp) + 2 * total_kp) + offB;
 
     const uint8_t* dense8 = reinterpret_cast<const uint8_t*>(smem);
-    uint32_t* nfine32 = smem + kDenseFineOff / 4;
+    uint32_t* nfine32 = smem + kDenseFineOff / 4;   // half-cell histogram: one dword per cell of grid type 1, a byte per half cell (as in dense_pair)
     const uint8_t* nfine8 = reinterpret_cast<const uint8_t*>(nfine32);
     uint8_t* nleft8 = reinterpret_cast<uint8_t*>(smem) + kDenseNleftOff;
     uint32_t* misc = smem + kDenseMiscOff / 4;
@@ -1502,78 +1515,72 @@ __device__ __forceinline__ bool dense_scales_pair(const FilterParams& p, uint32_
     if (tid < 16) trash[tid] = 0;
     if (tid < kFineN / 4) nfine32[tid] = 0;
 
-    constexpr int kStageRegs = 10;
-    float2 tb[kStageRegs];
-    if (stage_b) {
+    // ---- both frames' codes staged in the still unused matrix area, then the pair's (queryIdx, trainIdx) (see dense_pair)
+    const uint32_t phA = (uint32_t)(reinterpret_cast<uintptr_t>(lcodeA) >> 1) & 7u, phB = (uint32_t)(reinterpret_cast<uintptr_t>(scodeB) >> 2) & 3u;
+    const uint32_t qA = (phA + (uint32_t)nA + 7u) >> 3, qB = (phB + (uint32_t)nB + 3u) >> 2;  // uint4s of either copy
+    const bool staged = (qA + qB) * 16u <= kDenseBytes;  // workgroup-uniform
+    const uint4* __restrict__ srcA = reinterpret_cast<const uint4*>(lcodeA - phA);
+    const uint4* __restrict__ srcB = reinterpret_cast<const uint4*>(scodeB - phB);
+    constexpr int kStageRegs = 4;  // 64 KB of codes (10 900 keypoints a frame) through registers; larger frames finish in a plain loop
+    uint4 tb[kStageRegs];
 #pragma unroll
-        for (int i = 0; i < kStageRegs; ++i) tb[i] = ptsB[min(i * NT + tid, nB - 1)];
+    for (int i = 0; i < kStageRegs; ++i) {  // (unconditional: a pair too large to stage just reads a few code words it does not use)
+        const uint32_t j = min((uint32_t)(i * NT + tid), qA + qB - 1u);
+        const uint4* src = j < qA ? srcA + j : srcB + (j - qA);
+        tb[i] = *src;
     }
     uint2 qt[KPT];
 #pragma unroll
     for (int k = 0; k < KPT; ++k) qt[k] = *reinterpret_cast<const uint2*>(&matches[min(k * NT + tid, m - 1)]);
-    const uint32_t staged16 = stage_b ? ((uint32_t)nB * 8u + 15u) >> 4 : 0u;
+    const uint32_t staged16 = staged ? qA + qB : 0u;
     {
         const uint4 z4 = make_uint4(0, 0, 0, 0);
         uint4* d4 = reinterpret_cast<uint4*>(smem);
         for (uint32_t i = staged16 + tid; i < kDenseBytes / 16; i += NT) d4[i] = z4;
     }
-    float2* lds_b = reinterpret_cast<float2*>(smem);
-    if (stage_b) {
+    if (staged) {
+        uint4* d4 = reinterpret_cast<uint4*>(smem);
 #pragma unroll
         for (int i = 0; i < kStageRegs; ++i)
-            if (i * NT + tid < nB) lds_b[i * NT + tid] = tb[i];
-        for (int j = kStageRegs * NT + tid; j < nB; j += NT) lds_b[j] = ptsB[j];
+            if ((uint32_t)(i * NT + tid) < qA + qB) d4[i * NT + tid] = tb[i];
+        for (uint32_t j = kStageRegs * NT + tid; j < qA + qB; j += NT) d4[j] = *(j < qA ? srcA + j : srcB + (j - qA));
     }
+    const uint16_t* ldsA = reinterpret_cast<const uint16_t*>(smem) + phA;  // left code of frame A's keypoint q at ldsA[q]
+    const uint32_t* ldsB = smem + 4u * qA + phB;                           // scale code of frame B's keypoint t at ldsB[t]
     __syncthreads();
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (see dense_pair: the left-side gathers go out together)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
-    GMS_STAMP(4);  // records and frame B landed
-    // code word as in dense_pair (E = E(r) of the current scale, 10 bits); cell1 = left cell under grid type 1; rs = the
-    // right cells of scales 1, 2 and 3 (bits 0..7, 8..15, 16..25)
-    uint32_t code[KPT], aux[KPT];  // aux = left cell under grid type 1 : 9 | right cell on the 20 x 20 grid : 9 | on the 28 x 28 grid : 10 |
-                                   //       low bit of the 40 x 40 cell's x, y : 2 (the rest of it is twice the 20 x 20 cell's)
+    GMS_STAMP(4);  // indices landed, codes staged
+    // code word as in dense_pair (E = E(r) of the current scale, 10 bits); aux = left cell under grid type 1 : 9 | right cell on the
+    // 20 x 20 grid : 9 | on the 28 x 28 grid : 10 | low bit of the 40 x 40 cell's x, y : 2 (the scale code as it stands, 9 bits up)
+    uint32_t code[KPT], aux[KPT];
     {
-        float2 a[KPT], b[KPT];
+        uint32_t ca[KPT], cb[KPT];
+        if (staged) {
 #pragma unroll
-        for (int k = 0; k < KPT; ++k) a[k] = ptsA[min(qt[k].x, (uint32_t)(nA - 1))];
-        if (stage_b) {
+            for (int k = 0; k < KPT; ++k) ca[k] = ldsA[min(qt[k].x, (uint32_t)(nA - 1))];
 #pragma unroll
-            for (int k = 0; k < KPT; ++k) b[k] = lds_b[min(qt[k].y, (uint32_t)(nB - 1))];
+            for (int k = 0; k < KPT; ++k) cb[k] = ldsB[min(qt[k].y, (uint32_t)(nB - 1))];
         } else {
 #pragma unroll
-            for (int k = 0; k < KPT; ++k) b[k] = ptsB[min(qt[k].y, (uint32_t)(nB - 1))];
+            for (int k = 0; k < KPT; ++k) ca[k] = lcodeA[min(qt[k].x, (uint32_t)(nA - 1))];
+#pragma unroll
+            for (int k = 0; k < KPT; ++k) cb[k] = scodeB[min(qt[k].y, (uint32_t)(nB - 1))];
         }
         bool any_bad = false, spill = false;
 #pragma unroll
         for (int k = 0; k < KPT; ++k) {
             const bool live = k * NT + tid < m;
-            const uint32_t worst = max(max(__float_as_uint(a[k].x), __float_as_uint(a[k].y)),
-                                       max(__float_as_uint(b[k].x), __float_as_uint(b[k].y)));
-            const float fx = 20.0f * a[k].x, fy = 20.0f * a[k].y;   // mulss, rounded to fp32
-            const uint32_t hx = (uint32_t)(int)(fx + fx), hy = (uint32_t)(int)(fy + fy);  // floor(2f), 2f exact
-            // getGridIndexRight per scale: (int)(wr * x) + (int)(wr * y) * wr, no bounds test (clamped 24-bit form: see dense_pair)
-            uint32_t r[4];
-            bool in_grid = true;
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const uint32_t wr = s == 0 ? 20u : s == 1 ? 10u : s == 2 ? 14u : 28u;
-                const float fw = (float)wr;
-                const uint32_t rx = (uint32_t)(int)(fw * b[k].x), ry = (uint32_t)(int)(fw * b[k].y);
-                r[s] = __umul24(min(ry, 4096u), wr) + min(rx, 4096u);
-                in_grid = in_grid && r[s] < wr * wr;
-            }
-            const bool ok = ((int)(qt[k].x < (uint32_t)nA) & (int)(qt[k].y < (uint32_t)nB) & (int)(worst < 0x49800000u) & (int)in_grid) != 0;
-            const bool binned = live & ok & (max(hx, hy) < 40u);
-            const uint32_t f = binned ? __umul24(hy, (uint32_t)kFineW) + hx : 0u;
-            const uint32_t old = atomicAdd(binned ? &nfine32[f >> 2] : &trash[lane & 7], 1u << ((f << 3) & 31u));
-            spill |= binned & (((old >> ((f << 3) & 31u)) & 255u) == 255u);
+            const uint32_t cell = ca[k] >> kLCellShift;  // under grid type 1; kLCellNever / kLCellBad above the grid
+            const bool ok = ((int)(qt[k].x < (uint32_t)nA) & (int)(qt[k].y < (uint32_t)nB) & (int)(cell != kLCellBad) & (int)((cb[k] & kSCodeBad) == 0u)) != 0;
+            const bool binned = live & ok & (cell < kLCellNever);
+            const uint32_t sh = ((ca[k] & 1u) << 3) | ((ca[k] & 4u) << 2);  // byte (hx & 1) + 2 (hy & 1) of the cell's dword
+            const uint32_t old = atomicAdd(binned ? &nfine32[cell] : &trash[lane & 7], 1u << sh);
+            spill |= binned & (((old >> sh) & 255u) == 255u);
             any_bad |= live & !ok;
-            const uint32_t q = (hx & 1u) + __umul24(hy & 1u, 20u);
-            const uint32_t edge = ((hx + 25u) & kDEdgeX) | ((hy + 89u) & kDEdgeY);
-            code[k] = binned ? (q | edge | ((403u - r[0]) << kDEShift)) : kDNever;
-            // (the 10 x 10 and 14 x 14 cells follow from the 20 x 20 and 28 x 28 ones: fl(10 n) = fl(20 n) / 2 exactly, and 14 / 28 alike)
-            const uint32_t odd40 = ((uint32_t)(int)(40.0f * b[k].x) & 1u) | (((uint32_t)(int)(40.0f * b[k].y) & 1u) << 1);
-            aux[k] = binned ? ((__umul24(hy >> 1, (uint32_t)kLeftW) + (hx >> 1)) | (r[0] << 9) | (r[3] << 18) | (odd40 << 28)) : 0u;
+            const uint32_t r0 = cb[k] & 0x1FFu;
+            code[k] = binned ? ((ca[k] & 31u) | ((ca[k] & 0x60u) << 1) | ((403u - r0) << kDEShift)) : kDNever;
+            aux[k] = binned ? (cell | ((cb[k] & 0x1FFFFFu) << 9)) : 0u;
         }
         if (any_bad) misc[8] = 1;
         if (spill) misc[13] = 1;  // (not misc[11]: that one is written again while slower waves may still be reading this)
@@ -1650,7 +1657,7 @@ __device__ __forceinline__ bool dense_scales_pair(const FilterParams& p, uint32_
             uint32_t* nl32cur = nl32 + (g & 1) * (kLeftN / 2);
             const uint16_t* nl16cur = reinterpret_cast<const uint16_t*>(nl32cur);
             if (!CROWDED && tid < kLeftN) {
-                const uint32_t n = dense_nleft(nfine8, tid % kLeftW, tid / kLeftW, gx, gy);
+                const uint32_t n = dense_nleft_cm(nfine8, tid % kLeftW, tid / kLeftW, gx, gy);
                 if (n > 255u) misc[11] = 1;
                 nleft8[tid] = (uint8_t)n;
             }
