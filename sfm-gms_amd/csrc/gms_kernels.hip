@@ -885,23 +885,8 @@ __device__ __forceinline__ bool dense_threshold_rejects(uint32_t T, uint32_t n, 
     return threshold_rejects(T, n, score, factor, fast_ok);
 }
 
-// mNumberPointsInPerCellLeft of cell (x, y) under the grid type shifted by (gx, gy) half cells
-__device__ __forceinline__ uint32_t dense_nleft(const uint8_t* nfine8, int x, int y, int gx, int gy)
-{
-    const int hx0 = 2 * x - gx, hy0 = 2 * y - gy;  // hx0 + 1, hy0 + 1 <= 39
-    uint32_t n = 0;
-#pragma unroll
-    for (int dy = 0; dy < 2; ++dy)
-#pragma unroll
-        for (int dx = 0; dx < 2; ++dx) {
-            const int hx = hx0 + dx, hy = hy0 + dy;
-            const uint32_t v = nfine8[max(hy, 0) * kFineW + max(hx, 0)];
-            n += (hx >= 0 && hy >= 0) ? v : 0u;
-        }
-    return n;
-}
-
-// The same for dense_pair's histogram, which is laid out by cell: one dword per cell of grid type 1, its four half cells in the
+// mNumberPointsInPerCellLeft of cell (x, y) under the grid type shifted by (gx, gy) half cells, from the half-cell histogram --
+// which is laid out by cell: one dword per cell of grid type 1, its four half cells in the
 // four bytes (byte index (hx & 1) + 2 (hy & 1)) -- the index a left code word yields without arithmetic.
 __device__ __forceinline__ uint32_t dense_nleft_cm(const uint8_t* nfine8, int x, int y, int gx, int gy)
 {
