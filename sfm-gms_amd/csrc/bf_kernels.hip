@@ -7,18 +7,19 @@
 // (frame_a, frame_b) gets its n(frame_a) matches written at d_matches[match_off ...] -- straight into the batch's match
 // array, so the matches never cross PCIe.
 //
-//   NORM_HAMMING, 256-bit rows (ORB)   bf_hamming_kernel: integer VALU. A lane keeps Q query rows in registers; the train
-//       rows are wave-uniform, so they arrive through the SCALAR cache (s_load_dwordx8) and feed v_xor / v_bcnt directly
-//       as SGPR operands: no LDS, no vector loads in the loop. 18 VALU instructions per (query, train): 8 xor, 8 popcount-
-//       accumulate, one shift-or that packs (distance, trainIdx), one unsigned min (lowest trainIdx wins ties for free).
-//   NORM_L2, 128 floats (SIFT)         bf_l2_mfma_kernel: d^2 = |a|^2 + |b|^2 - 2 a.b with the cross term on the matrix cores
-//       (v_mfma_f32_32x32x16_bf16, train rows x query columns, K = 128). SIFT descriptors are integers 0..255 stored as
-//       floats: exact in bf16 (8 significant bits), every product and partial sum below 2^24 is exact in the fp32
-//       accumulator, so d^2 is the exact integer the reference's fp32 loop produces, in any summation order -- the
-//       arg-min and sqrtf(d^2) are bit-identical. gms_bf_prepare_device checks that property per frame while it builds the
-//       bf16 table and the norms; a pair with a frame that fails it takes
+//   bf_mfma_kernel<true>               NORM_HAMMING, 256-bit rows (ORB), with a prepared block: the bits as FP4 elements on
+//       v_mfma_scale_f32_32x32x64_f8f6f4, the arg-min riding in the accumulator's fraction (details at the kernel).
+//   bf_mfma_kernel<false>              NORM_L2, 128 floats (SIFT): SIFT descriptors are integers 0..255 stored as floats; as int8
+//       (a - 128 on the train side, 127 - b on the query side) the cross term of d^2 runs on v_mfma_i32_32x32x32_i8 and a short
+//       exact search of the winning 32-row block settles the arg-min; d^2 is the exact integer the reference's fp32 loop produces
+//       (every partial sum below 2^24), so sqrtf(d^2) is bit-identical. gms_bf_prepare_device checks the integer property per
+//       frame while it builds the int8 table; a pair with a frame that fails it takes
 //   bf_l2_loop_kernel                  the reference's own arithmetic, sum_k (a_k - b_k)^2 in fp32 in index order (no FMA
 //       contraction), one lane per query, train rows broadcast from LDS. Slow and exact; also any dimension other than 128.
+//   bf_hamming_kernel                  NORM_HAMMING without a prepared block: integer VALU. A lane keeps Q query rows in registers;
+//       the train rows are wave-uniform, so they arrive through the SCALAR cache (s_load_dwordx8) and feed v_xor / v_bcnt directly
+//       as SGPR operands: no LDS, no vector loads in the loop. 18 VALU instructions per (query, train): 8 xor, 8 popcount-
+//       accumulate, one shift-or that packs (distance, trainIdx), one unsigned min (lowest trainIdx wins ties for free).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
