@@ -10,8 +10,11 @@
 //               returning atomic per match, verification reads neighbour counts directly, the DMatch records
 //               stay in registers from load to copy-out. Described in front of dense_pair() below. Pairs that
 //               do not qualify are handed to hash_pair() by the same workgroup before anything is written.
-//   filter_kernel / hash_pair()          everything else (scale hypotheses, crowded cells): the matrix has at
-//               most M non-zeros and is kept as a hash table --
+//   filter_kernel_dense_scales / dense_scales_pair()   scale hypotheses on the same byte matrix with a runtime row stride:
+//               scales 0..3 evaluated (scale 1 first), every later one -- and scale 4 -- bounded first by a probe that bins
+//               without verifying and lets a scale skip when it cannot win; leaves a per-pair record for
+//   filter_kernel / hash_pair()          everything else (scale 4 when it has to be evaluated, crowded cells, the fallback of
+//               both kernels above): the matrix has at most M non-zeros and is kept as a hash table --
 //
 //   code[KPT]   (registers) one dword per match: right cell of the current scale, half-cell index of the
 //               left point (it carries the left cell under all four grid types), 8 per-rotation inlier bits
