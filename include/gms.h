@@ -121,7 +121,7 @@ int  gms_ctx_reserve(gms_ctx* ctx, int n_pairs, int max_m, int with_rotation, in
  * frame: d_pts[2*i] = kp[i].x / (float)w[frame], d_pts[2*i+1] = kp[i].y / (float)h[frame]
  * (IEEE fp32 divide). d_frame_off has n_frames+1 entries (keypoint offsets), d_wh 2*n_frames ints.
  * d_pts is the frame table the filter works from and needs gms_frame_table_bytes(total_kp) bytes (16 per keypoint + 16):
- * the normalised points (8 bytes each), then two 32-bit cell-code words per keypoint -- everything about a keypoint that does
+ * the normalised points (8 bytes each), then 8 bytes of cell codes per keypoint -- everything about a keypoint that does
  * not depend on the pair it is matched in (its cells on the left grid's four half-cell shifted types and on the right grids of
  * setScale) is worked out once per frame here, not once per pair. Opaque beyond the points; always pass it back whole. */
 int64_t gms_frame_table_bytes(int64_t total_kp);
