@@ -291,8 +291,10 @@ __device__ __forceinline__ void hash_pair(const FilterParams& p, uint32_t* smem,
     const bool probed4 = (part0 >> 4) != 0;                      //   "scale 4 was probed and cannot be bounded out"
     const bool resumed = scales_done != 0;
     for (int i = tid; i < (kMcap >> 5); i += NT) bestmask[i] = resumed ? part[kPartialHeaderDw + i] : 0u;
-    for (int i = tid; i < kFineStride; i += NT) nfine[i] = 0;
-    for (int i = tid; i < 4 * kFineStride; i += NT) fdesc4[i] = 0;
+    if (scales_done < (p.with_scale ? 5 : 1)) {  // (a pair whose scales are all decided goes straight to the copy-out and touches neither)
+        for (int i = tid; i < kFineStride; i += NT) nfine[i] = 0;
+        for (int i = tid; i < 4 * kFineStride; i += NT) fdesc4[i] = 0;
+    }
 
     const bool bad_pair = m < 0 || m > kMcap || pr.frame_a < 0 || pr.frame_a >= p.n_frames ||
                           pr.frame_b < 0 || pr.frame_b >= p.n_frames;
