@@ -71,7 +71,7 @@ typedef struct gms_pair_result {
     int32_t n_inliers;  /* number of gms_dmatch written for this pair                           */
     int32_t best_scale; /* 0..4 index into {1, 1/2, 1/sqrt2, sqrt2, 2}; -1 if no hypothesis won  */
     int32_t best_rot;   /* 1..8 rotation pattern; -1 if no hypothesis won                        */
-    int32_t status;     /* GMS_OK or GMS_ERR_DOMAIN for this pair                                */
+    int32_t status;     /* GMS_OK, GMS_ERR_DOMAIN (input outside the reference's domain) or GMS_ERR_BAD_ARG (the pair's match range overlaps another pair's) */
 } gms_pair_result;
 
 typedef struct gms_ctx gms_ctx;
@@ -108,6 +108,15 @@ int  gms_ctx_synchronize(gms_ctx* ctx);
  * given flags. After it, such calls neither allocate nor synchronise -- they are pure stream-ordered launches and can
  * be captured into a hipGraph. May allocate and synchronise itself. */
 int  gms_ctx_reserve(gms_ctx* ctx, int n_pairs, int max_m, int with_rotation, int with_scale);
+/* What the context's most recent gms_filter_device launch ran with, for reports (bench.py prints them beside its numbers). The
+ * library picks between bit-identical kernel variants from what earlier launches of the context saw: a probe kernel behind
+ * every sixteenth launch writes a verdict, and the first later launch that finds that kernel complete adopts it. */
+#define GMS_QUERY_LAST_DEALT        1 /* 1: the byte-matrix kernel dealt the matches to its lanes (inputs in spatial order) */
+#define GMS_QUERY_LAST_SCALE_PROBE  2 /* bit s set: scale hypothesis s was bounded by a probe before being evaluated       */
+#define GMS_QUERY_LAST_KPT          3 /* matches per thread of the workgroup kernel (0: the large-pair kernels ran)        */
+#define GMS_QUERY_LAUNCHES          4 /* filter launches of the context so far                                             */
+#define GMS_QUERY_CUS               5 /* compute units of the context's device                                             */
+int  gms_ctx_query(gms_ctx* ctx, int what, int64_t* value);
 
 /* ---- device-resident batch path (throughput API) ---------------------------------------------
  * All d_* pointers are device pointers on the context's device; calls are stream-ordered on the
@@ -120,10 +129,14 @@ int  gms_ctx_reserve(gms_ctx* ctx, int n_pairs, int max_m, int with_rotation, in
  * gms_normalize_device: GMSMatcher::normalizePoints (DLL@0x180048420) for every keypoint of every
  * frame: d_pts[2*i] = kp[i].x / (float)w[frame], d_pts[2*i+1] = kp[i].y / (float)h[frame]
  * (IEEE fp32 divide). d_frame_off has n_frames+1 entries (keypoint offsets), d_wh 2*n_frames ints.
- * d_pts is the frame table the filter works from and needs gms_frame_table_bytes(total_kp) bytes (16 per keypoint + 16):
- * the normalised points (8 bytes each), then 8 bytes of cell codes per keypoint -- everything about a keypoint that does
- * not depend on the pair it is matched in (its cells on the left grid's four half-cell shifted types and on the right grids of
- * setScale) is worked out once per frame here, not once per pair. Opaque beyond the points; always pass it back whole. */
+ * d_pts is the frame table the filter works from and needs gms_frame_table_bytes(total_kp) bytes (16 per keypoint + 32):
+ * a 16-byte header (GMS_FRAME_TABLE_HEADER_BYTES: a magic word and total_kp, so that the table describes itself), the
+ * normalised points (8 bytes each, point i at float index 4 + 2 i), then 8 bytes of cell codes per keypoint -- everything
+ * about a keypoint that does not depend on the pair it is matched in (its cells on the left grid's four half-cell shifted
+ * types and on the right grids of setScale) is worked out once per frame here, not once per pair. Opaque beyond the points;
+ * always pass the block back whole (16-byte aligned). gms_filter_device may be given any n_frames / d_frame_off whose frames lie
+ * inside the table (a prefix of the frames, say): where the code arrays are is read from the header, not derived from the call. */
+#define GMS_FRAME_TABLE_HEADER_BYTES 16
 int64_t gms_frame_table_bytes(int64_t total_kp);
 int gms_normalize_device(gms_ctx* ctx, const gms_keypoint* d_kp, const int64_t* d_frame_off,
                          const int32_t* d_wh, int n_frames, int64_t total_kp, float* d_pts);
@@ -132,7 +145,12 @@ int gms_normalize_device(gms_ctx* ctx, const gms_keypoint* d_kp, const int64_t* 
  * 0x180047dc0, 0x180048630, 0x180048d10, 0x180048340) for n_pairs independent pairs.
  *   d_pts/d_frame_off  normalised keypoint table from gms_normalize_device
  *   d_pairs            n_pairs descriptors; max_m >= every d_pairs[i].m (host-known upper bound)
- *   d_matches          putative matches, pair i at [match_off, match_off+m)
+ *   d_matches          putative matches, pair i at [match_off, match_off+m). The ranges of a batch's pairs must be DISJOINT
+ *                      (empty pairs aside): pair i's survivors are written over the head of the same range of d_out, so
+ *                      overlapping ranges would make pairs overwrite each other. Validated on the device behind the first launch
+ *                      of a context and every sixteenth (every launch with GMS_CHECK_PAIRS=1): every pair whose range
+ *                      overlaps another's gets status GMS_ERR_BAD_ARG in d_results (gms_filter_host_batch validates every call
+ *                      on the host and returns GMS_ERR_BAD_ARG).
  *   d_out              same offsets/capacity; pair i's survivors are written at d_out[match_off ...]
  *   d_results          n_pairs result records
  *   d_mask             optional (may be NULL): per-match inlier byte (0/1) at the match's offset */

@@ -44,6 +44,8 @@ def load():
     lib.gms_ref_grid_index_right.restype = i32
     lib.gms_ref_right_grid.argtypes = [i32, C.POINTER(i32), C.POINTER(i32)]
     lib.gms_ref_right_grid.restype = None
+    lib.gms_ref_right_grid_from.argtypes = [i32, i32, i32, C.POINTER(i32), C.POINTER(i32)]
+    lib.gms_ref_right_grid_from.restype = None
     lib.gms_ref_normalize.argtypes = [C.c_float, i32]
     lib.gms_ref_normalize.restype = C.c_float
     lib.gms_ref_threshold_rejects.argtypes = [i32, i32, i32, dbl]
@@ -52,6 +54,8 @@ def load():
     lib.gms_ref_assign_pairs.restype = i32
     lib.gms_ref_verify_cells.argtypes = [vp, vp, i32, i32, i32, dbl, vp]
     lib.gms_ref_verify_cells.restype = i32
+    lib.gms_ref_neighbors.argtypes = [i32, i32, vp]
+    lib.gms_ref_neighbors.restype = None
     lib.gms_ref_scale_ratio.argtypes = [i32]
     lib.gms_ref_scale_ratio.restype = dbl
     lib.disp_ref_map_and_rms.argtypes = [vp, i32, vp, i32, vp, i32, i32, i32, vp, i32, vp, vp, vp, vp, vp]
@@ -133,6 +137,14 @@ def assign_pairs(p1, p2, matches, wr, hr):
     rc = lib.gms_ref_assign_pairs(p1.ctypes.data, p2.ctypes.data, mt.ctypes.data, m, int(wr), int(hr),
                                   pairs.ctypes.data, nleft.ctypes.data, motion.ctypes.data)
     return rc, pairs, nleft, motion
+
+
+def neighbors(gw, gh):
+    """initalizeNeighbors / getNB9 for a gw x gh grid: int32 [gw * gh, 9]."""
+    lib = load()
+    out = np.zeros((gw * gh, 9), dtype=np.int32)
+    lib.gms_ref_neighbors(int(gw), int(gh), out.ctypes.data)
+    return out
 
 
 def verify_cells(motion, nleft, wr, hr, rotation_type, factor=6.0):

@@ -22,9 +22,16 @@
  *     GMSMatcher::verifyCellPairs after its cv::sum(row) test (DLL@0x180048e12) was executed out of the DLL one
  *     cell at a time for rotation types 1..8 on nine motion matrices (all five right grids, four factors);
  *     tests/golden/refdll_verify_cells.npz holds mCellPairs and gms_ref_verify_cells() must reproduce it;
+ *   - init_neighbors (getNB9 / initalizeNeighbors): the DLL's own initalizeNeighbors was executed (its operator new / delete
+ *     pointed at this process's allocator) for the left grid, the five right grids of setScale and three odd grids;
+ *     tests/golden/refdll_nb9.npz holds the tables, gms_ref_neighbors() must reproduce them -- and the verify fragment
+ *     above consumed THOSE tables, not restated ones;
  *   - the rotation-pattern table, the scale-ratio table and the 0.5 constant: compared byte for byte with the DLL
  *     by tests/test_oracle_pins.py when /root/reference exists.
- * Everything else (normalizePoints, getNB9, setScale, the loops of run and getInlierMask) follows the DLL's
+ *   - normalize_points: GMSMatcher::normalizePoints executed out of the DLL on cv::KeyPoint records of eight image sizes
+ *     (tests/golden/refdll_normalize.npz); set_scale's arithmetic: the head of GMSMatcher::setScale executed up to its first
+ *     import, after the DLL's own static initialiser of mScaleRatios (tests/golden/refdll_setscale.npz).
+ * What is left (the loops of run and getInlierMask, matchGMS's copy-out) follows the DLL's
  * disassembly address by address (cited per function, "DLL@0x..." = virtual address in that DLL, image base
  * 0x180000000) and keeps the reference's dense 400 x N_right motion matrix and
  * loop order on purpose, so that it is an obviously faithful, structurally independent checker for the sparse
@@ -88,7 +95,24 @@ typedef struct {
     unsigned char* mask;       /* mvbInlierMask                                                */
     double threshold_factor;
     int domain_error;
+    unsigned char* best_mask;  /* getInlierMask's copy of the best mask                        */
+    /* allocation sizes (bytes) of the buffers above, in the order of buf_slot() below: a state can be kept and
+     * reused from call to call (gms_ref_scratch), buffers only ever grow -- storage only, no arithmetic */
+    size_t cap[11];
 } gms_ref_state;
+
+/* Grow-only buffer: makes *p hold at least `bytes` bytes. Contents are NOT preserved (every user initialises what it
+ * reads, exactly as after the reference's fresh allocations). */
+static int ensure(void** p, size_t* cap, size_t bytes)
+{
+    if (bytes == 0) bytes = 1;
+    if (*cap >= bytes) return 0;
+    free(*p);
+    *p = malloc(bytes);
+    *cap = *p ? bytes : 0;
+    return *p ? 0 : -1;
+}
+#define ENSURE(st, field, slot, bytes) ensure((void**)&(st)->field, &(st)->cap[slot], (bytes))
 
 /* GMSMatcher::normalizePoints, DLL@0x180048420: cvtdq2ps on width/height, divss per coordinate. */
 static void normalize_points(const gms_keypoint* kp, int n, int width, int height, float* out)
@@ -154,11 +178,9 @@ static int set_scale(gms_ref_state* st, int scale)
     st->wr = round_f64(st->wl * gms_ref_scale_ratio(scale));
     st->hr = round_f64(st->hl * gms_ref_scale_ratio(scale));
     st->n_right = st->wr * st->hr;
-    free(st->nb_right);
-    free(st->motion);
-    st->nb_right = (int*)malloc(sizeof(int) * 9 * (size_t)st->n_right);
-    st->motion = (int*)malloc(sizeof(int) * (size_t)st->n_left * (size_t)st->n_right);
-    if (!st->nb_right || !st->motion) return -1;
+    if (ENSURE(st, nb_right, 0, sizeof(int) * 9 * (size_t)st->n_right) ||
+        ENSURE(st, motion, 1, sizeof(int) * (size_t)st->n_left * (size_t)st->n_right))
+        return -1;
     init_neighbors(st->nb_right, st->wr, st->hr);
     return 0;
 }
@@ -252,11 +274,12 @@ static int run(gms_ref_state* st, int rotation_type)
     return c;
 }
 
-int gms_ref_match(const gms_keypoint* kp1, int n1, int w1, int h1,
-                  const gms_keypoint* kp2, int n2, int w2, int h2,
-                  const gms_dmatch* matches, int m,
-                  int with_rotation, int with_scale, double threshold_factor,
-                  gms_dmatch* out, int* n_out, unsigned char* mask_out, gms_pair_result* result)
+/* matchGMS (DLL@0x180048280) on a caller-kept state: `st` holds nothing but storage between calls. */
+static int match_with_state(gms_ref_state* st, const gms_keypoint* kp1, int n1, int w1, int h1,
+                            const gms_keypoint* kp2, int n2, int w2, int h2,
+                            const gms_dmatch* matches, int m,
+                            int with_rotation, int with_scale, double threshold_factor,
+                            gms_dmatch* out, int* n_out, unsigned char* mask_out, gms_pair_result* result)
 {
     if (n_out) *n_out = 0;
     if (result) {
@@ -270,37 +293,32 @@ int gms_ref_match(const gms_keypoint* kp1, int n1, int w1, int h1,
         return GMS_ERR_BAD_ARG;
     if (mask_out && m > 0) memset(mask_out, 0, (size_t)m);
 
-    gms_ref_state st;
-    memset(&st, 0, sizeof st);
-    st.n_matches = m;
-    st.n1 = n1;
-    st.n2 = n2;
-    st.matches = matches;
-    st.threshold_factor = threshold_factor;
-    st.wl = 20;
-    st.hl = 20;
-    st.n_left = 400;
+    st->n_matches = m;
+    st->n1 = n1;
+    st->n2 = n2;
+    st->matches = matches;
+    st->threshold_factor = threshold_factor;
+    st->domain_error = 0;
+    st->wl = 20;
+    st->hl = 20;
+    st->n_left = 400;
 
     int rc = GMS_OK;
     unsigned char* best_mask = NULL;
-    st.p1 = (float*)malloc(sizeof(float) * 2 * (size_t)(n1 ? n1 : 1));
-    st.p2 = (float*)malloc(sizeof(float) * 2 * (size_t)(n2 ? n2 : 1));
-    st.nb_left = (int*)malloc(sizeof(int) * 9 * 400);
-    st.n_per_cell_left = (int*)malloc(sizeof(int) * 400);
-    st.cell_pairs = (int*)malloc(sizeof(int) * 400);
-    st.pair_first = (int*)malloc(sizeof(int) * (size_t)(m ? m : 1));
-    st.pair_second = (int*)malloc(sizeof(int) * (size_t)(m ? m : 1));
-    st.mask = (unsigned char*)malloc((size_t)(m ? m : 1));
-    best_mask = (unsigned char*)calloc((size_t)(m ? m : 1), 1);
-    if (!st.p1 || !st.p2 || !st.nb_left || !st.n_per_cell_left || !st.cell_pairs || !st.pair_first ||
-        !st.pair_second || !st.mask || !best_mask) {
+    if (ENSURE(st, p1, 2, sizeof(float) * 2 * (size_t)n1) || ENSURE(st, p2, 3, sizeof(float) * 2 * (size_t)n2) ||
+        ENSURE(st, nb_left, 4, sizeof(int) * 9 * 400) || ENSURE(st, n_per_cell_left, 5, sizeof(int) * 400) ||
+        ENSURE(st, cell_pairs, 6, sizeof(int) * 400) || ENSURE(st, pair_first, 7, sizeof(int) * (size_t)m) ||
+        ENSURE(st, pair_second, 8, sizeof(int) * (size_t)m) || ENSURE(st, mask, 9, (size_t)m) ||
+        ENSURE(st, best_mask, 10, (size_t)m)) {
         rc = GMS_ERR_BAD_ARG;
         goto done;
     }
+    best_mask = st->best_mask;
+    memset(best_mask, 0, (size_t)(m ? m : 1));
 
-    normalize_points(kp1, n1, w1, h1, st.p1);
-    normalize_points(kp2, n2, w2, h2, st.p2);
-    init_neighbors(st.nb_left, st.wl, st.hl);
+    normalize_points(kp1, n1, w1, h1, st->p1);
+    normalize_points(kp2, n2, w2, h2, st->p2);
+    init_neighbors(st->nb_left, st->wl, st->hl);
 
     /* Domain check (the reference has none, DLL@0x180048280): indices in range, matched points
      * finite and non-negative. Outside it the reference reads/writes out of bounds. */
@@ -310,8 +328,8 @@ int gms_ref_match(const gms_keypoint* kp1, int n1, int w1, int h1,
             rc = GMS_ERR_DOMAIN;
             goto done;
         }
-        if (!coord_ok(st.p1[2 * q]) || !coord_ok(st.p1[2 * q + 1]) || !coord_ok(st.p2[2 * t]) ||
-            !coord_ok(st.p2[2 * t + 1])) {
+        if (!coord_ok(st->p1[2 * q]) || !coord_ok(st->p1[2 * q + 1]) || !coord_ok(st->p2[2 * t]) ||
+            !coord_ok(st->p2[2 * t + 1])) {
             rc = GMS_ERR_DOMAIN;
             goto done;
         }
@@ -324,18 +342,18 @@ int gms_ref_match(const gms_keypoint* kp1, int n1, int w1, int h1,
     int n_scales = with_scale ? 5 : 1;
     int n_rots = with_rotation ? 8 : 1;
     for (int scale = 0; scale < n_scales; scale++) {
-        if (set_scale(&st, scale)) {
+        if (set_scale(st, scale)) {
             rc = GMS_ERR_BAD_ARG;
             goto done;
         }
         for (int rot = 1; rot <= n_rots; rot++) {
-            int num_inlier = run(&st, rot);
-            if (st.domain_error) {
+            int num_inlier = run(st, rot);
+            if (st->domain_error) {
                 rc = GMS_ERR_DOMAIN;
                 goto done;
             }
             if (num_inlier > max_inlier) {
-                memcpy(best_mask, st.mask, (size_t)m);
+                memcpy(best_mask, st->mask, (size_t)m);
                 max_inlier = num_inlier;
                 best_scale = scale;
                 best_rot = rot;
@@ -359,18 +377,63 @@ int gms_ref_match(const gms_keypoint* kp1, int n1, int w1, int h1,
 
 done:
     if (result) result->status = rc;
-    free(st.p1);
-    free(st.p2);
-    free(st.nb_left);
-    free(st.nb_right);
-    free(st.motion);
-    free(st.n_per_cell_left);
-    free(st.cell_pairs);
-    free(st.pair_first);
-    free(st.pair_second);
-    free(st.mask);
-    free(best_mask);
     return rc;
+}
+
+static void state_release(gms_ref_state* st)
+{
+    free(st->p1);
+    free(st->p2);
+    free(st->nb_left);
+    free(st->nb_right);
+    free(st->motion);
+    free(st->n_per_cell_left);
+    free(st->cell_pairs);
+    free(st->pair_first);
+    free(st->pair_second);
+    free(st->mask);
+    free(st->best_mask);
+    memset(st, 0, sizeof *st);
+}
+
+/* Whole call with fresh storage, as the reference's stack GMSMatcher has it (DLL@0x180048280). */
+int gms_ref_match(const gms_keypoint* kp1, int n1, int w1, int h1,
+                  const gms_keypoint* kp2, int n2, int w2, int h2,
+                  const gms_dmatch* matches, int m,
+                  int with_rotation, int with_scale, double threshold_factor,
+                  gms_dmatch* out, int* n_out, unsigned char* mask_out, gms_pair_result* result)
+{
+    gms_ref_state st;
+    memset(&st, 0, sizeof st);
+    int rc = match_with_state(&st, kp1, n1, w1, h1, kp2, n2, w2, h2, matches, m, with_rotation, with_scale,
+                              threshold_factor, out, n_out, mask_out, result);
+    state_release(&st);
+    return rc;
+}
+
+/* The same call on storage kept from call to call (one scratch per host thread): identical arithmetic and loop
+ * order, no allocator traffic once the buffers have reached the largest shape. For the multi-threaded CPU baseline
+ * (gms_ref_mt.c): glibc serves the 640 KB .. 2.5 MB motion matrix by mmap/munmap, which serialises every thread of
+ * the process on one kernel lock. */
+struct gms_ref_scratch {
+    gms_ref_state st;
+};
+gms_ref_scratch* gms_ref_scratch_create(void) { return (gms_ref_scratch*)calloc(1, sizeof(gms_ref_scratch)); }
+void gms_ref_scratch_destroy(gms_ref_scratch* s)
+{
+    if (!s) return;
+    state_release(&s->st);
+    free(s);
+}
+int gms_ref_match_ws(gms_ref_scratch* s, const gms_keypoint* kp1, int n1, int w1, int h1,
+                     const gms_keypoint* kp2, int n2, int w2, int h2,
+                     const gms_dmatch* matches, int m,
+                     int with_rotation, int with_scale, double threshold_factor,
+                     gms_dmatch* out, int* n_out, unsigned char* mask_out, gms_pair_result* result)
+{
+    if (!s) return GMS_ERR_BAD_ARG;
+    return match_with_state(&s->st, kp1, n1, w1, h1, kp2, n2, w2, h2, matches, m, with_rotation, with_scale,
+                            threshold_factor, out, n_out, mask_out, result);
 }
 
 /* Exposed pieces, so tests can pin them one at a time. */
@@ -396,12 +459,22 @@ void gms_ref_right_grid(int scale, int* wr, int* hr)
     *wr = round_f64(20 * gms_ref_scale_ratio(scale));
     *hr = round_f64(20 * gms_ref_scale_ratio(scale));
 }
+/* setScale's grid arithmetic for any left grid (DLL@0x180048c37-0x180048c71): pinned by tests/golden/refdll_setscale.npz */
+void gms_ref_right_grid_from(int left_w, int left_h, int scale, int* wr, int* hr)
+{
+    *wr = round_f64(left_w * gms_ref_scale_ratio(scale));
+    *hr = round_f64(left_h * gms_ref_scale_ratio(scale));
+}
 float gms_ref_normalize(float v, int extent) { return v / (float)extent; }
 int gms_ref_threshold_rejects(int T, int n, int score, double factor)
 {
     double thresh = sqrt((double)T / (double)n) * factor;
     return thresh > (double)score;
 }
+
+/* initalizeNeighbors / getNB9 for a gw x gh grid: out[gw * gh][9]. Pinned against the DLL's own initalizeNeighbors
+ * (DLL@0x180048180, tests/golden/refdll_nb9.npz). */
+void gms_ref_neighbors(int gw, int gh, int* out) { init_neighbors(out, gw, gh); }
 
 /* assignMatchPairs for grid types 1..4 in sequence, exactly as run() drives it (motion and nLeft zeroed before each
  * type, the right cell cached by type 1), on ALREADY NORMALISED points. Outputs per grid type t (0-based):

@@ -20,12 +20,26 @@ int gms_ref_match(const gms_keypoint* kp1, int n1, int w1, int h1,
                   int with_rotation, int with_scale, double threshold_factor,
                   gms_dmatch* out, int* n_out, unsigned char* mask_out, gms_pair_result* result);
 
+/* The same call on storage kept between calls (one scratch per host thread): identical arithmetic and loop order,
+ * no allocation once the buffers have grown to the largest shape seen. */
+typedef struct gms_ref_scratch gms_ref_scratch;
+gms_ref_scratch* gms_ref_scratch_create(void);
+void gms_ref_scratch_destroy(gms_ref_scratch* s);
+int gms_ref_match_ws(gms_ref_scratch* s, const gms_keypoint* kp1, int n1, int w1, int h1,
+                     const gms_keypoint* kp2, int n2, int w2, int h2,
+                     const gms_dmatch* matches, int m,
+                     int with_rotation, int with_scale, double threshold_factor,
+                     gms_dmatch* out, int* n_out, unsigned char* mask_out, gms_pair_result* result);
+
 /* Pieces, for pinning tests. */
 int   gms_ref_grid_index_left(float nx, float ny, int type);          /* DLL@0x180047bc0 */
 int   gms_ref_grid_index_right(float nx, float ny, int wr, int hr);   /* DLL@0x180047d60 */
 void  gms_ref_right_grid(int scale, int* wr, int* hr);                /* DLL@0x180048c10 */
+void  gms_ref_right_grid_from(int left_w, int left_h, int scale, int* wr, int* hr); /* DLL@0x180048c37 */
 float gms_ref_normalize(float v, int extent);                         /* DLL@0x180048420 */
 int   gms_ref_threshold_rejects(int T, int n, int score, double factor); /* DLL@0x180049171 */
+
+void  gms_ref_neighbors(int gw, int gh, int* out);                      /* DLL@0x180048180 / 0x180048030 */
 
 int   gms_ref_assign_pairs(const float* p1, const float* p2, const int* matches, int m, int wr, int hr,
                            int* pairs, int* nleft, int* motion);                 /* DLL@0x180047880 */

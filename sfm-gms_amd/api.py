@@ -68,6 +68,12 @@ class GmsContext:
     def synchronize(self):
         _check(self._lib.gms_ctx_synchronize(self._h), self._lib, "synchronize")
 
+    def query(self, what):
+        """gms_ctx_query: 1 = last launch dealt, 2 = its scale-probe mask, 3 = its matches per thread, 4 = launches, 5 = CUs."""
+        v = C.c_int64(0)
+        _check(self._lib.gms_ctx_query(self._h, int(what), C.byref(v)), self._lib, "gms_ctx_query")
+        return int(v.value)
+
     # -- one-shot, host arrays ---------------------------------------------------------------------
     def match(self, size1, size2, keypoints1, keypoints2, matches1to2, withRotation=False, withScale=False,
               thresholdFactor=6.0, return_result=False):

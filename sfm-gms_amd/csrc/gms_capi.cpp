@@ -53,9 +53,10 @@ namespace {
 //   GMS_BAND_WS_BYTES=n  budget of the large-pair workspace (default 4 GiB); a batch is filtered in slices that fit it
 //   GMS_DEAL=0|1         never / always deal the matches to the lanes of the byte-matrix kernel (default: what the probe saw)
 //   GMS_SCALE_PROBE=0|1  never / always bound the finer scale hypotheses' inlier counts first (default: while it pays, see below)
+//   GMS_CHECK_PAIRS=0|1  never / always validate the pair table behind a launch (default: the first launch and every sixteenth)
 struct Knobs {
     bool dense_on = true, band_on = true;
-    int stagger_us = -1, deal = -1, scale_probe = -1;
+    int stagger_us = -1, deal = -1, scale_probe = -1, check_pairs = -1;
     size_t band_ws_budget = (size_t)4 << 30;
 };
 const Knobs& knobs()
@@ -67,6 +68,7 @@ const Knobs& knobs()
         if (const char* e = std::getenv("GMS_STAGGER_US")) v.stagger_us = std::atoi(e);
         if (const char* e = std::getenv("GMS_DEAL")) v.deal = std::atoi(e) != 0 ? 1 : 0;
         if (const char* e = std::getenv("GMS_SCALE_PROBE")) v.scale_probe = std::atoi(e) != 0 ? 1 : 0;
+        if (const char* e = std::getenv("GMS_CHECK_PAIRS")) v.check_pairs = std::atoi(e) != 0 ? 1 : 0;
         if (const char* e = std::getenv("GMS_BAND_WS_BYTES")) {
             const long long b = std::atoll(e);
             if (b > 0) v.band_ws_budget = (size_t)b;
@@ -158,6 +160,13 @@ struct gms_ctx {
     // verdict[1] "probing scale hypotheses pays" (probe_verdict_kernel, below)
     uint32_t* verdict = nullptr;
     unsigned dense_launches = 0;
+    // The host never reads a pinned word that a kernel may be writing: a verdict kernel is followed by an event, and the first
+    // launch (or gms_ctx_synchronize) that finds the event complete ADOPTS the words; launches run on the adopted values in between.
+    // last_* = what the most recent launch ran with (gms_ctx_query).
+    int use_dealt = 0, use_probe = 1, last_dealt = 0, last_probe = 0, last_kpt = 0;
+    hipEvent_t verdict_event = nullptr;
+    bool verdict_pending = false;
+    unsigned filter_launches = 0;  // every launch of the context (pair-table validation every sixteenth)
     // Scale hypotheses: the kernels can bound a scale's inlier count before evaluating it (gms_kernels.hip, PROBE) and skip the
     // scale when it cannot win -- a gain when at least half of the probes let a scale skip, a loss otherwise. The kernels count
     // both in probe_stats (device); every sixteenth launch with scale hypotheses probes whatever the verdict and is followed by a
@@ -243,7 +252,7 @@ int filter_launch(gms_ctx* c, hipStream_t st, const float* d_pts, const int64_t*
     const int kpt = w.kpt;
     p.table_slots = kpt ? gms::filter_table_slots(kpt) : 0;
     p.region_shift = kpt ? gms::filter_region_shift(kpt) : 0;
-    p.pts = reinterpret_cast<const float2*>(d_pts);
+    p.pts = reinterpret_cast<const float2*>(reinterpret_cast<const char*>(d_pts) + gms::kTableHeaderBytes);  // behind the table's header
     p.frame_off = d_frame_off;
     p.n_frames = n_frames;
     p.pairs = d_pairs;
@@ -263,7 +272,12 @@ int filter_launch(gms_ctx* c, hipStream_t st, const float* d_pts, const int64_t*
     // the byte-matrix path is tried first whenever there are no scale hypotheses (the reference's default flags,
     // DisparityUtil.cpp:149,299)
     p.dense = (knobs().dense_on && !with_scale) ? 1 : 0;
-    p.dealt = (p.dense && kpt && (knobs().deal >= 0 ? knobs().deal != 0 : ((volatile uint32_t*)c->verdict)[0] != 0u)) ? 1 : 0;
+    if (c->verdict_pending && !capturing && hipEventQuery(c->verdict_event) == hipSuccess) {
+        c->use_dealt = c->verdict[0] != 0u ? 1 : 0;
+        c->use_probe = c->verdict[1] != 0u ? 1 : 0;
+        c->verdict_pending = false;
+    }
+    p.dealt = (p.dense && kpt && (knobs().deal >= 0 ? knobs().deal != 0 : c->use_dealt != 0)) ? 1 : 0;
     // First-round stagger: the spread is about one pair's duration on the path the launch will mostly take -- 26 us (byte
     // matrix) / 72 us (hashed) at 10k matches, in proportion to max_m -- in ticks of the 100 MHz wall clock. Only launches of
     // at least four dispatch rounds are staggered, and none with scale hypotheses on the byte matrix: a pair takes ten times as
@@ -282,7 +296,7 @@ int filter_launch(gms_ctx* c, hipStream_t st, const float* d_pts, const int64_t*
     if (kpt && with_scale) {
         // the scales finer than 20 x 20 and the 14 x 14 one are probed (2, 3, 4); the measuring launches are left out of stream captures
         const bool measuring = knobs().scale_probe < 0 && !capturing && (c->scale_launches++ & 15u) == 0u;
-        const bool on = knobs().scale_probe >= 0 ? knobs().scale_probe != 0 : (measuring || ((volatile uint32_t*)c->verdict)[1] != 0u);
+        const bool on = knobs().scale_probe >= 0 ? knobs().scale_probe != 0 : (measuring || c->use_probe != 0);
         p.probe_scales = on ? 0x1D : 0;  // every scale but 1, which the byte-matrix kernel evaluates first
         p.probe_stats = measuring ? (uint32_t*)c->probe_stats.p : nullptr;
     }
@@ -294,6 +308,8 @@ int filter_launch(gms_ctx* c, hipStream_t st, const float* d_pts, const int64_t*
             void* dflag = nullptr;
             GMS_HIP(hipHostGetDevicePointer(&dflag, c->verdict, 0));
             GMS_HIP(gms::launch_probe_verdict(p.probe_stats, (uint32_t*)dflag + 1, st));
+            GMS_HIP(hipEventRecord(c->verdict_event, st));
+            c->verdict_pending = true;
         }
     } else if (kpt) {
         GMS_HIP(gms::launch_filter(p, kpt, n_pairs, st));
@@ -302,6 +318,8 @@ int filter_launch(gms_ctx* c, hipStream_t st, const float* d_pts, const int64_t*
             void* dflag = nullptr;
             GMS_HIP(hipHostGetDevicePointer(&dflag, c->verdict, 0));
             GMS_HIP(gms::launch_order_probe(p, (uint32_t*)dflag, st));
+            GMS_HIP(hipEventRecord(c->verdict_event, st));
+            c->verdict_pending = true;
         }
     } else if (knobs().band_on) {
         // Large pairs on the LDS kernels, a slice of the batch at a time so that the per-pair workspace (lists, histogram,
@@ -325,6 +343,14 @@ int filter_launch(gms_ctx* c, hipStream_t st, const float* d_pts, const int64_t*
         const int n_wg = n_pairs < c->n_cus ? n_pairs : c->n_cus;
         GMS_HIP(gms::launch_filter_big(p, w.mcap, n_wg, (uint32_t*)c->big_ws.p, st));
     }
+    c->last_dealt = p.dealt;
+    c->last_probe = p.probe_scales;
+    c->last_kpt = kpt;
+    // pair-table validation (ranges [match_off, match_off + m) must be disjoint: include/gms.h), behind the filter: offenders'
+    // status becomes GMS_ERR_BAD_ARG. The first launch of a context and every sixteenth; never inside a stream capture.
+    if (n_pairs > 1 && !capturing && knobs().check_pairs != 0 && (knobs().check_pairs == 1 || (c->filter_launches & 15u) == 0u))
+        GMS_HIP(gms::launch_check_pairs(d_pairs, n_pairs, d_results, (uint32_t*)c->probe_stats.p + 8, st));
+    if (!capturing) ++c->filter_launches;
     if (uses_ws && !capturing) {
         GMS_HIP(hipEventRecord(c->ws_event, st));
         c->ws_stream = st;
@@ -425,6 +451,7 @@ int gms_ctx_create(int device, gms_ctx** out_ctx)
     e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->lane[1].stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ws_event, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->verdict_event, hipEventDisableTiming);
     if (e == hipSuccess) e = hipHostMalloc((void**)&c->verdict, 64, hipHostMallocDefault);
     if (e == hipSuccess) {
         c->verdict[0] = 0;
@@ -440,6 +467,7 @@ int gms_ctx_create(int device, gms_ctx** out_ctx)
         if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
         if (c->lane[1].stream) (void)hipStreamDestroy(c->lane[1].stream);
         if (c->ws_event) (void)hipEventDestroy(c->ws_event);
+        if (c->verdict_event) (void)hipEventDestroy(c->verdict_event);
         if (c->verdict) (void)hipHostFree(c->verdict);
         c->probe_stats.release();
         delete c;
@@ -474,6 +502,7 @@ int gms_ctx_destroy(gms_ctx* c)
         (void)hipStreamDestroy(c->lane[1].stream);
         (void)hipStreamDestroy(c->own_stream);
         (void)hipEventDestroy(c->ws_event);
+        (void)hipEventDestroy(c->verdict_event);
     }
     delete c;
     return GMS_OK;
@@ -493,7 +522,26 @@ int gms_ctx_synchronize(gms_ctx* c)
     std::lock_guard<std::mutex> lock(c->mu);
     GMS_HIP(hipSetDevice(c->device));
     GMS_HIP(hipStreamSynchronize(c->stream));
+    if (c->verdict_pending && hipEventQuery(c->verdict_event) == hipSuccess) {  // (recorded on another stream: maybe not yet)
+        c->use_dealt = c->verdict[0] != 0u ? 1 : 0;
+        c->use_probe = c->verdict[1] != 0u ? 1 : 0;
+        c->verdict_pending = false;
+    }
     return GMS_OK;
+}
+
+int gms_ctx_query(gms_ctx* c, int what, int64_t* value)
+{
+    if (!c || !value) return GMS_ERR_BAD_ARG;
+    std::lock_guard<std::mutex> lock(c->mu);
+    switch (what) {
+    case GMS_QUERY_LAST_DEALT: *value = c->last_dealt; return GMS_OK;
+    case GMS_QUERY_LAST_SCALE_PROBE: *value = c->last_probe; return GMS_OK;
+    case GMS_QUERY_LAST_KPT: *value = c->last_kpt; return GMS_OK;
+    case GMS_QUERY_LAUNCHES: *value = (int64_t)c->filter_launches; return GMS_OK;
+    case GMS_QUERY_CUS: *value = c->n_cus; return GMS_OK;
+    default: return GMS_ERR_BAD_ARG;
+    }
 }
 
 int gms_ctx_reserve(gms_ctx* c, int n_pairs, int max_m, int with_rotation, int with_scale)
@@ -509,7 +557,8 @@ int gms_ctx_reserve(gms_ctx* c, int n_pairs, int max_m, int with_rotation, int w
     return grow_workspace(c, w, c->stream);
 }
 
-int64_t gms_frame_table_bytes(int64_t total_kp) { return total_kp < 0 ? 0 : total_kp * 16 + 16; }
+// header (16) | points (8 each) | lcode, rcode (2 each) | scode (4 each) | 16 spare bytes (the staging copies read whole uint4s)
+int64_t gms_frame_table_bytes(int64_t total_kp) { return total_kp < 0 ? 0 : gms::kTableHeaderBytes + total_kp * 16 + 16; }
 
 int gms_normalize_device(gms_ctx* c, const gms_keypoint* d_kp, const int64_t* d_frame_off,
                          const int32_t* d_wh, int n_frames, int64_t total_kp, float* d_pts)
@@ -567,10 +616,10 @@ int gms_match_ctx(gms_ctx* c, const gms_keypoint* kp1, int n1, int w1, int h1,
     GMS_HIP(L.hout.reserve(out_bytes));
     // (a DevBuf that grows frees its old block: earlier work of this lane is complete -- every host-pointer call ends
     // synchronised -- unless the caller switched streams in between, which the synchronize below covers)
-    if (in_bytes > L.din.cap || out_bytes > L.dout.cap || nkp * 16 + 16 > c->tab_pts.cap) GMS_HIP(hipDeviceSynchronize());
+    if (in_bytes > L.din.cap || out_bytes > L.dout.cap || (size_t)gms_frame_table_bytes((int64_t)nkp) > c->tab_pts.cap) GMS_HIP(hipDeviceSynchronize());
     GMS_HIP(L.din.reserve(in_bytes));
     GMS_HIP(L.dout.reserve(out_bytes));
-    GMS_HIP(c->tab_pts.reserve(nkp * 16 + 16));
+    GMS_HIP(c->tab_pts.reserve((size_t)gms_frame_table_bytes((int64_t)nkp)));
     char* hin = (char*)L.hin.p;
     const CallHeader hdr = {{0, n1, (int64_t)n1 + n2}, {w1, h1, w2, h2}, {0, 1, m, 0, 0}};
     std::memcpy(hin, &hdr, sizeof hdr);
@@ -649,12 +698,23 @@ int gms_filter_host_batch(gms_ctx* c, const gms_keypoint* kp, const int64_t* fra
     const int64_t total_kp = frame_off[n_frames];
     if (total_kp < 0 || (total_kp > 0 && !kp)) return GMS_ERR_BAD_ARG;
     int max_m = 0;
+    bool in_order = true;
     for (int i = 0; i < n_pairs; ++i) {
         if (pairs[i].m < 0 || pairs[i].match_off < 0) return GMS_ERR_BAD_ARG;
         if (pairs[i].m > gms_max_matches()) return GMS_ERR_CAPACITY;
         max_m = std::max(max_m, pairs[i].m);
+        if (i + 1 < n_pairs && pairs[i].match_off + pairs[i].m > pairs[i + 1].match_off) in_order = false;
     }
     if (max_m > 0 && (!matches || !out)) return GMS_ERR_BAD_ARG;
+    if (!in_order) {  // the pairs' match ranges must be disjoint (include/gms.h): sort the non-empty ones by start and look at the neighbours
+        std::vector<std::pair<int64_t, int64_t>> r;
+        r.reserve((size_t)n_pairs);
+        for (int i = 0; i < n_pairs; ++i)
+            if (pairs[i].m > 0) r.emplace_back(pairs[i].match_off, pairs[i].match_off + pairs[i].m);
+        std::sort(r.begin(), r.end());
+        for (size_t i = 1; i < r.size(); ++i)
+            if (r[i - 1].second > r[i].first) return GMS_ERR_BAD_ARG;
+    }
 
     std::lock_guard<std::mutex> lock(c->mu);
     GMS_HIP(hipSetDevice(c->device));
@@ -702,7 +762,7 @@ int gms_filter_host_batch(gms_ctx* c, const gms_keypoint* kp, const int64_t* fra
     // ---- the frame table: (pt.x, pt.y) of every keypoint through pinned memory in pieces, then normalizePoints on the GPU
     const size_t small_bytes = align16((size_t)(n_frames + 1) * 8) + (size_t)n_frames * 8;
     GMS_HIP(c->tab_kp.reserve((size_t)total_kp * 8));
-    GMS_HIP(c->tab_pts.reserve((size_t)total_kp * 16 + 16));
+    GMS_HIP(c->tab_pts.reserve((size_t)gms_frame_table_bytes(total_kp)));
     GMS_HIP(c->tab_small.reserve(small_bytes));
     {
         hipStream_t st = c->lane[0].stream;

@@ -84,6 +84,16 @@ constexpr uint32_t rotation_pack(int rot)
     return w;
 }
 
+// Number of keypoints the frame table behind p.pts was built for (normalize_kernel's header), or -1 when the block does not
+// start with the header: the byte-matrix kernels then leave the pair to the path that works from the points alone.
+__device__ __forceinline__ int64_t table_total_kp(const FilterParams& p)
+{
+    const uint32_t* __restrict__ h = reinterpret_cast<const uint32_t*>(p.pts) - kTableHeaderBytes / 4;
+    const uint2 magic = *reinterpret_cast<const uint2*>(h);
+    const int64_t total = *reinterpret_cast<const int64_t*>(h + 2);
+    return (magic.x == kTableMagic0 && magic.y == kTableMagic1) ? total : (int64_t)-1;
+}
+
 // lane ^ 1 exchange on the VALU (DPP quad_perm [1,0,3,2]), no LDS round trip
 __device__ __forceinline__ uint32_t dpp_xor1(uint32_t x)
 {

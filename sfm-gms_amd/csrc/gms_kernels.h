@@ -17,8 +17,14 @@ constexpr size_t kLdsBytes = 160 * 1024;               // gfx950 LDS per CU (and
 constexpr uint32_t kPartialHeaderDw = 4;
 constexpr uint32_t kPartialStrideDw = kPartialHeaderDw + 16 * 1024 / 32;
 
+// The frame table (gms_frame_table_bytes) starts with a 16-byte header -- magic, then the number of keypoints it was built
+// for -- so that the kernels find the code arrays behind the points by themselves, whatever n_frames / frame_off a filter call
+// passes (a prefix or a subset of the table's frames is fine). A block without the header is filtered from its points alone.
+constexpr uint32_t kTableMagic0 = 0x46534D47u, kTableMagic1 = 0x31424154u;  // "GMSF" "TAB1"
+constexpr int kTableHeaderBytes = 16;
+
 struct FilterParams {
-    const float2* pts;          // normalised keypoints of all frames
+    const float2* pts;          // normalised keypoints of all frames (the table's points: kTableHeaderBytes behind its start)
     const int64_t* frame_off;   // n_frames + 1
     int n_frames;
     const gms_pair* pairs;
@@ -58,6 +64,8 @@ hipError_t launch_normalize(const void* d_kp, int kp_stride_bytes, const int64_t
 hipError_t launch_filter(const FilterParams& p, int kpt, int n_pairs, hipStream_t stream);
 hipError_t launch_order_probe(const FilterParams& p, uint32_t* flag, hipStream_t stream);  // *flag: pinned host word
 hipError_t launch_probe_verdict(uint32_t* stats, uint32_t* flag, hipStream_t stream);      // FilterParams::probe_stats -> pinned host word
+// pair-table validation: ranges [match_off, match_off + m) must be disjoint; offenders get GMS_ERR_BAD_ARG in d_results (d_flag: a device word)
+hipError_t launch_check_pairs(const gms_pair* d_pairs, int n_pairs, gms_pair_result* d_results, uint32_t* d_flag, hipStream_t stream);
 hipError_t launch_filter_scales(const FilterParams& p, int kpt, int n_pairs, hipStream_t stream);
 // large pairs (gms_kernel_big.hip): code words and table in a per-workgroup HBM slab
 constexpr int kBigMaxMatches = 1 << 22;       // per pair: 4 194 304 (a 2594 x 1131 one-keypoint-per-pixel frame of DisparityUtil.cpp:299 has 2.93 M)

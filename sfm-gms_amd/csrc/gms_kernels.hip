@@ -203,6 +203,12 @@ __global__ void __launch_bounds__(256)
 normalize_kernel(const char* __restrict__ kp, int kp_stride, const int64_t* __restrict__ frame_off,
                  const int32_t* __restrict__ wh, int n_frames, int64_t total, float2* __restrict__ pts)
 {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {  // the table's header (gms_kernels.h): the kernels read the keypoint count from here
+        uint32_t* h = reinterpret_cast<uint32_t*>(pts) - kTableHeaderBytes / 4;
+        h[0] = kTableMagic0;
+        h[1] = kTableMagic1;
+        *reinterpret_cast<int64_t*>(h + 2) = total;
+    }
     uint16_t* __restrict__ lcode = reinterpret_cast<uint16_t*>(pts + total);
     uint16_t* __restrict__ rcode = lcode + total;
     uint32_t* __restrict__ scode = reinterpret_cast<uint32_t*>(rcode + total);
@@ -942,7 +948,8 @@ __device__ __forceinline__ bool dense_pair(const FilterParams& p, uint32_t* smem
     if (nA <= 0 || nB <= 0) return false;
     const gms_dmatch* __restrict__ matches = p.matches + pr.match_off;
     // the frame table's code words (written by normalize_kernel behind the points): frame A's left codes, frame B's right codes
-    const int64_t total_kp = p.frame_off[p.n_frames];
+    const int64_t total_kp = table_total_kp(p);
+    if (total_kp < 0 || offA + nA > total_kp || offB + nB > total_kp) return false;  // (workgroup-uniform) no header, or frames beyond the table
     const uint16_t* __restrict__ lcodeA = reinterpret_cast<const uint16_t*>(p.pts + total_kp) + offA;
     const uint16_t* __restrict__ rcodeB = reinterpret_cast<const uint16_t*>(p.pts + total_kp) + total_kp + offB;
 
@@ -1432,10 +1439,12 @@ order_probe_kernel(FilterParams p, uint32_t* __restrict__ flag)
     if (pr.m >= 128 && pr.frame_a >= 0 && pr.frame_a < p.n_frames) {
         const int64_t offA = p.frame_off[pr.frame_a];
         const int nA = (int)(p.frame_off[pr.frame_a + 1] - offA);
-        const uint16_t* __restrict__ lcode = reinterpret_cast<const uint16_t*>(p.pts + p.frame_off[p.n_frames]) + offA;
+        const int64_t total_kp = table_total_kp(p);
+        const bool table_ok = total_kp >= 0 && nA > 0 && offA + nA <= total_kp;
+        const uint16_t* __restrict__ lcode = reinterpret_cast<const uint16_t*>(p.pts + (table_ok ? total_kp : 0)) + offA;
         const int start = (pr.m >> 1) & ~63;
         const uint32_t q = (uint32_t)p.matches[pr.match_off + start + lane].queryIdx;
-        const uint32_t lc = nA > 0 ? (uint32_t)lcode[min(q, (uint32_t)(nA - 1))] >> kLCellShift : kLCellNever;
+        const uint32_t lc = table_ok ? (uint32_t)lcode[min(q, (uint32_t)(nA - 1))] >> kLCellShift : kLCellNever;
         const uint32_t cell = lc >= kLCellNever ? 0x10000u + (uint32_t)lane : lc;  // never binned: equals nobody
         const uint32_t next = (uint32_t)__shfl_down((int)cell, 1);
         const unsigned long long same = __ballot(lane < 63 && cell == next);
@@ -1489,7 +1498,8 @@ __device__ __forceinline__ bool dense_scales_pair(const FilterParams& p, uint32_
     if (nA <= 0 || nB <= 0) return false;
     const gms_dmatch* __restrict__ matches = p.matches + pr.match_off;
     // the frame table's code words (normalize_kernel): frame A's left codes (16 bits), frame B's scale codes (32 bits)
-    const int64_t total_kp = p.frame_off[p.n_frames];
+    const int64_t total_kp = table_total_kp(p);
+    if (total_kp < 0 || offA + nA > total_kp || offB + nB > total_kp) return false;  // (workgroup-uniform) no header, or frames beyond the table
     const uint16_t* __restrict__ lcodeA = reinterpret_cast<const uint16_t*>(p.pts + total_kp) + offA;
     const uint32_t* __restrict__ scodeB = reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint16_t*>(p.pts + total_kp) + 2 * total_kp) + offB;
 
@@ -2016,6 +2026,71 @@ int filter_pick_kpt(int max_m)
     return 0;
 }
 
+// ---- pair-table validation (every sixteenth launch of a context, gms_capi.cpp) ----------------------------------------------
+// The pairs of a batch own disjoint ranges [match_off, match_off + m) of the match / output arrays (include/gms.h): a pair's
+// survivors are written over the head of its own range, so overlapping ranges would let one pair overwrite what another still
+// reads. Tables are almost always laid out in order, so: one pass tests "every range ends before the next one starts"; only when
+// that fails a second kernel compares every pair with every other (tiles of 256 through LDS; 67 M comparisons for 8192 pairs)
+// and marks both partners of every overlap GMS_ERR_BAD_ARG in the results, behind the filter that wrote them. Empty ranges
+// overlap nothing.
+__global__ void __launch_bounds__(256)
+pairs_in_order_kernel(const gms_pair* __restrict__ pairs, int n_pairs, uint32_t* __restrict__ flag)
+{
+    const int i = (int)(blockIdx.x * 256u + threadIdx.x);
+    bool bad = false;
+    if (i + 1 < n_pairs) {
+        const gms_pair a = pairs[i], b = pairs[i + 1];
+        bad = a.match_off + (int64_t)max(a.m, 0) > b.match_off;
+    }
+    if (__ballot(bad) != 0ull && (threadIdx.x & 63) == 0) atomicOr(flag, 1u);
+}
+
+__global__ void __launch_bounds__(256)
+pairs_overlap_kernel(const gms_pair* __restrict__ pairs, int n_pairs, const uint32_t* __restrict__ flag,
+                     gms_pair_result* __restrict__ results)
+{
+    if (*flag == 0u) return;  // the table is in order: nothing overlaps
+    __shared__ int64_t s_lo[256], s_hi[256];
+    const int i = (int)(blockIdx.x * 256u + threadIdx.x);
+    int64_t lo = 0, hi = 0;  // an empty range
+    if (i < n_pairs) {
+        const gms_pair a = pairs[i];
+        lo = a.match_off;
+        hi = a.match_off + (int64_t)max(a.m, 0);
+    }
+    bool clash = false;
+    for (int base = 0; base < n_pairs; base += 256) {
+        const int j = base + (int)threadIdx.x;
+        int64_t l = 0, h = 0;
+        if (j < n_pairs) {
+            const gms_pair b = pairs[j];
+            l = b.match_off;
+            h = b.match_off + (int64_t)max(b.m, 0);
+        }
+        __syncthreads();
+        s_lo[threadIdx.x] = l;
+        s_hi[threadIdx.x] = h;
+        __syncthreads();
+        const int n_tile = min(256, n_pairs - base);
+        for (int t = 0; t < n_tile; ++t) {
+            const int64_t tl = s_lo[t], th = s_hi[t];
+            clash |= (base + t != i) & (tl < hi) & (lo < th) & (tl < th) & (lo < hi);
+        }
+    }
+    if (i < n_pairs && clash) results[i].status = GMS_ERR_BAD_ARG;
+}
+
+hipError_t launch_check_pairs(const gms_pair* d_pairs, int n_pairs, gms_pair_result* d_results, uint32_t* d_flag, hipStream_t stream)
+{
+    if (n_pairs < 2) return hipSuccess;
+    hipError_t e = hipMemsetAsync(d_flag, 0, 4, stream);
+    if (e != hipSuccess) return e;
+    const unsigned blocks = (unsigned)((n_pairs + 255) / 256);
+    hipLaunchKernelGGL(pairs_in_order_kernel, dim3(blocks), dim3(256), 0, stream, d_pairs, n_pairs, d_flag);
+    hipLaunchKernelGGL(pairs_overlap_kernel, dim3(blocks), dim3(256), 0, stream, d_pairs, n_pairs, d_flag, d_results);
+    return hipGetLastError();
+}
+
 // Scale probes of the launches so far: [0] probed and evaluated anyway, [1] probed and skipped. A probe costs about 45 % of a
 // scale and saves the rest when it lets the scale skip: it pays from a skip rate of one half.
 __global__ void probe_verdict_kernel(uint32_t* stats, uint32_t* flag)
@@ -2045,7 +2120,8 @@ hipError_t launch_normalize(const void* d_kp, int kp_stride_bytes, const int64_t
     int64_t blocks = (total_kp + 255) / 256;
     if (blocks > 8192) blocks = 8192;
     hipLaunchKernelGGL(normalize_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, reinterpret_cast<const char*>(d_kp),
-                       kp_stride_bytes, d_frame_off, d_wh, n_frames, total_kp, reinterpret_cast<float2*>(d_pts));
+                       kp_stride_bytes, d_frame_off, d_wh, n_frames, total_kp,
+                       reinterpret_cast<float2*>(reinterpret_cast<char*>(d_pts) + kTableHeaderBytes));
     return hipGetLastError();
 }
 

@@ -10,6 +10,7 @@
 #pragma once
 #include <algorithm>
 #include <cstdint>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 #include <utility>
@@ -85,11 +86,11 @@ inline void matchGMSBatch(const std::vector<Size>& sizes, const std::vector<std:
                           const double thresholdFactor = 6.0, std::vector<bool>* ok = nullptr)
 {
     if (sizes.size() != keypoints.size() || pairs.size() != matches1to2.size()) throw std::invalid_argument("mi355::matchGMSBatch: sizes");
-    static gms_ctx* ctx = nullptr;  // one context per process, created on first use
-    if (!ctx) {
-        const int rc = gms_ctx_create(0, &ctx);
-        if (rc != GMS_OK) throw std::runtime_error(std::string("mi355::matchGMSBatch: ") + gms_error_string(rc));
-    }
+    static gms_ctx* ctx = nullptr;  // one context per process, created on first use (by exactly one of the threads that race here)
+    static int ctx_rc = GMS_OK;
+    static std::once_flag ctx_once;
+    std::call_once(ctx_once, [] { ctx_rc = gms_ctx_create(0, &ctx); });
+    if (ctx_rc != GMS_OK || !ctx) throw std::runtime_error(std::string("mi355::matchGMSBatch: ") + gms_error_string(ctx_rc));
     std::vector<int64_t> frame_off(keypoints.size() + 1, 0);
     std::vector<int32_t> wh(2 * keypoints.size());
     for (size_t f = 0; f < keypoints.size(); ++f) {

@@ -46,12 +46,18 @@ def save(path, ds):
 
 
 def load(path):
+    import os
     with open(path, "rb") as f:
         hdr = np.frombuffer(f.read(_HEADER.itemsize), dtype=_HEADER)
         if len(hdr) != 1 or hdr["magic"][0] != MAGIC or int(hdr["desc_kind"][0]) > 2:
             raise ValueError(f"{path}: not a GMSFRM01 file")
         n, kind = int(hdr["n_frames"][0]), int(hdr["desc_kind"][0]) - 1
         total, n_pairs, total_m = int(hdr["total_kp"][0]), int(hdr["n_pairs"][0]), int(hdr["total_matches"][0])
+        # the header must describe exactly the bytes that follow it (same rule as gms_dataset_read), before anything is read
+        row = {-1: 0, 0: 32, 1: 512}[kind]
+        payload = 8 * n + (8 * (n + 1) if n else 0) + (28 + row) * total + 24 * n_pairs + 16 * total_m
+        if max(total, n_pairs, total_m) > 1 << 40 or os.fstat(f.fileno()).st_size != _HEADER.itemsize + payload:
+            raise ValueError(f"{path}: header does not describe this file")
         take = lambda dt, count: np.frombuffer(f.read(np.dtype(dt).itemsize * count), dtype=dt, count=count)
         wh = take("<i4", 2 * n).reshape(-1, 2)
         off = take("<i8", n + 1) if n else np.zeros(1, dtype=np.int64)
@@ -62,6 +68,9 @@ def load(path):
         desc = take(dt, total * width).reshape(-1, width) if dt is not None else None
         pairs = take(PAIR_DTYPE, n_pairs)
         matches = take(DMATCH_DTYPE, total_m)
+        if n_pairs and not ((pairs["frame_a"] >= 0) & (pairs["frame_a"] < n) & (pairs["frame_b"] >= 0) & (pairs["frame_b"] < n) &
+                            (pairs["m"] >= 0) & (pairs["match_off"] >= 0) & (pairs["match_off"] + pairs["m"] <= total_m)).all():
+            raise ValueError(f"{path}: a pair names a frame or a match range outside the file")
     frames = [kp[off[i]:off[i + 1]] for i in range(n)]
     descs = [desc[off[i]:off[i + 1]] for i in range(n)] if desc is not None else None
     return Dataset(frames, [tuple(x) for x in wh.tolist()], descs, kind, pairs, matches)

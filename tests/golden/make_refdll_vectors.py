@@ -149,6 +149,81 @@ def verify_fixture():
     print("verify fixture", os.path.getsize(os.path.join(HERE, "refdll_verify_cells.npz")), "bytes")
 
 
+def nb9_fixture():
+    """GMSMatcher::initalizeNeighbors (and getNB9 through it) run out of the DLL for the left grid, the five right grids of
+    setScale and two non-square grids: the [w * h, 9] neighbour tables as the DLL fills them."""
+    grids = [(20, 20), (10, 10), (14, 14), (28, 28), (40, 40), (7, 3), (1, 5), (1, 1)]
+    out = {"grids": np.array(grids, dtype=np.int32)}
+    with tempfile.TemporaryDirectory() as tmp:
+        exe = os.path.join(tmp, "refdll_runner")
+        subprocess.check_call(["gcc", "-O1", "-o", exe, os.path.join(HERE, "refdll_runner.c")])
+        fin, fout = os.path.join(tmp, "in.bin"), os.path.join(tmp, "out.bin")
+        with open(fin, "wb") as f:
+            f.write(np.int32(len(grids)).tobytes())
+            f.write(np.array(grids, dtype=np.int32).tobytes())
+        subprocess.check_call([exe, DLL, fin, fout, "nb9"])
+        raw = np.fromfile(fout, dtype=np.int32)
+    pos = 0
+    for w, h in grids:
+        out[f"nb9_{w}x{h}"] = raw[pos:pos + 9 * w * h].reshape(w * h, 9).copy()
+        pos += 9 * w * h
+    assert pos == len(raw)
+    np.savez_compressed(os.path.join(HERE, "refdll_nb9.npz"), **out)
+    print("nb9 fixture", os.path.getsize(os.path.join(HERE, "refdll_nb9.npz")), "bytes")
+
+
+def normalize_fixture():
+    """GMSMatcher::normalizePoints run out of the DLL on cv::KeyPoint records of several image sizes (the reference's own images:
+    450 x 375, 1920 x 1080, 2016 x 1512, 1390 x 1110, 2594 x 1131, and BASELINE's 640 x 480 / 3840 x 2160), counts that exercise
+    both its four-at-a-time loop and its tail, coordinates that are integers, sub-pixel, tiny, on the far border."""
+    rng = np.random.default_rng(0x5F3759DF ^ 4)
+    kp_dtype = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")])
+    out = {}
+    cases = [(450, 375, 301), (1920, 1080, 1000), (2016, 1512, 7), (1390, 1110, 3), (2594, 1131, 258), (640, 480, 1), (3840, 2160, 513), (3, 7, 5)]
+    with tempfile.TemporaryDirectory() as tmp:
+        exe = os.path.join(tmp, "refdll_runner")
+        subprocess.check_call(["gcc", "-O1", "-o", exe, os.path.join(HERE, "refdll_runner.c")])
+        for i, (w, h, n) in enumerate(cases):
+            kp = np.zeros(n, dtype=kp_dtype)
+            kp["x"] = rng.uniform(0, w, n).astype(np.float32)
+            kp["y"] = rng.uniform(0, h, n).astype(np.float32)
+            kp["x"][: n // 3] = np.floor(kp["x"][: n // 3])                       # integer pixels (the per-pixel grids of DisparityUtil.cpp:123-133)
+            kp["y"][n // 5: n // 2] = np.floor(kp["y"][n // 5: n // 2])
+            kp["x"][-1], kp["y"][-1] = np.nextafter(np.float32(w), np.float32(0)), np.float32(1e-30)
+            kp["x"][0], kp["y"][0] = 0.0, 0.0
+            kp["size"], kp["angle"], kp["response"], kp["octave"], kp["class_id"] = 31.0, -1.0, rng.uniform(0, 1, n), 3, -1
+            fin, fout = os.path.join(tmp, "in.bin"), os.path.join(tmp, "out.bin")
+            with open(fin, "wb") as f:
+                f.write(np.array([n, w, h], dtype=np.int32).tobytes())
+                f.write(kp.tobytes())
+            subprocess.check_call([exe, DLL, fin, fout, "normalize"])
+            res = np.fromfile(fout, dtype=np.float32).reshape(n, 2)
+            out[f"c{i}_size"] = np.array([w, h], dtype=np.int32)
+            out[f"c{i}_xy"] = np.stack([kp["x"], kp["y"]], axis=1)
+            out[f"c{i}_normalized"] = res
+    np.savez_compressed(os.path.join(HERE, "refdll_normalize.npz"), **out)
+    print("normalize fixture", os.path.getsize(os.path.join(HERE, "refdll_normalize.npz")), "bytes")
+
+
+def setscale_fixture():
+    """The head of GMSMatcher::setScale run out of the DLL for scales 0..4 (after the DLL's own static initialiser has filled the
+    two dynamic entries of mScaleRatios): the ratios, the right grid per scale, and the shape of the neighbour table it asks for."""
+    out = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        exe = os.path.join(tmp, "refdll_runner")
+        subprocess.check_call(["gcc", "-O1", "-o", exe, os.path.join(HERE, "refdll_runner.c")])
+        for lw, lh in ((20, 20), (15, 25)):
+            fin, fout = os.path.join(tmp, "in.bin"), os.path.join(tmp, "out.bin")
+            with open(fin, "wb") as f:
+                f.write(np.array([lw, lh], dtype=np.int32).tobytes())
+            subprocess.check_call([exe, DLL, fin, fout, "setscale"])
+            raw = open(fout, "rb").read()
+            out["ratios"] = np.frombuffer(raw[:40], dtype=np.float64).copy()
+            out[f"left{lw}x{lh}"] = np.frombuffer(raw[40:], dtype=np.int32).reshape(5, 6).copy()
+    np.savez_compressed(os.path.join(HERE, "refdll_setscale.npz"), **out)
+    print("setscale fixture", out["ratios"].tolist(), out["left20x20"].tolist())
+
+
 def main():
     if not os.path.exists(DLL):
         sys.exit("reference DLL not present: this generator runs only where /root/reference is mounted")
@@ -167,6 +242,9 @@ def main():
                         right_dims=np.array([20, 10, 14, 28, 40], dtype=np.int32))
     assign_fixture()
     verify_fixture()
+    nb9_fixture()
+    normalize_fixture()
+    setscale_fixture()
     print(len(pts), "points;", "left range", res[:, :4].min(), res[:, :4].max(), "; file",
           os.path.getsize(os.path.join(HERE, "refdll_grid_index.npz")), "bytes")
 

@@ -33,16 +33,44 @@
  *   match never reach the fragment). Object layout from the disassembly: mGridNumberLeft @+0x60, mGridNumberRight
  *   @+0x64, motion data @+0x78 / row-step pointer @+0xb0, per-cell counts @+0xc8, mCellPairs.begin @+0xe0, left
  *   neighbour table data @+0x140 / step pointer @+0x178, right neighbour table data @+0x1a0 / step pointer @+0x1d8,
- *   mThresholdFactor @+0x1f0. The two neighbour tables are filled by this file (getNB9 allocates through the CRT and
- *   cannot be run).
+ *   mThresholdFactor @+0x1f0. The two neighbour tables are filled by the DLL's own GMSMatcher::initalizeNeighbors (see "nb9").
  *   in.bin : int32 wr, hr; double factor; 400 int32 counts; 400 * wr * hr int32 motion
  *   out.bin: 8 x 400 int32 mCellPairs (rotation types 1..8)
+ *
+ * usage: refdll_runner <dll> <in.bin> <out.bin> nb9
+ *   GMSMatcher::initalizeNeighbors (RVA 0x48180) and, through it, GMSMatcher::getNB9 (RVA 0x48030), run out of the DLL. getNB9
+ *   builds a std::vector<int>(9, -1): operator new (RVA 0x81650) loops on the CRT's malloc through the import slot at RVA
+ *   0x901b0, the vector's release ends in free through the slot at RVA 0x901b8 (api-ms-win-crt-heap-l1-1-0.dll: _callnewh
+ *   0x901a8, malloc 0x901b0, free 0x901b8). The image's imports are unresolved here, so those two slots are pointed at
+ *   ms_abi wrappers of this process's malloc / free -- an allocator, no arithmetic. initalizeNeighbors(this, Mat& neighbor,
+ *   const Size& grid) reads neighbor.rows @+0x08, neighbor.data @+0x10 and the pointer to the row step @+0x48.
+ *   in.bin : int32 n, then n x (int32 width, int32 height)
+ *   out.bin: per grid: width * height x 9 int32 (the neighbour table)
+ *
+ * usage: refdll_runner <dll> <in.bin> <out.bin> normalize
+ *   GMSMatcher::normalizePoints (RVA 0x48420): (this, const std::vector<cv::KeyPoint>& kp, const cv::Size& size,
+ *   std::vector<cv::Point2f>& npts). It resizes npts to kp.size() first; handed a vector that already has that size it
+ *   allocates nothing and is a leaf. Vectors are {begin, end, capacity-end} pointer triples; KeyPoint stride 0x1c.
+ *   in.bin : int32 n, width, height; n x 28-byte cv::KeyPoint records
+ *   out.bin: n x (float nx, float ny)
+ *
+ * usage: refdll_runner <dll> <in.bin> <out.bin> setscale
+ *   The head of GMSMatcher::setScale (RVA 0x48c10): mGridSizeRight = cvRound(mGridSizeLeft * mScaleRatios[scale]) per axis
+ *   (cvtdq2pd, mulsd, cvtsd2si), mGridNumberRight = their product -- everything up to its first import, cv::Mat::zeros(rows,
+ *   cols, type) through the slot at RVA 0x903f8. That slot is pointed at a function of this file that records the three
+ *   arguments and takes control back (longjmp): nothing of opencv_core is emulated, the call simply ends the experiment.
+ *   Two of the five mScaleRatios entries (.data RVA 0x2c5018 / 0x2c5020) are written by a static initialiser of the DLL
+ *   (RVA 0x10b0, a leaf: sqrtpd of the constant 2.0, then 1.0 / that); it is run first, as the loader would.
+ *   in.bin : int32 left_w, left_h
+ *   out.bin: 5 doubles (mScaleRatios after the initialiser), then per scale 0..4: int32 right_w, right_h, n_right, and the
+ *            rows, cols, type handed to cv::Mat::zeros (the right neighbour table: n_right x 9, CV_32SC1 = 4)
  */
 #define _GNU_SOURCE
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <setjmp.h>
 #include <sys/mman.h>
 
 /* see "verify" above: emulates verifyCellPairs' prologue, then jumps into its body */
@@ -72,6 +100,41 @@ __asm__(".intel_syntax noprefix\n"
         "  xorps xmm7, xmm7\n"
         "  jmp r9\n"
         ".att_syntax prefix\n");
+
+/* see "setscale" above: what setScale hands to its first import, and the way back */
+static jmp_buf g_back;
+static int32_t g_zeros_args[3];
+static void __attribute__((ms_abi)) stop_at_mat_zeros(void* ret_slot, int rows, int cols, int type)
+{
+    (void)ret_slot;
+    g_zeros_args[0] = rows;
+    g_zeros_args[1] = cols;
+    g_zeros_args[2] = type;
+    longjmp(g_back, 1);
+}
+
+/* the two CRT imports getNB9 needs (see "nb9" above) */
+static void* __attribute__((ms_abi)) crt_malloc(size_t n) { return malloc(n); }
+static void __attribute__((ms_abi)) crt_free(void* p) { free(p); }
+typedef void(__attribute__((ms_abi)) * init_nb_fn)(void* self, void* mat, const int32_t* grid_size);
+
+/* GMSMatcher::initalizeNeighbors out of the image: fills table[w * h][9] */
+static void dll_neighbors(unsigned char* img, int32_t* table, int w, int h)
+{
+    *(void**)(img + 0x901b0) = (void*)crt_malloc;
+    *(void**)(img + 0x901b8) = (void*)crt_free;
+    uint64_t step = 36;
+    unsigned char mat[0x60];
+    memset(mat, 0, sizeof mat);
+    *(int32_t*)(mat + 0x08) = w * h;      /* rows */
+    *(int32_t*)(mat + 0x0c) = 9;          /* cols */
+    *(void**)(mat + 0x10) = table;        /* data */
+    *(void**)(mat + 0x48) = &step;        /* step.p */
+    const int32_t size[2] = {w, h};
+    unsigned char self[0x200];
+    memset(self, 0, sizeof self);
+    ((init_nb_fn)(img + 0x48180))(self, mat, size);
+}
 
 typedef int(__attribute__((ms_abi)) * left_fn)(void* self, const float* pt, int type);
 typedef int(__attribute__((ms_abi)) * right_fn)(void* self, const float* pt);
@@ -166,19 +229,9 @@ int main(int argc, char** argv)
         if (fread(nleft, 4, 400, in) != 400 || fread(motion, 4, 400 * (size_t)nr, in) != 400 * (size_t)nr) return 6;
         int32_t* nb_left = malloc(sizeof(int32_t) * 9 * 400);
         int32_t* nb_right = malloc(sizeof(int32_t) * 9 * (size_t)nr);
-        for (int pass = 0; pass < 2; pass++) {  /* getNB9 by restatement (DLL@0x180048030) */
-            int32_t* nb = pass ? nb_right : nb_left;
-            const int gw = pass ? wr : 20, gh = pass ? hr : 20;
-            for (int idx = 0; idx < gw * gh; idx++) {
-                for (int k = 0; k < 9; k++) nb[9 * idx + k] = -1;
-                for (int yi = -1; yi <= 1; yi++)
-                    for (int xi = -1; xi <= 1; xi++) {
-                        const int xx = idx % gw + xi, yy = idx / gw + yi;
-                        if (xx < 0 || xx >= gw || yy < 0 || yy >= gh) continue;
-                        nb[9 * idx + xi + 4 + yi * 3] = xx + yy * gw;
-                    }
-            }
-        }
+        /* both neighbour tables by the DLL's own initalizeNeighbors / getNB9 (DLL@0x180048180 / 0x180048030) */
+        dll_neighbors(img, nb_left, 20, 20);
+        dll_neighbors(img, nb_right, wr, hr);
         uint64_t step_motion = (uint64_t)nr * 4, step_nb = 36;
         unsigned char self[0x200];
         memset(self, 0, sizeof self);
@@ -203,6 +256,77 @@ int main(int argc, char** argv)
             }
             fwrite(cell_pairs, 4, 400, out);
         }
+        fclose(in);
+        fclose(out);
+        return 0;
+    }
+    if (argc == 5 && strcmp(argv[4], "nb9") == 0) {
+        FILE* in = fopen(argv[2], "rb");
+        FILE* out = fopen(argv[3], "wb");
+        if (!in || !out) return 6;
+        int32_t n = 0;
+        if (fread(&n, 4, 1, in) != 1) return 6;
+        for (int i = 0; i < n; i++) {
+            int32_t wh[2];
+            if (fread(wh, 4, 2, in) != 2) return 6;
+            int32_t* table = malloc(sizeof(int32_t) * 9 * (size_t)wh[0] * wh[1]);
+            memset(table, 0x55, sizeof(int32_t) * 9 * (size_t)wh[0] * wh[1]);
+            dll_neighbors(img, table, wh[0], wh[1]);
+            fwrite(table, 4, 9 * (size_t)wh[0] * wh[1], out);
+            free(table);
+        }
+        fclose(in);
+        fclose(out);
+        return 0;
+    }
+    if (argc == 5 && strcmp(argv[4], "setscale") == 0) {
+        typedef void(__attribute__((ms_abi)) * void_fn)(void);
+        typedef void(__attribute__((ms_abi)) * scale_fn)(void* self, int scale);
+        FILE* in = fopen(argv[2], "rb");
+        FILE* out = fopen(argv[3], "wb");
+        if (!in || !out) return 6;
+        int32_t left[2];
+        if (fread(left, 4, 2, in) != 2) return 6;
+        ((void_fn)(img + 0x10b0))();                       /* the static initialiser of mScaleRatios[2], [3] */
+        fwrite(img + 0x2c5008, 8, 5, out);
+        *(void**)(img + 0x903f8) = (void*)stop_at_mat_zeros;
+        for (volatile int s = 0; s < 5; s++) {
+            static unsigned char self[0x400];
+            memset(self, 0, sizeof self);
+            *(int32_t*)(self + 0x50) = left[0];
+            *(int32_t*)(self + 0x54) = left[1];
+            memset(g_zeros_args, 0xff, sizeof g_zeros_args);
+            if (setjmp(g_back) == 0) {
+                ((scale_fn)(img + 0x48c10))(self, s);
+                return 7;                                   /* it must not get past cv::Mat::zeros */
+            }
+            int32_t res[6] = {*(int32_t*)(self + 0x58), *(int32_t*)(self + 0x5c), *(int32_t*)(self + 0x64),
+                              g_zeros_args[0], g_zeros_args[1], g_zeros_args[2]};
+            fwrite(res, 4, 6, out);
+        }
+        fclose(in);
+        fclose(out);
+        return 0;
+    }
+    if (argc == 5 && strcmp(argv[4], "normalize") == 0) {
+        typedef void(__attribute__((ms_abi)) * norm_fn)(void* self, void* kp_vec, const int32_t* size, void* out_vec);
+        FILE* in = fopen(argv[2], "rb");
+        FILE* out = fopen(argv[3], "wb");
+        if (!in || !out) return 6;
+        int32_t hdr[3];
+        if (fread(hdr, 4, 3, in) != 3) return 6;
+        const size_t n = (size_t)hdr[0];
+        unsigned char* kp = malloc(28 * (n ? n : 1));
+        float* npts = malloc(8 * (n ? n : 1));
+        if (fread(kp, 28, n, in) != n) return 6;
+        memset(npts, 0x55, 8 * (n ? n : 1));
+        void* kp_vec[3] = {kp, kp + 28 * n, kp + 28 * n};
+        void* out_vec[3] = {npts, (unsigned char*)npts + 8 * n, (unsigned char*)npts + 8 * n};
+        unsigned char self[0x200];
+        memset(self, 0, sizeof self);
+        ((norm_fn)(img + 0x48420))(self, kp_vec, hdr + 1, out_vec);
+        if (out_vec[0] != (void*)npts) return 7; /* it must not have reallocated */
+        fwrite(npts, 8, n, out);
         fclose(in);
         fclose(out);
         return 0;

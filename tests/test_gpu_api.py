@@ -255,7 +255,7 @@ def test_config3_thousand_frame_table_two_chunks(ctx, pkg, oracle, synth):
     size, n_frames, n_kp, per_chunk = (1920, 1080), 1000, 10000, 1024
     frames = synth.make_sequence(1000, n_frames, size=size, n_kp=n_kp)
     table = batch.FrameTable(ctx, frames, [size] * n_frames)
-    assert table.d_pts.numel() * 4 == 160_000_016 and table.total * 8 == 80_000_000   # points: 80 MB, beyond the L2s
+    assert table.d_pts.numel() * 4 == 160_000_032 and table.total * 8 == 80_000_000   # points: 80 MB, beyond the L2s
     dev = table.device
     kp_all = np.concatenate(frames)
     wh = np.array([size] * n_frames, dtype=np.int32).reshape(-1)
@@ -289,3 +289,82 @@ def test_config3_thousand_frame_table_two_chunks(ctx, pkg, oracle, synth):
             got = d_out[j * n_kp:j * n_kp + k].cpu().numpy().view(np.uint8).reshape(-1).view(pkg.DMATCH_DTYPE)
             assert got.tobytes() == wout[t * n_kp:t * n_kp + k].tobytes()
         del d_matches, d_out, d_res, d_pairs
+
+
+# ---- the frame table describes itself: any subset of its frames may be named by a filter call ------------------------------
+@pytest.mark.parametrize("rot,scale", [(False, False), (True, True)])
+def test_filter_with_a_prefix_of_the_frame_table(pkg, oracle, synth, rot, scale):
+    """gms_filter_device with n_frames smaller than the table was built for (and with an offsets array of its own): the kernels
+    read where the code arrays lie from the table's header, not from frame_off[n_frames]. Before the header existed this read
+    later frames' points as cell codes and returned wrong inliers without any error."""
+    import torch
+    batch = importlib.import_module("sfm-gms_amd.batch")
+    size = (1280, 720)
+    frames, pairs, matches = _sequence(pkg, synth, 8, 2500, 10, 93, size)
+    use = 5                                                     # the call names frames 0..4 only
+    keep = (pairs["frame_a"] < use) & (pairs["frame_b"] < use)
+    pairs = pairs[keep]
+    assert len(pairs) >= 3
+    with pkg.GmsContext(0) as ctx:
+        table = batch.FrameTable(ctx, frames, [size] * len(frames))
+        dev = table.device
+        d_foff = torch.from_numpy(table.frame_off_host[:use + 1].copy()).to(dev)
+        d_pairs, d_matches = batch._to_dev(pairs, dev), batch._to_dev(matches, dev)
+        d_out = torch.zeros(len(matches) * 16, dtype=torch.uint8, device=dev)
+        d_res = torch.zeros(len(pairs) * 16, dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize()
+        ctx.filter_device(table.d_pts.data_ptr(), d_foff.data_ptr(), use, d_pairs.data_ptr(), len(pairs), int(pairs["m"].max()),
+                          d_matches.data_ptr(), d_out.data_ptr(), d_res.data_ptr(), None, rot, scale, 6.0)
+        ctx.synchronize()
+        out, res = d_out.cpu().numpy().view(pkg.DMATCH_DTYPE), d_res.cpu().numpy().view(pkg.RESULT_DTYPE)
+        # a block that carries the points but no header (a caller's own copy of the points, say): filtered from the points alone
+        bare = table.d_pts.clone()
+        bare[:4] = 0
+        d_out2, d_res2 = torch.zeros_like(d_out), torch.zeros_like(d_res)
+        torch.cuda.synchronize()
+        ctx.filter_device(bare.data_ptr(), d_foff.data_ptr(), use, d_pairs.data_ptr(), len(pairs), int(pairs["m"].max()),
+                          d_matches.data_ptr(), d_out2.data_ptr(), d_res2.data_ptr(), None, rot, scale, 6.0)
+        ctx.synchronize()
+        out2, res2 = d_out2.cpu().numpy().view(pkg.DMATCH_DTYPE), d_res2.cpu().numpy().view(pkg.RESULT_DTYPE)
+    failed, wout, wres, _ = _oracle_batch(oracle, frames[:use], [size] * use, table.frame_off_host[:use + 1], pairs, matches, rot, scale)
+    assert failed == 0 and wres["n_inliers"].sum() > 0
+    _same(pairs, out, res, wout, wres)
+    _same(pairs, out2, res2, wout, wres)
+
+
+# ---- overlapping match ranges are refused (round 2's api.log: silently different counts on the large-pair path) -----------
+def test_overlapping_match_ranges_are_flagged(pkg, oracle, synth):
+    """Pairs own disjoint ranges [match_off, match_off + m) of the match / output arrays (include/gms.h). The device check runs behind
+    the first launch of a context: every pair that overlaps another gets GMS_ERR_BAD_ARG, the others keep their results. In order
+    (each range ending inside the next) and out of order (the table shuffled). The host-batch entry refuses the call."""
+    import torch
+    batch = importlib.import_module("sfm-gms_amd.batch")
+    size = (1280, 720)
+    for n_kp, shuffled in ((20000, False), (3000, True), (3000, False)):
+        frames, pairs, matches = _sequence(pkg, synth, 6, n_kp, 12, 95, size, ragged=False)
+        pairs = pairs.copy()
+        pairs["match_off"][5] -= n_kp // 2        # pair 5 now starts inside pair 4's range
+        pairs["m"][8] = 0                          # an empty pair overlaps nothing ...
+        pairs["match_off"][8] = pairs["match_off"][2] + 7   # ... wherever it points
+        order = np.random.default_rng(3).permutation(len(pairs)) if shuffled else np.arange(len(pairs))
+        tab = pairs[order]
+        want_bad = np.isin(order, [4, 5])
+        with pkg.GmsContext(0) as ctx:             # a fresh context: its first launch is a checked one
+            table = batch.FrameTable(ctx, frames, [size] * len(frames))
+            out, res, _ = batch.filter_pairs(ctx, table, tab, matches, False, False, 6.0, want_mask=False)
+            assert np.array_equal(res["status"] == -1, want_bad), (n_kp, shuffled, res["status"])
+            assert (res["status"][~want_bad] == 0).all()
+            good = np.flatnonzero(~want_bad & (order != 3))      # (pair 3 lies before 4: untouched; 4's tail was overwritten by 5's head)
+            failed, wout, wres, _ = _oracle_batch(oracle, frames, [size] * len(frames), table.frame_off_host, tab[good], matches, False, False)
+            assert failed == 0
+            _same(tab[good], out, res[good], wout, wres)
+            with pytest.raises(pkg.GmsError) as e:
+                ctx.filter_host_batch(frames, [size] * len(frames), tab, matches, False, False, 6.0)
+            assert e.value.code == -1
+            # the same table with the overlap removed passes both entries
+            fixed = tab.copy()
+            fixed["match_off"][np.flatnonzero(order == 5)[0]] += n_kp // 2
+            out, res, _ = batch.filter_pairs(ctx, table, fixed, matches, False, False, 6.0, want_mask=False)
+            assert (res["status"] == 0).all()
+            out2, res2 = ctx.filter_host_batch(frames, [size] * len(frames), fixed, matches, False, False, 6.0)
+            assert res2.tobytes() == res.tobytes()

@@ -184,7 +184,7 @@ def test_normalize_kernel_is_ieee_fp32_divide(ctx, pkg):
         xy[:3] = [[0.0, 0.0], [-0.0, -0.0], [np.nextafter(np.float32(w), np.float32(0)), 0.5]]
         frames.append(synth.make_keypoints(xy))
     table = batch.FrameTable(ctx, frames, sizes)
-    got = table.d_pts.cpu().numpy()[: 2 * table.total].reshape(-1, 2)
+    got = table.d_pts.cpu().numpy()[4: 4 + 2 * table.total].reshape(-1, 2)          # behind the table's 16-byte header
     for f, (w, h) in enumerate(sizes):
         lo, hi = table.frame_off_host[f], table.frame_off_host[f + 1]
         want = np.stack([frames[f]["x"] / np.float32(w), frames[f]["y"] / np.float32(h)], axis=1) + np.float32(0.0)
@@ -261,3 +261,19 @@ def test_full_size_properties(ctx, pkg, synth):
     # true correspondences (trainIdx == queryIdx) dominate what survives
     kept = out[: int(res["n_inliers"][0])]
     assert (kept["queryIdx"] == kept["trainIdx"]).mean() > 0.9
+
+
+def test_normalize_kernel_against_the_reference_binary(ctx, pkg, synth):
+    """The product kernel directly against the reference DLL: gms_normalize_device on the cv::KeyPoint coordinates of
+    tests/golden/refdll_normalize.npz must produce the bits GMSMatcher::normalizePoints produced when it was executed out of
+    opencv_xfeatures2d452.dll (tests/golden/make_refdll_vectors.py)."""
+    import os
+    batch = importlib.import_module("sfm-gms_amd.batch")
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "refdll_normalize.npz"))
+    n_cases = len([k for k in z.files if k.endswith("_size")])
+    frames = [synth.make_keypoints(z[f"c{i}_xy"]) for i in range(n_cases)]
+    sizes = [tuple(int(v) for v in z[f"c{i}_size"]) for i in range(n_cases)]
+    table = batch.FrameTable(ctx, frames, sizes)
+    got = table.d_pts.cpu().numpy()[4: 4 + 2 * table.total].reshape(-1, 2)
+    want = np.concatenate([z[f"c{i}_normalized"] for i in range(n_cases)])
+    assert got.view(np.uint32).tobytes() == want.view(np.uint32).tobytes()

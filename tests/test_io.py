@@ -57,3 +57,37 @@ def test_broken_files_are_refused(pkg, synth, tmp_path):
             io.load(p)
     assert lib.gms_dataset_read(str(tmp_path / "missing").encode(), C.byref(cd)) == -7
     assert lib.gms_error_string(-7).decode().startswith("dataset file")
+
+
+def test_crafted_headers_and_out_of_range_pairs_are_refused(pkg, synth, tmp_path):
+    """A header whose counts wrap the byte sizes (n_pairs = 2^60, total_matches = 2^59: 24 * 2^60 + 16 * 2^59 = 2^65 wraps to a tiny
+    allocation) or simply exceed the file, and pairs that name frames / match ranges outside the file: GMS_ERR_IO, nothing allocated."""
+    io, ds = _dataset(pkg, synth, -1)
+    lib = pkg.load_library()
+    good = str(tmp_path / "good.gmsf")
+    io.save(good, ds)
+    raw = bytearray(open(good, "rb").read())
+    hdr = np.frombuffer(bytes(raw[:40]), dtype=io._HEADER).copy()
+    cd = io._CDataset()
+
+    def refused(name, data):
+        p = str(tmp_path / name)
+        open(p, "wb").write(bytes(data))
+        assert lib.gms_dataset_read(p.encode(), C.byref(cd)) == -7 and cd.owner is None
+        with pytest.raises(ValueError):
+            io.load(p)
+
+    h = hdr.copy()
+    h["n_frames"], h["total_kp"], h["n_pairs"], h["total_matches"] = 0, 0, 1 << 60, 1 << 59
+    refused("wrap", h.tobytes() + bytes(raw[40:]))
+    h = hdr.copy()
+    h["total_matches"] = int(hdr["total_matches"][0]) + 1            # one match more than the file holds
+    refused("long", h.tobytes() + bytes(raw[40:]))
+    refused("padded", bytes(raw) + b"\0" * 16)                       # bytes the header does not account for
+    pair_off = 40 + 8 * 4 + 8 * 5 + 28 * 210                         # header, wh, frame_off, keypoints (no descriptors)
+    pairs = np.frombuffer(bytes(raw[pair_off:pair_off + 48]), dtype=pkg.PAIR_DTYPE).copy()
+    assert pairs.tobytes() == ds.pairs.tobytes()
+    for field, value in (("frame_b", 4), ("frame_a", -1), ("m", -3), ("match_off", 71), ("match_off", -1)):
+        bad = pairs.copy()
+        bad[field][1] = value
+        refused(f"pair_{field}_{value}", bytes(raw[:pair_off]) + bad.tobytes() + bytes(raw[pair_off + 48:]))

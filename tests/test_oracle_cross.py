@@ -96,3 +96,36 @@ def test_oracle_batch_threads_agree(oracle, synth, pkg):
     f4, o4, r4, m4 = oracle.batch(kp_all, foff, wh, pairs, matches, True, False, 6.0, 4)
     assert f1 == f4 == 0 and np.array_equal(m1, m4) and r1.tobytes() == r4.tobytes() and o1.tobytes() == o4.tobytes()
     assert r1["n_inliers"].sum() > 0
+
+
+def test_oracle_batch_on_reused_storage_equals_fresh_calls(oracle, synth, pkg):
+    """gms_ref_batch keeps one scratch state per thread (gms_ref_match_ws): a thread's pairs alternate between large and small
+    shapes and every flag combination, and each must equal the one-shot call on fresh storage."""
+    sizes = [(640, 480), (1920, 1080), (333, 777)]
+    counts = [700, 60, 1500, 5, 0, 900]
+    rng = np.random.default_rng(5)
+    frames = [synth.make_keypoints(np.stack([rng.uniform(0, sizes[i % 3][0] - 1, n), rng.uniform(0, sizes[i % 3][1] - 1, n)],
+                                            axis=1).astype(np.float32)) for i, n in enumerate(counts)]
+    foff = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+    wh = np.array([sizes[i % 3] for i in range(len(counts))], dtype=np.int32).reshape(-1)
+    combos = [(0, 2), (1, 3), (2, 0), (3, 5), (5, 2), (2, 5), (1, 0), (4, 2), (0, 5)]
+    pairs = np.zeros(len(combos), dtype=pkg.PAIR_DTYPE)
+    chunks, off = [], 0
+    for i, (a, b) in enumerate(combos):
+        m = 0 if min(counts[a], counts[b]) == 0 else int(rng.integers(1, 2 * counts[a]))
+        q = rng.integers(0, max(counts[a], 1), m)
+        t = np.where(rng.uniform(size=m) < 0.6, q % max(counts[b], 1), rng.integers(0, max(counts[b], 1), m))
+        chunks.append(synth.make_matches(q, t, rng))
+        pairs[i] = (a, b, m, 0, off)
+        off += m
+    matches = np.concatenate(chunks)
+    kp_all = np.concatenate(frames)
+    for rot, scale in cases.FLAGS:
+        for threads in (1, 3):
+            failed, out, res, mask = oracle.batch(kp_all, foff, wh, pairs, matches, rot, scale, 6.0, threads)
+            assert failed == 0
+            for i, (a, b) in enumerate(combos):
+                o, m = int(pairs[i]["match_off"]), int(pairs[i]["m"])
+                rc, want, wmask, wres = oracle.match(sizes[a % 3], sizes[b % 3], frames[a], frames[b], matches[o:o + m], rot, scale, 6.0)
+                assert rc == 0 and res[i].tobytes() == wres.tobytes()
+                assert np.array_equal(mask[o:o + m], wmask) and out[o:o + len(want)].tobytes() == want.tobytes()

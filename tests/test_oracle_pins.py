@@ -178,3 +178,53 @@ def test_cell_verification_matches_the_reference_binary(oracle):
     assert eq[5, 5] == 5 * 20 + 5          # 36 == 6 * sqrt(324 / 9): equality is not a rejection
     assert eq[10, 10] == -2 and eq[9, 11] == -2 and eq[12, 10] == 12 * 20 + 10   # one vote short around cell 210
     assert eq[0, 0] == -1 and eq[1, 1] == -2 and eq[0, 5] == -2                   # empty row; its neighbour; a border
+
+
+def test_neighbour_tables_match_the_reference_binary(oracle):
+    """tests/golden/refdll_nb9.npz: GMSMatcher::initalizeNeighbors -- and getNB9 through it -- executed out of the reference DLL
+    (its operator new / delete pointed at the host allocator: refdll_runner.c "nb9") for the left grid, the five right grids of
+    setScale and three odd grids. Both restatements must produce the same [w * h, 9] tables; the verify fixture above was
+    generated with the DLL's tables, so nothing the pinned verifyCellPairs body consumed comes from a restatement any more."""
+    import gms_ref_sparse
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "refdll_nb9.npz"))
+    grids = [tuple(int(v) for v in g) for g in z["grids"]]
+    assert {(20, 20), (10, 10), (14, 14), (28, 28), (40, 40)} <= set(grids) and len(grids) == 8
+    for w, h in grids:
+        want = z[f"nb9_{w}x{h}"]
+        assert want.shape == (w * h, 9)
+        assert np.array_equal(oracle.neighbors(w, h), want), (w, h)
+        assert np.array_equal(np.array([gms_ref_sparse._neighbors(i, w, h) for i in range(w * h)], dtype=np.int32), want), (w, h)
+    t = z["nb9_20x20"]
+    assert list(t[0]) == [-1, -1, -1, -1, 0, 1, -1, 20, 21] and list(t[399]) == [378, 379, -1, 398, 399, -1, -1, -1, -1]
+    assert list(z["nb9_7x3"][10]) == [2, 3, 4, 9, 10, 11, 16, 17, 18] and list(z["nb9_1x1"][0]) == [-1, -1, -1, -1, 0, -1, -1, -1, -1]
+
+
+def test_normalize_points_matches_the_reference_binary(oracle):
+    """tests/golden/refdll_normalize.npz: GMSMatcher::normalizePoints executed out of the reference DLL on cv::KeyPoint records of
+    eight image sizes (its four-at-a-time loop and its tail). The oracle's divide must give the same bits."""
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "refdll_normalize.npz"))
+    lib = oracle.load()
+    n_cases = len([k for k in z.files if k.endswith("_size")])
+    assert n_cases == 8
+    for i in range(n_cases):
+        w, h = (int(v) for v in z[f"c{i}_size"])
+        xy, want = z[f"c{i}_xy"], z[f"c{i}_normalized"]
+        got = np.array([[lib.gms_ref_normalize(float(x), w), lib.gms_ref_normalize(float(y), h)] for x, y in xy], dtype=np.float32)
+        assert got.view(np.uint32).tobytes() == want.view(np.uint32).tobytes(), (w, h)
+        assert (want[0] == 0).all() and want[-1, 0] < 1.0        # (0, 0) stays 0; the last representable x stays inside [0, 1)
+
+
+def test_set_scale_matches_the_reference_binary(oracle):
+    """tests/golden/refdll_setscale.npz: the DLL's static initialiser of mScaleRatios and the head of GMSMatcher::setScale, executed
+    out of the reference DLL for scales 0..4 on the 20 x 20 left grid and on a 15 x 25 one (7.5 -> 8, 12.5 -> 12, 37.5 -> 38:
+    cvRound is round-half-even). Right grid, cell count, and the n_right x 9 int32 neighbour table it then asks cv::Mat::zeros for."""
+    import ctypes as C
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "refdll_setscale.npz"))
+    lib = oracle.load()
+    assert [oracle.load().gms_ref_scale_ratio(s) for s in range(5)] == z["ratios"].tolist()
+    for key, (lw, lh) in (("left20x20", (20, 20)), ("left15x25", (15, 25))):
+        for s in range(5):
+            wr, hr = C.c_int(0), C.c_int(0)
+            lib.gms_ref_right_grid_from(lw, lh, s, C.byref(wr), C.byref(hr))
+            assert [wr.value, hr.value, wr.value * hr.value, wr.value * hr.value, 9, 4] == z[key][s].tolist(), (key, s)
+    assert z["left20x20"][:, 0].tolist() == [20, 10, 14, 28, 40] and z["left15x25"][1].tolist()[:2] == [8, 12]
