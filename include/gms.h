@@ -33,6 +33,7 @@ extern "C" {
 #define GMS_ERR_NO_DEVICE (-4) /* no usable gfx950 device                                        */
 #define GMS_ERR_CAPACITY  (-5) /* m exceeds what this build supports (see gms_max_matches())     */
 #define GMS_ERR_IO        (-7) /* gms_dataset_read / _write: cannot open, short file, or not a GMSFRM01 file             */
+#define GMS_ERR_NO_MODEL  (-8) /* two-view stage: fewer than five correspondences, or no essential matrix / pose could be estimated */
 #define GMS_ERR_NOT_RESERVED (-6) /* a workspace would have to grow while the stream is being captured: call
                                      gms_ctx_reserve() for this shape first                          */
 
@@ -245,8 +246,10 @@ int gms_triangulate_device(gms_ctx* ctx, const double camera[4], const double di
  * correspondence by triangulation in normalised coordinates (positive depth below the threshold in both cameras); the first of
  * (R1, t), (R2, t), (R1, -t), (R2, -t) with the most such points wins. E (3 x 3 row-major) and camera = (fx, fy, cx, cy) are HOST
  * pointers; d_in_mask (optional: findEssentialMat's inlier mask, non-zero = use) and everything else device pointers.
- * *d_pose receives R, t, the winner's point count and its index; d_out_mask (optional) 255 / 0 per correspondence.
- * Stream-ordered; the context keeps the max_matches + 40 bytes of scratch. fp64, agrees with OpenCV to rounding (R1 / R2 and the
+ * *d_pose receives R, t, the winner's point count and its index; d_out_mask (optional) per correspondence what the reference's
+ * bitwise_and leaves: the input mask's byte where the point passes (255 without an input mask), 0 elsewhere.
+ * Stream-ordered; the context keeps max_matches + 48 bytes of scratch, which grows (one stream synchronisation) on first use of a
+ * larger max_matches -- GMS_ERR_NOT_RESERVED instead when the stream is being captured; gms_ctx_reserve(ctx, 1, max_matches, ...) sizes it. fp64, agrees with OpenCV to rounding (R1 / R2 and the
  * sign of t may be numbered differently than by another SVD: `which` is informational). */
 typedef struct gms_pose {
     double  R[9], t[3];
@@ -255,6 +258,69 @@ typedef struct gms_pose {
 int gms_recover_pose_device(gms_ctx* ctx, const double E[9], const double camera[4], const float* d_coords1, const float* d_coords2,
                             const int32_t* d_n_matches, int max_matches, const uint8_t* d_in_mask, gms_pose* d_pose,
                             uint8_t* d_out_mask);
+
+/* ---- the same consumers for a whole batch ---------------------------------------------------------------------------
+ * What structureFromMotion does with the survivors of ONE pair (SfMUtil.cpp:25-82) and matchBasedDispCalculate with its map
+ * (DisparityUtil.cpp:170-201), for every pair of a batch per launch: same pair table, same offsets as gms_filter_device. Every
+ * per-match array (coords, mask, 3-D points) holds pair i's entries at its match_off (coords: 2 floats per match, points: 3 doubles),
+ * d_tv holds one record per pair. Stream-ordered on the context's stream, no allocation, no synchronisation, capturable.
+ *
+ *   gms_gather_points_batch_device   SfMUtil.cpp:25-35. Zeroes d_tv, then n_points = the pair's n_inliers and the coordinates.
+ *   gms_find_essential_batch_device  SfMUtil.cpp:39: cv::findEssentialMat(coords1, coords2, cameraMatrix, RANSAC, prob, threshold,
+ *       mask) of OpenCV 4.5.2 -- points normalised with the camera matrix, threshold / ((fx + fy) / 2), RANSAC over five-point
+ *       minimal solves (Nister) with cv::RNG((uint64)-1) drawing the samples, at most max_iters (OpenCV: 1000) iterations, the
+ *       bound shrinking by RANSACUpdateNumIters(prob, ...) whenever a model with strictly more inliers appears; error =
+ *       (x2^T E x1)^2 / (|E x1|_xy^2 + |E^T x2|_xy^2) as fp32 against (float)threshold^2. E: row-major, unit Frobenius norm, largest
+ *       entry positive (an SVD leaves the sign open); the models of one sample are tried in ascending order of E[0], E[1], ...
+ *       (OpenCV's order is that of its polynomial root finder: it only matters between models of equal inlier count).
+ *       d_mask: 1 / 0 per correspondence. Pairs with fewer than five correspondences or no model: status GMS_ERR_NO_MODEL.
+ *       fp64; agrees with an SVD / eigenvalue based implementation to rounding, not bit for bit.
+ *   gms_recover_pose_batch_device    SfMUtil.cpp:45: cv::recoverPose(E, coords1, coords2, cameraMatrix, R, t, mask), distance
+ *       threshold 50; d_mask is in/out as in the reference (use_in_mask = 0: output only, 255 / 0).
+ *   gms_triangulate_batch_device     SfMUtil.cpp:65-82,128-143: the correspondences with a non-zero mask byte (d_mask NULL: all),
+ *       compacted in order, cv::undistortPoints, cv::triangulatePoints with [I|0] and [R|t], division by the fourth coordinate:
+ *       pair i's n_triangulated points at d_points3d[3 * match_off ...]; reprojection error sums in normalised coordinates.
+ *   gms_two_view_batch_device        all four, in stream order.
+ *   gms_disparity_batch_device       DisparityUtil.cpp:170-201 per pair: pair i's map (width x height of frame_a, row-major) at
+ *       d_disparity + i * map_stride, its ground truth (optional) at d_gt + i * gt_stride (gt_stride 0: one image for all),
+ *       d_work: n_pairs * map_stride uint32 of scratch, d_stats one record per pair. */
+typedef struct gms_camera {   /* cameraMatrix and distCoeffs as structureFromMotion receives them (SfMUtil.cpp:4; main.cpp:59-67) */
+    double fx, fy, cx, cy;
+    double k1, k2, p1, p2, k3;
+} gms_camera;
+typedef struct gms_two_view {
+    double  E[9];                      /* findEssentialMat                                                   */
+    double  R[9], t[3];                /* recoverPose                                                        */
+    double  sum_sq_err1, sum_sq_err2;  /* sums of squared reprojection errors of the triangulated points     */
+    int64_t n_finite, n_behind;        /* triangulated points that are finite / of those, behind a camera    */
+    int32_t n_points;                  /* correspondences of the pair (the filter's n_inliers)               */
+    int32_t n_ransac;                  /* inliers of E (non-zero bytes of findEssentialMat's mask)           */
+    int32_t ransac_iters;              /* RANSAC iterations run                                              */
+    int32_t n_pose;                    /* recoverPose's return value                                         */
+    int32_t pose_which;                /* which of (R1,t) (R2,t) (R1,-t) (R2,-t) won: informational          */
+    int32_t n_triangulated;            /* points written to d_points3d                                       */
+    int32_t status;                    /* GMS_OK, GMS_ERR_DOMAIN, GMS_ERR_NO_MODEL, or the filter's status   */
+    int32_t reserved;
+} gms_two_view;
+int gms_gather_points_batch_device(gms_ctx* ctx, const gms_keypoint* d_kp, const int64_t* d_frame_off, int n_frames,
+                                   const gms_pair* d_pairs, int n_pairs, int max_m, const gms_dmatch* d_filtered,
+                                   const gms_pair_result* d_results, float* d_coords1, float* d_coords2, gms_two_view* d_tv);
+int gms_find_essential_batch_device(gms_ctx* ctx, const gms_camera* camera, double prob, double threshold, int max_iters,
+                                    const gms_pair* d_pairs, int n_pairs, const float* d_coords1, const float* d_coords2,
+                                    uint8_t* d_mask, gms_two_view* d_tv);
+int gms_recover_pose_batch_device(gms_ctx* ctx, const gms_camera* camera, int use_in_mask, const gms_pair* d_pairs, int n_pairs,
+                                  const float* d_coords1, const float* d_coords2, uint8_t* d_mask, gms_two_view* d_tv);
+int gms_triangulate_batch_device(gms_ctx* ctx, const gms_camera* camera, const gms_pair* d_pairs, int n_pairs,
+                                 const float* d_coords1, const float* d_coords2, const uint8_t* d_mask, double* d_points3d,
+                                 gms_two_view* d_tv);
+int gms_two_view_batch_device(gms_ctx* ctx, const gms_camera* camera, double prob, double threshold, int max_iters,
+                              const gms_keypoint* d_kp, const int64_t* d_frame_off, int n_frames, const gms_pair* d_pairs, int n_pairs,
+                              int max_m, const gms_dmatch* d_filtered, const gms_pair_result* d_results, float* d_coords1,
+                              float* d_coords2, uint8_t* d_mask, double* d_points3d, gms_two_view* d_tv);
+int gms_disparity_batch_device(gms_ctx* ctx, const gms_keypoint* d_kp, const int64_t* d_frame_off, const int32_t* d_wh, int n_frames,
+                               const gms_pair* d_pairs, int n_pairs, int max_m, const gms_dmatch* d_filtered,
+                               const gms_pair_result* d_results, const uint8_t* d_gt, int64_t gt_stride, int disp_ratio,
+                               uint8_t* d_disparity, int64_t map_stride, uint32_t* d_work, gms_disparity_stats* d_stats);
 
 /* ---- ingest format -----------------------------------------------------------------------------------------
  * The reference keeps detector and matcher output in process (std::vector<cv::KeyPoint>, cv::Mat descriptors,
@@ -288,6 +354,11 @@ const char* gms_version(void);
  * Host pointers; out[i] = 1 iff the cell would be rejected. */
 int gms_selftest_threshold(gms_ctx* ctx, const int32_t* T, const int32_t* n, const int32_t* score,
                            double factor, int count, uint8_t* out);
+
+/* Test hook (no production use): the five-point minimal solver of gms_find_essential_batch_device alone, exactly as the RANSAC
+ * kernel runs it, on n_samples caller-given samples of NORMALISED points. Host pointers: pts[20 s ..] = x1[5], y1[5], x2[5], y2[5]
+ * of sample s; models[90 s ..] receives up to ten 3 x 3 matrices (zeros beyond counts[s]). */
+int gms_selftest_five_point(gms_ctx* ctx, const double* pts, int n_samples, double* models, int32_t* counts);
 
 #ifdef __cplusplus
 }

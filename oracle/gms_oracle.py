@@ -106,17 +106,22 @@ def match(size1, size2, kp1, kp2, matches, with_rotation=False, with_scale=False
 
 
 def batch(kp_all, frame_off, wh, pairs, matches, with_rotation=False, with_scale=False, threshold_factor=6.0,
-          n_threads=1):
-    """Returns (n_failed, out, results, mask) over a batch of pairs."""
+          n_threads=1, bufs=None):
+    """Returns (n_failed, out, results, mask) over a batch of pairs. bufs = (out, mask, res) arrays to write into (timing loops pass
+    the same, already touched, arrays every time so that no page fault of a fresh allocation lands inside the timed call)."""
     lib = load()
     kp_all = np.ascontiguousarray(kp_all, dtype=KEYPOINT_DTYPE)
     frame_off = np.ascontiguousarray(frame_off, dtype=np.int64)
     wh = np.ascontiguousarray(wh, dtype=np.int32)
     pairs = np.ascontiguousarray(pairs, dtype=PAIR_DTYPE)
     mt = np.ascontiguousarray(matches, dtype=DMATCH_DTYPE)
-    out = np.zeros(max(len(mt), 1), dtype=DMATCH_DTYPE)
-    mask = np.zeros(max(len(mt), 1), dtype=np.uint8)
-    res = np.zeros(max(len(pairs), 1), dtype=RESULT_DTYPE)
+    if bufs is not None:
+        out, mask, res = bufs
+        assert len(out) >= max(len(mt), 1) and len(mask) >= max(len(mt), 1) and len(res) >= max(len(pairs), 1)
+    else:
+        out = np.zeros(max(len(mt), 1), dtype=DMATCH_DTYPE)
+        mask = np.zeros(max(len(mt), 1), dtype=np.uint8)
+        res = np.zeros(max(len(pairs), 1), dtype=RESULT_DTYPE)
     failed = lib.gms_ref_batch(kp_all.ctypes.data, frame_off.ctypes.data, wh.ctypes.data, len(frame_off) - 1,
                                pairs.ctypes.data, len(pairs), mt.ctypes.data, int(bool(with_rotation)),
                                int(bool(with_scale)), float(threshold_factor), out.ctypes.data,

@@ -176,6 +176,51 @@ class GmsContext:
         _check(self._lib.gms_recover_pose_device(self._h, e.ctypes.data, cam.ctypes.data, d_coords1, d_coords2, d_n_matches,
                                                  int(max_matches), d_in_mask, d_pose, d_out_mask), self._lib, "gms_recover_pose_device")
 
+    # -- the same consumers for a whole batch (SfMUtil.cpp:25-82, DisparityUtil.cpp:170-201): one launch per stage ---------------------
+    def gather_points_batch_device(self, d_kp, d_frame_off, n_frames, d_pairs, n_pairs, max_m, d_filtered, d_results, d_coords1,
+                                   d_coords2, d_tv):
+        _check(self._lib.gms_gather_points_batch_device(self._h, d_kp, d_frame_off, int(n_frames), d_pairs, int(n_pairs), int(max_m),
+                                                        d_filtered, d_results, d_coords1, d_coords2, d_tv),
+               self._lib, "gms_gather_points_batch_device")
+
+    def find_essential_batch_device(self, camera, d_pairs, n_pairs, d_coords1, d_coords2, d_mask, d_tv, prob=0.999, threshold=1.0,
+                                    max_iters=1000):
+        """cv::findEssentialMat(..., RANSAC, prob, threshold, mask) per pair; camera: a CAMERA_DTYPE record (types.make_camera)."""
+        _check(self._lib.gms_find_essential_batch_device(self._h, camera.ctypes.data, float(prob), float(threshold), int(max_iters),
+                                                         d_pairs, int(n_pairs), d_coords1, d_coords2, d_mask, d_tv),
+               self._lib, "gms_find_essential_batch_device")
+
+    def recover_pose_batch_device(self, camera, d_pairs, n_pairs, d_coords1, d_coords2, d_mask, d_tv, use_in_mask=True):
+        _check(self._lib.gms_recover_pose_batch_device(self._h, camera.ctypes.data, int(bool(use_in_mask)), d_pairs, int(n_pairs),
+                                                       d_coords1, d_coords2, d_mask, d_tv), self._lib, "gms_recover_pose_batch_device")
+
+    def triangulate_batch_device(self, camera, d_pairs, n_pairs, d_coords1, d_coords2, d_mask, d_points3d, d_tv):
+        _check(self._lib.gms_triangulate_batch_device(self._h, camera.ctypes.data, d_pairs, int(n_pairs), d_coords1, d_coords2,
+                                                      d_mask or None, d_points3d, d_tv), self._lib, "gms_triangulate_batch_device")
+
+    def two_view_batch_device(self, camera, d_kp, d_frame_off, n_frames, d_pairs, n_pairs, max_m, d_filtered, d_results, d_coords1,
+                              d_coords2, d_mask, d_points3d, d_tv, prob=0.999, threshold=1.0, max_iters=1000):
+        """SfMUtil.cpp:25-82 for every pair of the batch: gather -> findEssentialMat -> recoverPose -> undistort + triangulate."""
+        _check(self._lib.gms_two_view_batch_device(self._h, camera.ctypes.data, float(prob), float(threshold), int(max_iters), d_kp,
+                                                   d_frame_off, int(n_frames), d_pairs, int(n_pairs), int(max_m), d_filtered, d_results,
+                                                   d_coords1, d_coords2, d_mask, d_points3d, d_tv), self._lib, "gms_two_view_batch_device")
+
+    def disparity_batch_device(self, d_kp, d_frame_off, d_wh, n_frames, d_pairs, n_pairs, max_m, d_filtered, d_results, d_gt, gt_stride,
+                               disp_ratio, d_disparity, map_stride, d_work, d_stats):
+        _check(self._lib.gms_disparity_batch_device(self._h, d_kp, d_frame_off, d_wh, int(n_frames), d_pairs, int(n_pairs), int(max_m),
+                                                    d_filtered, d_results, d_gt or None, int(gt_stride), int(disp_ratio), d_disparity,
+                                                    int(map_stride), d_work, d_stats), self._lib, "gms_disparity_batch_device")
+
+    def selftest_five_point(self, x1, x2):
+        """gms_selftest_five_point: x1, x2 [n_samples, 5, 2] normalised points -> list of [k, 3, 3] model arrays, one per sample."""
+        x1 = np.asarray(x1, dtype=np.float64).reshape(-1, 5, 2)
+        x2 = np.asarray(x2, dtype=np.float64).reshape(-1, 5, 2)
+        n = len(x1)
+        pts = np.ascontiguousarray(np.concatenate([x1[:, :, 0], x1[:, :, 1], x2[:, :, 0], x2[:, :, 1]], axis=1))
+        models, counts = np.zeros((max(n, 1), 90)), np.zeros(max(n, 1), dtype=np.int32)
+        _check(self._lib.gms_selftest_five_point(self._h, pts.ctypes.data, n, models.ctypes.data, counts.ctypes.data), self._lib, "selftest_five_point")
+        return [models[i, :9 * counts[i]].reshape(-1, 3, 3) for i in range(n)]
+
     def selftest_threshold(self, T, n, score, factor):
         T = np.ascontiguousarray(T, dtype=np.int32)
         n = np.ascontiguousarray(n, dtype=np.int32)

@@ -9,8 +9,10 @@ EXPORTED_SYMBOLS = [
     "gms_match", "gms_match_ctx", "gms_ctx_create", "gms_ctx_destroy", "gms_ctx_set_stream",
     "gms_ctx_synchronize", "gms_ctx_reserve", "gms_ctx_query", "gms_frame_table_bytes", "gms_normalize_device", "gms_filter_device",
     "gms_filter_host_batch", "gms_bf_prepared_bytes", "gms_bf_prepare_device", "gms_bfmatch_device", "gms_disparity_device",
-    "gms_gather_points_device", "gms_triangulate_device", "gms_recover_pose_device", "gms_dataset_write", "gms_dataset_read", "gms_dataset_free", "gms_max_matches",
-    "gms_last_hip_error", "gms_error_string", "gms_version", "gms_selftest_threshold",
+    "gms_gather_points_device", "gms_triangulate_device", "gms_recover_pose_device",
+    "gms_gather_points_batch_device", "gms_find_essential_batch_device", "gms_recover_pose_batch_device", "gms_triangulate_batch_device",
+    "gms_two_view_batch_device", "gms_disparity_batch_device", "gms_dataset_write", "gms_dataset_read", "gms_dataset_free", "gms_max_matches",
+    "gms_last_hip_error", "gms_error_string", "gms_version", "gms_selftest_threshold", "gms_selftest_five_point",
 ]
 
 _lib = None
@@ -55,9 +57,16 @@ def load_library():
     lib.gms_gather_points_device.argtypes = [vp, vp, i32, vp, i32, vp, vp, i32, vp, vp, vp]
     lib.gms_triangulate_device.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp]
     lib.gms_recover_pose_device.argtypes = [vp, vp, vp, vp, vp, vp, i32, vp, vp, vp]
+    lib.gms_gather_points_batch_device.argtypes = [vp, vp, vp, i32, vp, i32, i32, vp, vp, vp, vp, vp]
+    lib.gms_find_essential_batch_device.argtypes = [vp, vp, dbl, dbl, i32, vp, i32, vp, vp, vp, vp]
+    lib.gms_recover_pose_batch_device.argtypes = [vp, vp, i32, vp, i32, vp, vp, vp, vp]
+    lib.gms_triangulate_batch_device.argtypes = [vp, vp, vp, i32, vp, vp, vp, vp, vp]
+    lib.gms_two_view_batch_device.argtypes = [vp, vp, dbl, dbl, i32, vp, vp, i32, vp, i32, i32, vp, vp, vp, vp, vp, vp, vp]
+    lib.gms_disparity_batch_device.argtypes = [vp, vp, vp, vp, i32, vp, i32, i32, vp, vp, vp, i64, i32, vp, i64, vp, vp]
     lib.gms_normalize_device.argtypes = [vp, vp, vp, vp, i32, i64, vp]
     lib.gms_filter_device.argtypes = [vp, vp, vp, i32, vp, i32, i32, vp, i32, i32, dbl, vp, vp, vp]
     lib.gms_selftest_threshold.argtypes = [vp, vp, vp, vp, dbl, i32, vp]
+    lib.gms_selftest_five_point.argtypes = [vp, vp, i32, vp, vp]
     lib.gms_max_matches.argtypes = []
     lib.gms_last_hip_error.argtypes = []
     lib.gms_error_string.argtypes = [i32]

@@ -15,6 +15,7 @@
 #include <stdint.h>
 
 #include "gms_kernels.h"
+#include "twoview_core.h"
 
 namespace gms {
 namespace {
@@ -107,93 +108,12 @@ gather_points_kernel(const gms_keypoint* __restrict__ kp1, int n1, const gms_key
 // ---- two-view triangulation + reprojection error (SfMUtil.cpp:76-82,128-143) --------------------------------------------------------
 // Per surviving match: cv::undistortPoints with the camera matrix and (k1, k2, p1, p2, k3) -- the published five fixed-point
 // iterations -- gives normalised coordinates; cv::triangulatePoints' homogeneous DLT (rows x P[2] - P[0], y P[2] - P[1] of both
-// cameras, the right singular vector of the smallest singular value) gives X; SfMUtil.cpp:134-139 divides by X[3]. The singular
-// vector is computed as the eigenvector of the smallest eigenvalue of A^T A by cyclic Jacobi rotations in fp64 (a 4 x 4 symmetric
-// matrix: exact up to rounding after a few sweeps). Floating point, not bit-exact against OpenCV's SVD: the tests state the tolerance.
+// cameras, the right singular vector of the smallest singular value) gives X; SfMUtil.cpp:134-139 divides by X[3]. The arithmetic
+// (undistort_point, dlt_point) is twoview_core.h. Floating point, not bit-exact against OpenCV's SVD: the tests state the tolerance.
 struct CameraModel {
-    double fx, fy, cx, cy, k1, k2, p1, p2, k3;
+    tv::Camera c;
     double P1[12], P2[12];
 };
-
-__device__ inline void undistort_point(const CameraModel& c, double u, double v, double& xo, double& yo)
-{
-    const double x0 = (u - c.cx) / c.fx, y0 = (v - c.cy) / c.fy;
-    double x = x0, y = y0;
-    if (c.k1 != 0.0 || c.k2 != 0.0 || c.p1 != 0.0 || c.p2 != 0.0 || c.k3 != 0.0) {
-        for (int it = 0; it < 5; ++it) {
-            const double r2 = x * x + y * y;
-            const double icdist = 1.0 / (1.0 + ((c.k3 * r2 + c.k2) * r2 + c.k1) * r2);
-            const double dx = 2.0 * c.p1 * x * y + c.p2 * (r2 + 2.0 * x * x);
-            const double dy = c.p1 * (r2 + 2.0 * y * y) + 2.0 * c.p2 * x * y;
-            x = (x0 - dx) * icdist;
-            y = (y0 - dy) * icdist;
-        }
-    }
-    xo = x;
-    yo = y;
-}
-
-// cv::triangulatePoints for one correspondence: the homogeneous X with x1 ~ Pa X, x2 ~ Pb X -- the right singular vector of the
-// smallest singular value of the 4 x 4 DLT matrix, as the eigenvector of the smallest eigenvalue of A^T A (cyclic Jacobi, fp64).
-__device__ inline void dlt_point(const double* Pa, const double* Pb, double x1, double y1, double x2, double y2, double X[4])
-{
-    double A[4][4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        A[0][k] = x1 * Pa[8 + k] - Pa[k];
-        A[1][k] = y1 * Pa[8 + k] - Pa[4 + k];
-        A[2][k] = x2 * Pb[8 + k] - Pb[k];
-        A[3][k] = y2 * Pb[8 + k] - Pb[4 + k];
-    }
-    double S[4][4], V[4][4];
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            S[a][b] = A[0][a] * A[0][b] + A[1][a] * A[1][b] + A[2][a] * A[2][b] + A[3][a] * A[3][b];
-            V[a][b] = a == b ? 1.0 : 0.0;
-        }
-    for (int sweep = 0; sweep < 12; ++sweep) {
-        double off = 0.0;
-#pragma unroll
-        for (int a = 0; a < 4; ++a)
-#pragma unroll
-            for (int b = a + 1; b < 4; ++b) off += S[a][b] * S[a][b];
-        if (off < 1e-300) break;
-#pragma unroll
-        for (int p = 0; p < 3; ++p)
-#pragma unroll
-            for (int q = p + 1; q < 4; ++q) {
-                if (S[p][q] == 0.0) continue;
-                const double theta = (S[q][q] - S[p][p]) / (2.0 * S[p][q]);
-                const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
-                const double cs = 1.0 / sqrt(t * t + 1.0), sn = t * cs;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {  // S <- S J (columns p, q)
-                    const double skp = S[k][p], skq = S[k][q];
-                    S[k][p] = cs * skp - sn * skq;
-                    S[k][q] = sn * skp + cs * skq;
-                }
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {  // S <- J^T S (rows p, q)
-                    const double spk = S[p][k], sqk = S[q][k];
-                    S[p][k] = cs * spk - sn * sqk;
-                    S[q][k] = sn * spk + cs * sqk;
-                }
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const double vkp = V[k][p], vkq = V[k][q];
-                    V[k][p] = cs * vkp - sn * vkq;
-                    V[k][q] = sn * vkp + cs * vkq;
-                }
-            }
-    }
-    int best = 0;
-#pragma unroll
-    for (int k = 1; k < 4; ++k) best = S[k][k] < S[best][best] ? k : best;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) X[k] = best == 0 ? V[k][0] : best == 1 ? V[k][1] : best == 2 ? V[k][2] : V[k][3];
-}
 
 __global__ void __launch_bounds__(256)
 triangulate_kernel(CameraModel cam, const float2* __restrict__ coords1, const float2* __restrict__ coords2,
@@ -205,10 +125,10 @@ triangulate_kernel(CameraModel cam, const float2* __restrict__ coords1, const fl
     unsigned long long cnt = 0, behind = 0;
     if (i < n) {
         double x1, y1, x2, y2;
-        undistort_point(cam, (double)coords1[i].x, (double)coords1[i].y, x1, y1);
-        undistort_point(cam, (double)coords2[i].x, (double)coords2[i].y, x2, y2);
+        tv::undistort_point(cam.c, (double)coords1[i].x, (double)coords1[i].y, x1, y1);
+        tv::undistort_point(cam.c, (double)coords2[i].x, (double)coords2[i].y, x2, y2);
         double X[4];
-        dlt_point(cam.P1, cam.P2, x1, y1, x2, y2, X);
+        tv::dlt_point(cam.P1, cam.P2, x1, y1, x2, y2, X);
         const double px = X[0] / X[3], py = X[1] / X[3], pz = X[2] / X[3];  // SfMUtil.cpp:134-137
         points3d[3 * (size_t)i] = px;
         points3d[3 * (size_t)i + 1] = py;
@@ -268,7 +188,7 @@ pose_votes_kernel(PoseModel pm, const float2* __restrict__ coords1, const float2
         for (int h = 0; h < 4; ++h) {
             const double* P = pm.P[h];
             double Q[4];
-            dlt_point(P0, P, x1, y1, x2, y2, Q);
+            tv::dlt_point(P0, P, x1, y1, x2, y2, Q);
             bool ok = Q[2] * Q[3] > 0.0;
             const double qx = Q[0] / Q[3], qy = Q[1] / Q[3], qz = Q[2] / Q[3];
             ok = ok && qz < pm.dist_thresh;
@@ -287,7 +207,7 @@ pose_votes_kernel(PoseModel pm, const float2* __restrict__ coords1, const float2
 
 __global__ void __launch_bounds__(256)
 pose_pick_kernel(PoseModel pm, const int32_t* __restrict__ n_matches, int cap, const uint8_t* __restrict__ votes,
-                 const unsigned long long* __restrict__ counts, gms_pose* __restrict__ pose, uint8_t* __restrict__ out_mask)
+                 const unsigned long long* __restrict__ counts, const uint8_t* in_mask, gms_pose* __restrict__ pose, uint8_t* out_mask)
 {
     const unsigned long long g0 = counts[0], g1 = counts[1], g2 = counts[2], g3 = counts[3];
     int w;  // recoverPose's chain of comparisons
@@ -306,7 +226,8 @@ pose_pick_kernel(PoseModel pm, const int32_t* __restrict__ n_matches, int cap, c
     if (out_mask != nullptr) {
         const int n = min(*n_matches, cap);
         const int i = (int)(blockIdx.x * 256u + threadIdx.x);
-        if (i < n) out_mask[i] = ((votes[i] >> w) & 1u) ? 255 : 0;
+        // cv::recoverPose: bitwise_and(mask, hypothesis mask) -- the caller's byte where the point passes (255 without an input mask)
+        if (i < n) out_mask[i] = ((votes[i] >> w) & 1u) ? (in_mask ? in_mask[i] : (uint8_t)255) : (uint8_t)0;
     }
 }
 
@@ -330,7 +251,7 @@ hipError_t launch_recover_pose(const double* camera, const double P[4][12], doub
     if (max_matches > 0)
         hipLaunchKernelGGL(pose_votes_kernel, dim3(blocks), dim3(256), 0, stream, pm, reinterpret_cast<const float2*>(d_coords1),
                            reinterpret_cast<const float2*>(d_coords2), d_n_matches, max_matches, d_in_mask, votes, counts);
-    hipLaunchKernelGGL(pose_pick_kernel, dim3(blocks ? blocks : 1u), dim3(256), 0, stream, pm, d_n_matches, max_matches, votes, counts, d_pose,
+    hipLaunchKernelGGL(pose_pick_kernel, dim3(blocks ? blocks : 1u), dim3(256), 0, stream, pm, d_n_matches, max_matches, votes, counts, d_in_mask, d_pose,
                        max_matches > 0 ? d_out_mask : nullptr);
     return hipGetLastError();
 }
@@ -340,9 +261,9 @@ hipError_t launch_triangulate(const double* camera, const double* dist, const do
                               gms_triangulation_stats* d_stats, hipStream_t stream)
 {
     CameraModel cam;
-    cam.fx = camera[0]; cam.fy = camera[1]; cam.cx = camera[2]; cam.cy = camera[3];
-    cam.k1 = dist ? dist[0] : 0.0; cam.k2 = dist ? dist[1] : 0.0; cam.p1 = dist ? dist[2] : 0.0; cam.p2 = dist ? dist[3] : 0.0;
-    cam.k3 = dist ? dist[4] : 0.0;
+    cam.c.fx = camera[0]; cam.c.fy = camera[1]; cam.c.cx = camera[2]; cam.c.cy = camera[3];
+    cam.c.k1 = dist ? dist[0] : 0.0; cam.c.k2 = dist ? dist[1] : 0.0; cam.c.p1 = dist ? dist[2] : 0.0; cam.c.p2 = dist ? dist[3] : 0.0;
+    cam.c.k3 = dist ? dist[4] : 0.0;
     for (int k = 0; k < 12; ++k) {
         cam.P1[k] = P1[k];
         cam.P2[k] = P2[k];

@@ -18,11 +18,13 @@
 
 #include "gms.h"
 #include "gms_kernels.h"
+#include "twoview_core.h"
 
 static_assert(sizeof(gms_keypoint) == 28, "gms_keypoint must match cv::KeyPoint (stride 0x1c)");
 static_assert(sizeof(gms_dmatch) == 16, "gms_dmatch must match cv::DMatch (stride 0x10)");
 static_assert(sizeof(gms_pair) == 24, "gms_pair layout");
 static_assert(sizeof(gms_pair_result) == 16, "gms_pair_result layout");
+static_assert(sizeof(gms_two_view) == 232 && sizeof(gms_camera) == 72, "two-view records");
 
 static thread_local int t_last_hip = 0;
 #ifdef GMS_PHASE_TIMING
@@ -230,6 +232,19 @@ int grow_workspace(gms_ctx* c, const WsNeed& w, hipStream_t st)
     return GMS_OK;
 }
 
+// The scratch of gms_recover_pose_device (vote bytes + counters): grown like the filter's workspaces -- never inside a stream
+// capture, and only after everything that may still use the old block has finished.
+int grow_pose_ws(gms_ctx* c, size_t bytes, hipStream_t st)
+{
+    if (bytes <= c->pose_ws.cap) return GMS_OK;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) return GMS_ERR_NOT_RESERVED;
+    GMS_HIP(hipStreamSynchronize(st));
+    GMS_HIP(hipDeviceSynchronize());  // (an earlier call may have run on another stream of the caller's)
+    GMS_HIP(c->pose_ws.reserve(bytes));
+    return GMS_OK;
+}
+
 // The filter launches of one call on stream `st`. The caller holds c->mu and has selected the device.
 int filter_launch(gms_ctx* c, hipStream_t st, const float* d_pts, const int64_t* d_frame_off, int n_frames,
                   const gms_pair* d_pairs, int n_pairs, int max_m, const gms_dmatch* d_matches,
@@ -426,6 +441,7 @@ const char* gms_error_string(int code)
     case GMS_ERR_NO_DEVICE: return "no usable HIP device";
     case GMS_ERR_CAPACITY: return "too many matches per pair for this build";
     case GMS_ERR_IO: return "dataset file: cannot open, truncated, or not a GMSFRM01 file";
+    case GMS_ERR_NO_MODEL: return "two-view stage: too few correspondences, or no essential matrix / pose found";
     case GMS_ERR_NOT_RESERVED: return "workspace not reserved for this shape (stream capture in progress)";
     default: return "unknown error";
     }
@@ -554,7 +570,8 @@ int gms_ctx_reserve(gms_ctx* c, int n_pairs, int max_m, int with_rotation, int w
     GMS_TRY(plan_workspace(c, n_pairs, max_m, with_rotation != 0, with_scale != 0, true, &w));
     GMS_TRY(plan_workspace(c, n_pairs, max_m, with_rotation != 0, with_scale != 0, false, &w2));
     w.band = std::max(w.band, w2.band);
-    return grow_workspace(c, w, c->stream);
+    GMS_TRY(grow_workspace(c, w, c->stream));
+    return grow_pose_ws(c, (size_t)max_m + 48, c->stream);  // gms_recover_pose_device on a pair of this size
 }
 
 // header (16) | points (8 each) | lcode, rcode (2 each) | scode (4 each) | 16 spare bytes (the staging copies read whole uint4s)
@@ -912,88 +929,6 @@ int gms_triangulate_device(gms_ctx* c, const double camera[4], const double dist
     return GMS_OK;
 }
 
-// cv::decomposeEssentialMat: E = U diag(s, s, 0) V^T with det U = det V = +1, R1 = U W V^T, R2 = U W^T V^T, t = U's last column.
-// V and the singular values come from the eigen-decomposition of E^T E (cyclic Jacobi, fp64), U's first two columns from E v / s,
-// its third as their cross product (so det U = +1 by construction).
-static bool decompose_essential(const double E[9], double R1[9], double R2[9], double t[3])
-{
-    double S[3][3], V[3][3];
-    for (int a = 0; a < 3; ++a)
-        for (int b = 0; b < 3; ++b) {
-            S[a][b] = E[a] * E[b] + E[3 + a] * E[3 + b] + E[6 + a] * E[6 + b];
-            V[a][b] = a == b ? 1.0 : 0.0;
-        }
-    for (int sweep = 0; sweep < 30; ++sweep) {
-        const double off = S[0][1] * S[0][1] + S[0][2] * S[0][2] + S[1][2] * S[1][2];
-        if (off < 1e-300) break;
-        for (int p = 0; p < 2; ++p)
-            for (int q = p + 1; q < 3; ++q) {
-                if (S[p][q] == 0.0) continue;
-                const double theta = (S[q][q] - S[p][p]) / (2.0 * S[p][q]);
-                const double tt = (theta >= 0.0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
-                const double cs = 1.0 / std::sqrt(tt * tt + 1.0), sn = tt * cs;
-                for (int k = 0; k < 3; ++k) {
-                    const double a = S[k][p], b = S[k][q];
-                    S[k][p] = cs * a - sn * b;
-                    S[k][q] = sn * a + cs * b;
-                }
-                for (int k = 0; k < 3; ++k) {
-                    const double a = S[p][k], b = S[q][k];
-                    S[p][k] = cs * a - sn * b;
-                    S[q][k] = sn * a + cs * b;
-                }
-                for (int k = 0; k < 3; ++k) {
-                    const double a = V[k][p], b = V[k][q];
-                    V[k][p] = cs * a - sn * b;
-                    V[k][q] = sn * a + cs * b;
-                }
-            }
-    }
-    int ord[3] = {0, 1, 2};  // eigenvalues descending
-    for (int a = 0; a < 3; ++a)
-        for (int b = a + 1; b < 3; ++b)
-            if (S[ord[b]][ord[b]] > S[ord[a]][ord[a]]) std::swap(ord[a], ord[b]);
-    double v[3][3];  // v[j] = j-th right singular vector
-    for (int j = 0; j < 3; ++j)
-        for (int k = 0; k < 3; ++k) v[j][k] = V[k][ord[j]];
-    const double det = v[0][0] * (v[1][1] * v[2][2] - v[1][2] * v[2][1]) - v[0][1] * (v[1][0] * v[2][2] - v[1][2] * v[2][0]) +
-                       v[0][2] * (v[1][0] * v[2][1] - v[1][1] * v[2][0]);
-    if (det < 0.0)
-        for (int k = 0; k < 3; ++k) v[2][k] = -v[2][k];  // (the null direction: E v2 = 0 either way)
-    double u[3][3];
-    for (int j = 0; j < 2; ++j) {
-        double n2 = 0.0;
-        for (int r = 0; r < 3; ++r) {
-            u[j][r] = E[3 * r] * v[j][0] + E[3 * r + 1] * v[j][1] + E[3 * r + 2] * v[j][2];
-            n2 += u[j][r] * u[j][r];
-        }
-        if (!(n2 > 0.0)) return false;  // rank below two: not an essential matrix
-        const double inv = 1.0 / std::sqrt(n2);
-        for (int r = 0; r < 3; ++r) u[j][r] *= inv;
-    }
-    {   // re-orthogonalise u1 against u0 (the two singular values of an estimated E differ slightly: E v / |E v| is orthogonal only
-        // to rounding of the eigenvectors), then u2 = u0 x u1
-        double d = u[0][0] * u[1][0] + u[0][1] * u[1][1] + u[0][2] * u[1][2], n2 = 0.0;
-        for (int r = 0; r < 3; ++r) {
-            u[1][r] -= d * u[0][r];
-            n2 += u[1][r] * u[1][r];
-        }
-        const double inv = 1.0 / std::sqrt(n2);
-        for (int r = 0; r < 3; ++r) u[1][r] *= inv;
-    }
-    u[2][0] = u[0][1] * u[1][2] - u[0][2] * u[1][1];
-    u[2][1] = u[0][2] * u[1][0] - u[0][0] * u[1][2];
-    u[2][2] = u[0][0] * u[1][1] - u[0][1] * u[1][0];
-    // W = [0 1 0; -1 0 0; 0 0 1]: U W = [-u1, u0, u2], U W^T = [u1, -u0, u2] (columns); R1 = U W V^T, R2 = U W^T V^T
-    for (int r = 0; r < 3; ++r)
-        for (int c = 0; c < 3; ++c) {
-            R1[3 * r + c] = -u[1][r] * v[0][c] + u[0][r] * v[1][c] + u[2][r] * v[2][c];
-            R2[3 * r + c] = u[1][r] * v[0][c] - u[0][r] * v[1][c] + u[2][r] * v[2][c];
-        }
-    for (int r = 0; r < 3; ++r) t[r] = u[2][r];
-    return true;
-}
-
 int gms_recover_pose_device(gms_ctx* c, const double E[9], const double camera[4], const float* d_coords1, const float* d_coords2,
                             const int32_t* d_n_matches, int max_matches, const uint8_t* d_in_mask, gms_pose* d_pose, uint8_t* d_out_mask)
 {
@@ -1001,7 +936,7 @@ int gms_recover_pose_device(gms_ctx* c, const double E[9], const double camera[4
     if (max_matches > 0 && (!d_coords1 || !d_coords2)) return GMS_ERR_BAD_ARG;
     if (camera[0] == 0.0 || camera[1] == 0.0) return GMS_ERR_BAD_ARG;
     double R1[9], R2[9], t[3];
-    if (!decompose_essential(E, R1, R2, t)) return GMS_ERR_BAD_ARG;
+    if (!gms::tv::decompose_essential(E, R1, R2, t)) return GMS_ERR_BAD_ARG;  // cv::decomposeEssentialMat (twoview_core.h)
     double P[4][12];
     for (int h = 0; h < 4; ++h) {
         const double* R = (h & 1) ? R2 : R1;
@@ -1013,9 +948,112 @@ int gms_recover_pose_device(gms_ctx* c, const double E[9], const double camera[4
     }
     std::lock_guard<std::mutex> lock(c->mu);
     GMS_HIP(hipSetDevice(c->device));
-    GMS_HIP(c->pose_ws.reserve((size_t)max_matches + 48));
+    GMS_TRY(grow_pose_ws(c, (size_t)max_matches + 48, c->stream));
     GMS_HIP(gms::launch_recover_pose(camera, P, 50.0, d_coords1, d_coords2, d_n_matches, max_matches, d_in_mask, d_pose, d_out_mask,
                                      c->pose_ws.p, c->stream));
+    return GMS_OK;
+}
+
+// ---- the batched consumers (twoview_kernels.hip): nothing but launches on the context's stream --------------------------------
+static bool camera_ok(const gms_camera* cam) { return cam && cam->fx != 0.0 && cam->fy != 0.0; }
+
+int gms_gather_points_batch_device(gms_ctx* c, const gms_keypoint* d_kp, const int64_t* d_frame_off, int n_frames, const gms_pair* d_pairs,
+                                   int n_pairs, int max_m, const gms_dmatch* d_filtered, const gms_pair_result* d_results, float* d_coords1,
+                                   float* d_coords2, gms_two_view* d_tv)
+{
+    if (!c || n_frames < 0 || n_pairs < 0 || max_m < 0) return GMS_ERR_BAD_ARG;
+    if (n_pairs == 0) return GMS_OK;
+    if (!d_frame_off || !d_pairs || !d_results || !d_tv) return GMS_ERR_BAD_ARG;
+    if (max_m > 0 && (!d_kp || !d_filtered || !d_coords1 || !d_coords2)) return GMS_ERR_BAD_ARG;
+    std::lock_guard<std::mutex> lock(c->mu);
+    GMS_HIP(hipSetDevice(c->device));
+    GMS_HIP(gms::launch_gather_batch(d_kp, d_frame_off, n_frames, d_pairs, n_pairs, max_m, d_filtered, d_results, d_coords1, d_coords2, d_tv,
+                                     c->stream));
+    return GMS_OK;
+}
+
+int gms_find_essential_batch_device(gms_ctx* c, const gms_camera* camera, double prob, double threshold, int max_iters, const gms_pair* d_pairs,
+                                    int n_pairs, const float* d_coords1, const float* d_coords2, uint8_t* d_mask, gms_two_view* d_tv)
+{
+    if (!c || n_pairs < 0 || !camera_ok(camera)) return GMS_ERR_BAD_ARG;
+    if (!(prob > 0.0 && prob < 1.0) || !(threshold > 0.0) || max_iters < 1) return GMS_ERR_BAD_ARG;  // (CV_Assert(confidence > 0 && confidence < 1))
+    if (n_pairs == 0) return GMS_OK;
+    if (!d_pairs || !d_coords1 || !d_coords2 || !d_mask || !d_tv) return GMS_ERR_BAD_ARG;
+    std::lock_guard<std::mutex> lock(c->mu);
+    GMS_HIP(hipSetDevice(c->device));
+    GMS_HIP(gms::launch_find_essential_batch(*camera, prob, threshold, max_iters, d_pairs, n_pairs, d_coords1, d_coords2, d_mask, d_tv, c->stream));
+    return GMS_OK;
+}
+
+int gms_recover_pose_batch_device(gms_ctx* c, const gms_camera* camera, int use_in_mask, const gms_pair* d_pairs, int n_pairs,
+                                  const float* d_coords1, const float* d_coords2, uint8_t* d_mask, gms_two_view* d_tv)
+{
+    if (!c || n_pairs < 0 || !camera_ok(camera)) return GMS_ERR_BAD_ARG;
+    if (n_pairs == 0) return GMS_OK;
+    if (!d_pairs || !d_coords1 || !d_coords2 || !d_mask || !d_tv) return GMS_ERR_BAD_ARG;
+    std::lock_guard<std::mutex> lock(c->mu);
+    GMS_HIP(hipSetDevice(c->device));
+    GMS_HIP(gms::launch_recover_pose_batch(*camera, 50.0, use_in_mask ? 1 : 0, d_pairs, n_pairs, d_coords1, d_coords2, d_mask, d_tv, c->stream));
+    return GMS_OK;
+}
+
+int gms_triangulate_batch_device(gms_ctx* c, const gms_camera* camera, const gms_pair* d_pairs, int n_pairs, const float* d_coords1,
+                                 const float* d_coords2, const uint8_t* d_mask, double* d_points3d, gms_two_view* d_tv)
+{
+    if (!c || n_pairs < 0 || !camera_ok(camera)) return GMS_ERR_BAD_ARG;
+    if (n_pairs == 0) return GMS_OK;
+    if (!d_pairs || !d_coords1 || !d_coords2 || !d_points3d || !d_tv) return GMS_ERR_BAD_ARG;
+    std::lock_guard<std::mutex> lock(c->mu);
+    GMS_HIP(hipSetDevice(c->device));
+    GMS_HIP(gms::launch_triangulate_batch(*camera, d_pairs, n_pairs, d_coords1, d_coords2, d_mask, d_points3d, d_tv, c->stream));
+    return GMS_OK;
+}
+
+int gms_two_view_batch_device(gms_ctx* c, const gms_camera* camera, double prob, double threshold, int max_iters, const gms_keypoint* d_kp,
+                              const int64_t* d_frame_off, int n_frames, const gms_pair* d_pairs, int n_pairs, int max_m,
+                              const gms_dmatch* d_filtered, const gms_pair_result* d_results, float* d_coords1, float* d_coords2,
+                              uint8_t* d_mask, double* d_points3d, gms_two_view* d_tv)
+{
+    GMS_TRY(gms_gather_points_batch_device(c, d_kp, d_frame_off, n_frames, d_pairs, n_pairs, max_m, d_filtered, d_results, d_coords1, d_coords2, d_tv));
+    GMS_TRY(gms_find_essential_batch_device(c, camera, prob, threshold, max_iters, d_pairs, n_pairs, d_coords1, d_coords2, d_mask, d_tv));
+    GMS_TRY(gms_recover_pose_batch_device(c, camera, 1, d_pairs, n_pairs, d_coords1, d_coords2, d_mask, d_tv));
+    return gms_triangulate_batch_device(c, camera, d_pairs, n_pairs, d_coords1, d_coords2, d_mask, d_points3d, d_tv);
+}
+
+int gms_disparity_batch_device(gms_ctx* c, const gms_keypoint* d_kp, const int64_t* d_frame_off, const int32_t* d_wh, int n_frames,
+                               const gms_pair* d_pairs, int n_pairs, int max_m, const gms_dmatch* d_filtered, const gms_pair_result* d_results,
+                               const uint8_t* d_gt, int64_t gt_stride, int disp_ratio, uint8_t* d_disparity, int64_t map_stride, uint32_t* d_work,
+                               gms_disparity_stats* d_stats)
+{
+    if (!c || n_frames < 0 || n_pairs < 0 || max_m < 0 || map_stride <= 0 || gt_stride < 0) return GMS_ERR_BAD_ARG;
+    if (n_pairs == 0) return GMS_OK;
+    if (!d_frame_off || !d_wh || !d_pairs || !d_results || !d_disparity || !d_work || !d_stats || (d_gt && disp_ratio == 0)) return GMS_ERR_BAD_ARG;
+    if (max_m > 0 && (!d_kp || !d_filtered)) return GMS_ERR_BAD_ARG;
+    if (max_m >= (1 << 24)) return GMS_ERR_CAPACITY;  // the scatter key keeps the match index in 24 bits
+    std::lock_guard<std::mutex> lock(c->mu);
+    GMS_HIP(hipSetDevice(c->device));
+    GMS_HIP(gms::launch_disparity_batch(d_kp, d_frame_off, d_wh, n_frames, d_pairs, n_pairs, max_m, d_filtered, d_results, d_gt, gt_stride, disp_ratio,
+                                        d_disparity, map_stride, d_work, d_stats, c->stream));
+    return GMS_OK;
+}
+
+int gms_selftest_five_point(gms_ctx* c, const double* pts, int n_samples, double* models, int32_t* counts)
+{
+    if (!c || n_samples < 0 || (n_samples > 0 && (!pts || !models || !counts))) return GMS_ERR_BAD_ARG;
+    if (n_samples == 0) return GMS_OK;
+    std::lock_guard<std::mutex> lock(c->mu);
+    GMS_HIP(hipSetDevice(c->device));
+    const size_t b_pts = (size_t)n_samples * 20 * 8, b_models = (size_t)n_samples * 90 * 8, b_counts = (size_t)n_samples * 4;
+    GMS_HIP(hipStreamSynchronize(c->stream));
+    GMS_HIP(c->aux.reserve(b_pts + b_models + b_counts));
+    double* d_pts = (double*)c->aux.p;
+    double* d_models = d_pts + (size_t)n_samples * 20;
+    int* d_counts = (int*)(d_models + (size_t)n_samples * 90);
+    GMS_HIP(hipMemcpyAsync(d_pts, pts, b_pts, hipMemcpyHostToDevice, c->stream));
+    GMS_HIP(gms::launch_five_point_selftest(d_pts, n_samples, d_models, d_counts, c->stream));
+    GMS_HIP(hipMemcpyAsync(models, d_models, b_models, hipMemcpyDeviceToHost, c->stream));
+    GMS_HIP(hipMemcpyAsync(counts, d_counts, b_counts, hipMemcpyDeviceToHost, c->stream));
+    GMS_HIP(hipStreamSynchronize(c->stream));
     return GMS_OK;
 }
 

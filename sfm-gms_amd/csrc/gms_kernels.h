@@ -99,6 +99,21 @@ hipError_t launch_triangulate(const double* camera, const double* dist, const do
 hipError_t launch_recover_pose(const double* camera, const double P[4][12], double dist_thresh, const float* d_coords1, const float* d_coords2,
                                const int32_t* d_n_matches, int max_matches, const uint8_t* d_in_mask, gms_pose* d_pose, uint8_t* d_out_mask,
                                void* d_work, hipStream_t stream);
+// batched consumers (twoview_kernels.hip)
+hipError_t launch_gather_batch(const gms_keypoint* d_kp, const int64_t* d_frame_off, int n_frames, const gms_pair* d_pairs, int n_pairs, int max_m,
+                               const gms_dmatch* d_filtered, const gms_pair_result* d_results, float* d_coords1, float* d_coords2,
+                               gms_two_view* d_tv, hipStream_t stream);
+hipError_t launch_find_essential_batch(const gms_camera& cam, double prob, double threshold, int max_iters, const gms_pair* d_pairs, int n_pairs,
+                                       const float* d_coords1, const float* d_coords2, uint8_t* d_mask, gms_two_view* d_tv, hipStream_t stream);
+hipError_t launch_five_point_selftest(const double* d_pts, int n_samples, double* d_models, int* d_counts, hipStream_t stream);
+hipError_t launch_recover_pose_batch(const gms_camera& cam, double dist_thresh, int use_in_mask, const gms_pair* d_pairs, int n_pairs,
+                                     const float* d_coords1, const float* d_coords2, uint8_t* d_mask, gms_two_view* d_tv, hipStream_t stream);
+hipError_t launch_triangulate_batch(const gms_camera& cam, const gms_pair* d_pairs, int n_pairs, const float* d_coords1, const float* d_coords2,
+                                    const uint8_t* d_mask, double* d_points3d, gms_two_view* d_tv, hipStream_t stream);
+hipError_t launch_disparity_batch(const gms_keypoint* d_kp, const int64_t* d_frame_off, const int32_t* d_wh, int n_frames, const gms_pair* d_pairs,
+                                  int n_pairs, int max_m, const gms_dmatch* d_filtered, const gms_pair_result* d_results, const uint8_t* d_gt,
+                                  int64_t gt_stride, int disp_ratio, uint8_t* d_disparity, int64_t map_stride, uint32_t* d_work,
+                                  gms_disparity_stats* d_stats, hipStream_t stream);
 hipError_t launch_threshold(const int32_t* d_T, const int32_t* d_n, const int32_t* d_score, double factor,
                             int count, uint8_t* d_out, hipStream_t stream);
 

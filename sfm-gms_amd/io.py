@@ -80,3 +80,54 @@ class _CDataset(C.Structure):
     _fields_ = [("n_frames", C.c_int32), ("desc_kind", C.c_int32), ("n_pairs", C.c_int64), ("total_matches", C.c_int64),
                 ("wh", C.c_void_p), ("frame_off", C.c_void_p), ("keypoints", C.c_void_p), ("descriptors", C.c_void_p),
                 ("pairs", C.c_void_p), ("matches", C.c_void_p), ("owner", C.c_void_p)]
+
+
+def load_c(path):
+    """The same file through the C reader of the library (gms_dataset_read, csrc/gms_io.cpp): what a C / C++ caller gets. Returns a
+    Dataset whose arrays are copies (the C block is released before returning). Raises OSError on GMS_ERR_IO."""
+    from .capi import load_library
+    lib = load_library()
+    cd = _CDataset()
+    rc = lib.gms_dataset_read(str(path).encode(), C.byref(cd))
+    if rc != 0:
+        raise OSError(f"gms_dataset_read({path}): {lib.gms_error_string(rc).decode()}")
+    try:
+        n, kind = int(cd.n_frames), int(cd.desc_kind)
+
+        def arr(ptr, dtype, count):
+            if not ptr or count == 0:
+                return np.zeros(0, dtype=dtype)
+            buf = (C.c_char * (np.dtype(dtype).itemsize * count)).from_address(ptr)
+            return np.frombuffer(buf, dtype=dtype, count=count).copy()
+        wh = arr(cd.wh, "<i4", 2 * n).reshape(-1, 2)
+        off = arr(cd.frame_off, "<i8", n + 1) if n else np.zeros(1, dtype=np.int64)
+        total = int(off[-1])
+        kp = arr(cd.keypoints, KEYPOINT_DTYPE, total)
+        dt, width = _ROW[kind]
+        desc = arr(cd.descriptors, dt, total * width).reshape(-1, width) if dt is not None else None
+        pairs = arr(cd.pairs, PAIR_DTYPE, int(cd.n_pairs))
+        matches = arr(cd.matches, DMATCH_DTYPE, int(cd.total_matches))
+    finally:
+        lib.gms_dataset_free(C.byref(cd))
+    frames = [kp[off[i]:off[i + 1]] for i in range(n)]
+    descs = [desc[off[i]:off[i + 1]] for i in range(n)] if desc is not None else None
+    return Dataset(frames, [tuple(x) for x in wh.tolist()], descs, kind, pairs, matches)
+
+
+def save_c(path, ds):
+    """Dataset -> file through the C writer (gms_dataset_write)."""
+    from .capi import load_library
+    lib = load_library()
+    counts = np.array([len(f) for f in ds.frames], dtype=np.int64)
+    off = np.concatenate([[0], np.cumsum(counts)]).astype("<i8")
+    wh = np.ascontiguousarray(np.asarray(ds.sizes, dtype="<i4").reshape(-1))
+    kp = np.concatenate([np.ascontiguousarray(f, dtype=KEYPOINT_DTYPE) for f in ds.frames]) if len(ds.frames) else np.zeros(0, dtype=KEYPOINT_DTYPE)
+    dt, width = _ROW[ds.desc_kind]
+    desc = np.concatenate([np.ascontiguousarray(d, dtype=dt).reshape(-1, width) for d in ds.descriptors]) if dt is not None else None
+    pairs, matches = np.ascontiguousarray(ds.pairs, dtype=PAIR_DTYPE), np.ascontiguousarray(ds.matches, dtype=DMATCH_DTYPE)
+    cd = _CDataset(len(ds.frames), ds.desc_kind, len(pairs), len(matches), wh.ctypes.data, off.ctypes.data, kp.ctypes.data if len(kp) else None,
+                   desc.ctypes.data if desc is not None and len(desc) else None, pairs.ctypes.data if len(pairs) else None,
+                   matches.ctypes.data if len(matches) else None, None)
+    rc = lib.gms_dataset_write(str(path).encode(), C.byref(cd))
+    if rc != 0:
+        raise OSError(f"gms_dataset_write({path}): {lib.gms_error_string(rc).decode()}")

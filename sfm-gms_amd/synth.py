@@ -132,3 +132,79 @@ def sequence_descriptors(case_id, n_frames, n_kp, kind="orb", flip_bits=20, nois
             d[other] = np.clip(np.rint(rng.gamma(1.2, 22.0, (int(other.sum()), 128))), 0, 255)
             out.append(d.astype(np.float32))
     return out
+
+
+def make_two_view_scene(case_id, size=(2016, 1512), n_points=8000, camera=(1700.0, 1690.0, 1008.0, 756.0),
+                        dist=(-0.12, 0.05, 0.001, -0.0007, 0.01), yaw_deg=6.0, t=(-0.6, 0.02, 0.05), depth=(4.0, 9.0),
+                        noise_px=0.3, kind="orb", descriptor_outliers=0.3):
+    """Two calibrated views of one rigid scene, as structureFromMotion meets them (SfMUtil.cpp:4: two images, cameraMatrix,
+    distCoeffs): 3-D points in front of camera 1 = [I|0], camera 2 = [R|t], projected through the forward distortion model
+    (k1, k2, p1, p2, k3) and the camera matrix; points that leave either image are dropped. Keypoint i of frame 0 and keypoint i of
+    frame 1 show the same scene point; the descriptors say so for a share 1 - descriptor_outliers of the keypoints.
+    Returns dict(frames=[kp1, kp2], descriptors=[d1, d2], desc_kind, sizes, camera, dist, R, t, X)."""
+    rng = rng_for(case_id ^ 0x2F1E)
+    w, h = size
+    fx, fy, cx, cy = camera
+    half_w, half_h = 0.5 * w / fx * depth[1] * 0.55, 0.5 * h / fy * depth[1] * 0.55
+    X = np.stack([rng.uniform(-half_w, half_w, n_points), rng.uniform(-half_h, half_h, n_points), rng.uniform(depth[0], depth[1], n_points)], axis=1)
+    a = np.deg2rad(yaw_deg)
+    R = np.array([[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]]) @ \
+        np.array([[1, 0, 0], [0, np.cos(0.02), -np.sin(0.02)], [0, np.sin(0.02), np.cos(0.02)]])
+    tv = np.asarray(t, dtype=np.float64)
+
+    def project(Xc):
+        x, y = Xc[:, 0] / Xc[:, 2], Xc[:, 1] / Xc[:, 2]
+        k1, k2, p1, p2, k3 = dist if dist is not None else (0, 0, 0, 0, 0)
+        r2 = x * x + y * y
+        rad = 1 + ((k3 * r2 + k2) * r2 + k1) * r2
+        xd = x * rad + 2 * p1 * x * y + p2 * (r2 + 2 * x * x)
+        yd = y * rad + p1 * (r2 + 2 * y * y) + 2 * p2 * x * y
+        return np.stack([xd * fx + cx, yd * fy + cy], axis=1)
+
+    uv1, uv2 = project(X), project(X @ R.T + tv)
+    uv1 += rng.normal(0, noise_px, uv1.shape)
+    uv2 += rng.normal(0, noise_px, uv2.shape)
+    ok = (uv1[:, 0] > 1) & (uv1[:, 0] < w - 2) & (uv1[:, 1] > 1) & (uv1[:, 1] < h - 2) & \
+         (uv2[:, 0] > 1) & (uv2[:, 0] < w - 2) & (uv2[:, 1] > 1) & (uv2[:, 1] < h - 2)
+    uv1, uv2, X = uv1[ok].astype(np.float32), uv2[ok].astype(np.float32), X[ok]
+    n = len(uv1)
+    descs = sequence_descriptors(case_id, 2, n, kind, outlier_frac=descriptor_outliers)
+    return dict(frames=[make_keypoints(uv1), make_keypoints(uv2)], descriptors=descs, desc_kind=0 if kind == "orb" else 1,
+                sizes=[size, size], camera=camera, dist=dist, R=R, t=tv, X=X)
+
+
+def make_multi_view_scene(case_id, n_frames, size=(1920, 1080), n_kp=10000, camera=(1400.0, 1380.0, 960.0, 540.0), dist=None,
+                          yaw_span_deg=8.0, x_span=1.0, depth=(4.0, 9.0), noise_px=0.3):
+    """n_frames calibrated views of one rigid scene from cameras strung along a short arc (yaw and sideways translation growing with the
+    frame index): exactly n_kp scene points that stay inside every image, keypoint i of every frame showing scene point i -- the input of
+    structureFromMotion (SfMUtil.cpp:4) for every pair of a sequence. Returns dict(frames, sizes, camera, dist, R [n, 3, 3], t [n, 3], X)."""
+    rng = rng_for(case_id ^ 0x3A7C)
+    w, h = size
+    fx, fy, cx, cy = camera
+    Rs, ts = [], []
+    for f in range(n_frames):
+        s = (f / max(1, n_frames - 1)) - 0.5
+        a = np.deg2rad(yaw_span_deg) * s
+        Rs.append(np.array([[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]]))
+        ts.append(np.array([-x_span * s, 0.03 * s, 0.05 * s]))
+    half_w, half_h = 0.5 * w / fx * depth[0] * 0.8, 0.5 * h / fy * depth[0] * 0.8
+    k1, k2, p1, p2, k3 = dist if dist is not None else (0, 0, 0, 0, 0)
+
+    def project(Xc):
+        x, y = Xc[:, 0] / Xc[:, 2], Xc[:, 1] / Xc[:, 2]
+        r2 = x * x + y * y
+        rad = 1 + ((k3 * r2 + k2) * r2 + k1) * r2
+        return np.stack([(x * rad + 2 * p1 * x * y + p2 * (r2 + 2 * x * x)) * fx + cx, (y * rad + p1 * (r2 + 2 * y * y) + 2 * p2 * x * y) * fy + cy], axis=1)
+
+    X = np.zeros((0, 3))
+    while len(X) < n_kp:
+        cand = np.stack([rng.uniform(-half_w * 1.6, half_w * 1.6, 2 * n_kp), rng.uniform(-half_h * 1.4, half_h * 1.4, 2 * n_kp),
+                         rng.uniform(depth[0], depth[1], 2 * n_kp)], axis=1)
+        ok = np.ones(len(cand), dtype=bool)
+        for R, t in zip(Rs, ts):
+            uv = project(cand @ R.T + t)
+            ok &= (uv[:, 0] > 2) & (uv[:, 0] < w - 3) & (uv[:, 1] > 2) & (uv[:, 1] < h - 3)
+        X = np.concatenate([X, cand[ok]])
+    X = X[:n_kp]
+    frames = [make_keypoints((project(X @ R.T + t) + rng.normal(0, noise_px, (n_kp, 2))).astype(np.float32)) for R, t in zip(Rs, ts)]
+    return dict(frames=frames, sizes=[size] * n_frames, camera=camera, dist=dist, R=np.array(Rs), t=np.array(ts), X=X)

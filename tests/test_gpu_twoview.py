@@ -1,0 +1,318 @@
+"""-m gpu: the two-view stage for a batch of pairs (gms_gather_points_batch_device, gms_find_essential_batch_device,
+gms_recover_pose_batch_device, gms_triangulate_batch_device, gms_two_view_batch_device, gms_disparity_batch_device) -- against the numpy
+restatements (oracle/sfm_ref.py; OpenCV's calib3d is an import library in the reference: parity unpinned, tolerances stated per
+assertion), against the single-pair entry points, and BASELINE config 5 end to end from a dataset file read in a fresh process."""
+import importlib
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import sfm_ref
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _scene(seed, n, outliers, noise=0.3, camera=(1400.0, 1380.0, 960.0, 540.0)):
+    rng = np.random.default_rng(seed)
+    ang = np.deg2rad(6.0)
+    R = np.array([[np.cos(ang), 0, np.sin(ang)], [0, 1, 0], [-np.sin(ang), 0, np.cos(ang)]]) @ \
+        np.array([[1, 0, 0], [0, np.cos(0.03), -np.sin(0.03)], [0, np.sin(0.03), np.cos(0.03)]])
+    t = np.array([-0.6, 0.02, 0.05])
+    X = np.stack([rng.uniform(-2.2, 2.2, n), rng.uniform(-1.2, 1.2, n), rng.uniform(4, 9, n)], axis=1)
+    K = np.array([[camera[0], 0, camera[2]], [0, camera[1], camera[3]], [0, 0, 1.0]])
+    p1, p2 = X @ K.T, (X @ R.T + t) @ K.T
+    uv1 = (p1[:, :2] / p1[:, 2:3] + rng.normal(0, noise, (n, 2))).astype(np.float32)
+    uv2 = (p2[:, :2] / p2[:, 2:3] + rng.normal(0, noise, (n, 2))).astype(np.float32)
+    wrong = rng.uniform(size=n) < outliers
+    uv2[wrong] = np.stack([rng.uniform(0, 1920, int(wrong.sum())), rng.uniform(0, 1080, int(wrong.sum()))], axis=1).astype(np.float32)
+    return uv1, uv2, wrong, R, t
+
+
+def _coords_batch(pkg, scenes):
+    """scenes: list of (uv1, uv2): a pair table whose pair i owns [match_off, match_off + n_i + slack) and TWO_VIEW records with
+    n_points = n_i (what gms_gather_points_batch_device would have left)."""
+    types = importlib.import_module("sfm-gms_amd.types")
+    pairs = np.zeros(len(scenes), dtype=pkg.PAIR_DTYPE)
+    tv = np.zeros(len(scenes), dtype=types.TWO_VIEW_DTYPE)
+    off, c1, c2 = 0, [], []
+    for i, (u1, u2) in enumerate(scenes):
+        n, slack = len(u1), 3 + (i % 4)
+        pairs[i] = (0, 1, n + slack, 0, off)
+        tv["n_points"][i] = n
+        pad = np.full((slack, 2), 12345.0, dtype=np.float32)          # beyond n_points: never read
+        c1 += [u1, pad]
+        c2 += [u2, pad]
+        off += n + slack
+    return pairs, tv, np.concatenate(c1), np.concatenate(c2)
+
+
+def test_find_essential_batch_against_the_restatement(ctx, pkg):
+    """cv::findEssentialMat(coords1, coords2, K, RANSAC, prob, 1.0, mask) per pair of a ragged batch -- SfMUtil.cpp:39's confidence 0.7
+    and a stricter one; from 3 correspondences (no model) over exactly 5 and 6 to 3000 with a tenth to four fifths of them wrong. The
+    workgroup's RANSAC and the sequential numpy loop must make the same decisions: same iteration count, same inlier mask; E to 1e-9."""
+    import torch
+    types = importlib.import_module("sfm-gms_amd.types")
+    camera = (1400.0, 1380.0, 960.0, 540.0)
+    cases = [(1, 800, 0.3), (2, 3, 0.0), (3, 3000, 0.1), (4, 60, 0.5), (5, 6, 0.0), (6, 5, 0.0), (7, 400, 0.8), (8, 0, 0.0), (9, 1500, 0.45)]
+    scenes = [_scene(s, n, o)[:2] for s, n, o in cases]
+    pairs, tv, c1, c2 = _coords_batch(pkg, scenes)
+    dev = torch.device("cuda", 0)
+    d_pairs = torch.from_numpy(pairs.view(np.uint8).reshape(-1)).to(dev)
+    d_c1, d_c2 = torch.from_numpy(c1.reshape(-1).copy()).to(dev), torch.from_numpy(c2.reshape(-1).copy()).to(dev)
+    cam = types.make_camera(camera)
+    for prob in (0.7, 0.999):
+        d_tv = torch.from_numpy(tv.view(np.uint8).reshape(-1).copy()).to(dev)
+        d_mask = torch.full((len(c1),), 77, dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize()
+        ctx.find_essential_batch_device(cam, d_pairs.data_ptr(), len(pairs), d_c1.data_ptr(), d_c2.data_ptr(), d_mask.data_ptr(),
+                                        d_tv.data_ptr(), prob, 1.0, 1000)
+        ctx.synchronize()
+        got, mask = d_tv.cpu().numpy().view(types.TWO_VIEW_DTYPE), d_mask.cpu().numpy()
+        for i, (u1, u2) in enumerate(scenes):
+            E, want_mask, iters = sfm_ref.find_essential_mat(u1, u2, camera, prob, 1.0)
+            o, n = int(pairs["match_off"][i]), len(u1)
+            assert np.array_equal(mask[o:o + n], want_mask) and (mask[o + n:o + int(pairs["m"][i])] == 77).all(), (i, prob)
+            assert int(got["n_ransac"][i]) == int(want_mask.sum()) and int(got["ransac_iters"][i]) == iters, (i, prob)
+            if E is None:
+                assert int(got["status"][i]) == -8 and not got["E"][i].any()
+            else:
+                assert int(got["status"][i]) == 0 and np.abs(got["E"][i] - E).max() < 1e-9, (i, prob, np.abs(got["E"][i] - E).max())
+        assert int(got["n_ransac"][0]) > 400 and int(got["n_ransac"][2]) > 2300
+
+
+def _two_view_batch(pkg, synth, seeds, n_points=2500, size=(1920, 1080)):
+    """A sequence of independent two-view scenes: frames 2 k, 2 k + 1 are the two views of scene k; pair k = (2 k, 2 k + 1) with half
+    of its putative matches wrong."""
+    frames, pairs, matches, scenes, off = [], [], [], [], 0
+    for k, seed in enumerate(seeds):
+        sc = synth.make_two_view_scene(seed, size=size, n_points=n_points + 300 * k, camera=(1400.0, 1380.0, size[0] / 2.0, size[1] / 2.0))
+        n = len(sc["frames"][0])
+        rng = np.random.default_rng(seed)
+        train = np.arange(n)
+        wrong = rng.uniform(size=n) < 0.5
+        train[wrong] = rng.integers(0, n, int(wrong.sum()))
+        mt = synth.make_matches(np.arange(n), train, rng)
+        frames += sc["frames"]
+        pairs.append((2 * k, 2 * k + 1, n, 0, off))
+        matches.append(mt)
+        scenes.append(sc)
+        off += n
+    return frames, np.array(pairs, dtype=pkg.PAIR_DTYPE), np.concatenate(matches), scenes
+
+
+def test_two_view_batch_after_the_filter(ctx, pkg, oracle, synth):
+    """BASELINE config 5's chain for a batch: GMS with the FeatureMatchUtil.cpp:69 flags -> gms_two_view_batch_device (gather ->
+    findEssentialMat(0.7, 1.0) -> recoverPose -> inliers compacted -> undistort -> triangulate), against oracle filter + numpy chain.
+    Integer / verbatim parts exact (survivors, coordinates, RANSAC decisions, masks, counts); E, R, t to 1e-9; 3-D points of well
+    conditioned (true) correspondences to 1e-6 relative; error sums to 1e-8 relative."""
+    import torch
+    batch = importlib.import_module("sfm-gms_amd.batch")
+    types = importlib.import_module("sfm-gms_amd.types")
+    size = (1920, 1080)
+    frames, pairs, matches, scenes = _two_view_batch(pkg, synth, [31, 32, 33, 34])
+    pairs["m"][3] = 4                                              # a pair with too few matches for a model (and for GMS to keep any)
+    table = batch.FrameTable(ctx, frames, [size] * len(frames))
+    dev = table.device
+    total, n_pairs, max_m = len(matches), len(pairs), int(pairs["m"].max())
+    d_pairs, d_matches = batch._to_dev(pairs, dev), batch._to_dev(matches, dev)
+    d_out = torch.zeros(total * 16, dtype=torch.uint8, device=dev)
+    d_res = torch.zeros(n_pairs * 16, dtype=torch.uint8, device=dev)
+    d_c1, d_c2 = torch.zeros(2 * total, dtype=torch.float32, device=dev), torch.zeros(2 * total, dtype=torch.float32, device=dev)
+    d_mask = torch.zeros(total, dtype=torch.uint8, device=dev)
+    d_p3 = torch.zeros(3 * total, dtype=torch.float64, device=dev)
+    d_tv = torch.zeros(n_pairs * types.TWO_VIEW_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+    sc0 = scenes[0]
+    cam = types.make_camera(sc0["camera"], sc0["dist"])
+    torch.cuda.synchronize()
+    ctx.filter_device(table.d_pts.data_ptr(), table.d_frame_off.data_ptr(), table.n_frames, d_pairs.data_ptr(), n_pairs, max_m,
+                      d_matches.data_ptr(), d_out.data_ptr(), d_res.data_ptr(), None, True, True, 6.0)
+    ctx.two_view_batch_device(cam, table.d_kp.data_ptr(), table.d_frame_off.data_ptr(), table.n_frames, d_pairs.data_ptr(), n_pairs, max_m,
+                              d_out.data_ptr(), d_res.data_ptr(), d_c1.data_ptr(), d_c2.data_ptr(), d_mask.data_ptr(), d_p3.data_ptr(),
+                              d_tv.data_ptr(), 0.7, 1.0, 1000)
+    ctx.synchronize()
+    out, res = d_out.cpu().numpy().view(pkg.DMATCH_DTYPE), d_res.cpu().numpy().view(pkg.RESULT_DTYPE)
+    tv = d_tv.cpu().numpy().view(types.TWO_VIEW_DTYPE)
+    c1, c2 = d_c1.cpu().numpy().reshape(-1, 2), d_c2.cpu().numpy().reshape(-1, 2)
+    mask, p3 = d_mask.cpu().numpy(), d_p3.cpu().numpy().reshape(-1, 3)
+    for i in range(n_pairs):
+        a, b, m, o = int(pairs["frame_a"][i]), int(pairs["frame_b"][i]), int(pairs["m"][i]), int(pairs["match_off"][i])
+        rc, want, _, wres = oracle.match(size, size, frames[a], frames[b], matches[o:o + m], True, True, 6.0)
+        k = len(want)
+        assert rc == 0 and res[i].tobytes() == wres.tobytes() and out[o:o + k].tobytes() == want.tobytes()
+        _, w1, w2 = oracle.gather(frames[a], frames[b], want)
+        assert int(tv["n_points"][i]) == k and c1[o:o + k].tobytes() == w1.tobytes() and c2[o:o + k].tobytes() == w2.tobytes()
+        ref = sfm_ref.two_view(w1, w2, sc0["camera"], sc0["dist"], 0.7, 1.0)
+        if ref["E"] is None:
+            assert i == 3 and int(tv["status"][i]) == -8 and int(tv["n_triangulated"][i]) == 0
+            continue
+        t = tv[i]
+        assert int(t["status"]) == 0 and int(t["n_ransac"]) == ref["n_ransac"] and int(t["ransac_iters"]) == ref["iters"]
+        assert np.abs(t["E"] - ref["E"]).max() < 1e-9 and np.abs(t["R"] - ref["R"]).max() < 1e-9 and np.abs(t["t"] - ref["t"]).max() < 1e-9
+        assert int(t["n_pose"]) == ref["n_pose"] and np.array_equal(mask[o:o + k], ref["mask"])
+        kept = int((ref["mask"] != 0).sum())
+        assert int(t["n_triangulated"]) == kept and int(t["n_finite"]) == kept and int(t["n_behind"]) == ref["behind"]
+        got_pts = p3[o:o + kept]
+        true = (want["queryIdx"] == want["trainIdx"])[ref["mask"] != 0]
+        assert true.mean() > 0.95 and np.allclose(got_pts[true], ref["points"][true], rtol=1e-6, atol=1e-9)
+        assert abs(t["sum_sq_err1"] - ref["sum_sq_err1"]) <= 1e-8 * ref["sum_sq_err1"] + 1e-14
+        assert abs(t["sum_sq_err2"] - ref["sum_sq_err2"]) <= 1e-8 * ref["sum_sq_err2"] + 1e-14
+        # and the estimate is the scene: rotation within 0.3 degrees, translation direction within 3 degrees, points at scale |t|
+        sc = scenes[i]
+        cosang = (np.trace(t["R"] @ sc["R"].T) - 1) / 2
+        assert np.degrees(np.arccos(min(1.0, cosang))) < 0.3
+        tdir = sc["t"] / np.linalg.norm(sc["t"])
+        assert np.degrees(np.arccos(min(1.0, abs(float(t["t"] @ tdir))))) < 3.0
+        Xk = sc["X"][want["queryIdx"]][ref["mask"] != 0][true] / np.linalg.norm(sc["t"])
+        assert np.median(np.linalg.norm(got_pts[true] - Xk, axis=1) / np.linalg.norm(Xk, axis=1)) < 0.05
+
+
+def test_batched_stages_equal_the_single_pair_entry_points(ctx, pkg, oracle, synth):
+    """Every batched consumer on a ragged batch against the per-pair entry point fed the same survivors: gather (bytes), recoverPose given
+    the batch's own E (R, t, count, mask), triangulate with the batch's pose over the batch's mask (points, sums), disparity (map, stats)."""
+    import torch
+    batch = importlib.import_module("sfm-gms_amd.batch")
+    types = importlib.import_module("sfm-gms_amd.types")
+    size = (1920, 1080)
+    frames, pairs, matches, scenes = _two_view_batch(pkg, synth, [41, 42, 43], n_points=1800)
+    pairs["m"][1] = 900                                            # ragged: pair 1 uses the head of its range only
+    table = batch.FrameTable(ctx, frames, [size] * len(frames))
+    dev = table.device
+    total, n_pairs, max_m = len(matches), len(pairs), int(pairs["m"].max())
+    d_pairs, d_matches = batch._to_dev(pairs, dev), batch._to_dev(matches, dev)
+    z8 = lambda n: torch.zeros(n, dtype=torch.uint8, device=dev)
+    d_out, d_res = z8(total * 16), z8(n_pairs * 16)
+    d_c1, d_c2 = torch.zeros(2 * total, dtype=torch.float32, device=dev), torch.zeros(2 * total, dtype=torch.float32, device=dev)
+    d_mask, d_p3 = z8(total), torch.zeros(3 * total, dtype=torch.float64, device=dev)
+    d_tv = z8(n_pairs * types.TWO_VIEW_DTYPE.itemsize)
+    sc0 = scenes[0]
+    camera, dist = sc0["camera"], sc0["dist"]
+    cam = types.make_camera(camera, dist)
+    w, h = size
+    d_wh = table.d_wh
+    d_disp, d_work = z8(n_pairs * w * h), torch.zeros(n_pairs * w * h, dtype=torch.int32, device=dev)
+    d_dstats = z8(n_pairs * 24)
+    gt = np.random.default_rng(4).integers(0, 256, (h, w)).astype(np.uint8)
+    d_gt = torch.from_numpy(gt).to(dev)
+    torch.cuda.synchronize()
+    ctx.filter_device(table.d_pts.data_ptr(), table.d_frame_off.data_ptr(), table.n_frames, d_pairs.data_ptr(), n_pairs, max_m,
+                      d_matches.data_ptr(), d_out.data_ptr(), d_res.data_ptr(), None, False, False, 6.0)
+    ctx.two_view_batch_device(cam, table.d_kp.data_ptr(), table.d_frame_off.data_ptr(), table.n_frames, d_pairs.data_ptr(), n_pairs, max_m,
+                              d_out.data_ptr(), d_res.data_ptr(), d_c1.data_ptr(), d_c2.data_ptr(), d_mask.data_ptr(), d_p3.data_ptr(),
+                              d_tv.data_ptr(), 0.7, 1.0, 1000)
+    ctx.disparity_batch_device(table.d_kp.data_ptr(), table.d_frame_off.data_ptr(), d_wh.data_ptr(), table.n_frames, d_pairs.data_ptr(), n_pairs,
+                               max_m, d_out.data_ptr(), d_res.data_ptr(), d_gt.data_ptr(), 0, 4, d_disp.data_ptr(), w * h, d_work.data_ptr(),
+                               d_dstats.data_ptr())
+    ctx.synchronize()
+    tv = d_tv.cpu().numpy().view(types.TWO_VIEW_DTYPE)
+    res = d_res.cpu().numpy().view(pkg.RESULT_DTYPE)
+    mask_b, p3_b = d_mask.cpu().numpy(), d_p3.cpu().numpy().reshape(-1, 3)
+    c1_b, c2_b = d_c1.cpu().numpy().reshape(-1, 2), d_c2.cpu().numpy().reshape(-1, 2)
+    disp_b = d_disp.cpu().numpy().reshape(n_pairs, h, w)
+    dstats_b = d_dstats.cpu().numpy().view(types.DISPARITY_STATS_DTYPE)
+    kpb = types.KEYPOINT_DTYPE.itemsize
+    foff = table.frame_off_host
+    for i in range(n_pairs):
+        a, b, m, o = int(pairs["frame_a"][i]), int(pairs["frame_b"][i]), int(pairs["m"][i]), int(pairs["match_off"][i])
+        k = int(res["n_inliers"][i])
+        assert k > 200 and int(tv["status"][i]) == 0
+        d_kp1, d_kp2 = table.d_kp.data_ptr() + int(foff[a]) * kpb, table.d_kp.data_ptr() + int(foff[b]) * kpb
+        n1, n2 = int(foff[a + 1] - foff[a]), int(foff[b + 1] - foff[b])
+        src = d_out.data_ptr() + o * 16
+        d_n = d_res[16 * i:16 * i + 4].clone()
+        s_c1, s_c2 = torch.zeros(2 * m, dtype=torch.float32, device=dev), torch.zeros(2 * m, dtype=torch.float32, device=dev)
+        s_st = torch.zeros(1, dtype=torch.int32, device=dev)
+        s_pose, s_mask = z8(types.POSE_DTYPE.itemsize), z8(m)
+        s_pts, s_tstats = torch.zeros(3 * m, dtype=torch.float64, device=dev), z8(32)
+        s_disp, s_work, s_dstats = z8(w * h), torch.zeros(w * h, dtype=torch.int32, device=dev), z8(24)
+        # findEssentialMat's mask of the pair, recomputed from the batch's E (the batched mask array now holds recoverPose's output)
+        _, w1, w2 = oracle.gather(frames[a], frames[b], d_out.cpu().numpy().view(pkg.DMATCH_DTYPE)[o:o + k])
+        x1 = np.stack([(w1[:, 0].astype(np.float64) - camera[2]) / camera[0], (w1[:, 1].astype(np.float64) - camera[3]) / camera[1]], axis=1)
+        x2 = np.stack([(w2[:, 0].astype(np.float64) - camera[2]) / camera[0], (w2[:, 1].astype(np.float64) - camera[3]) / camera[1]], axis=1)
+        thr = 1.0 / ((camera[0] + camera[1]) / 2)
+        in_mask = (sfm_ref.sampson_errors(tv["E"][i], x1, x2) <= np.float32(thr * thr)).astype(np.uint8)
+        assert int(in_mask.sum()) == int(tv["n_ransac"][i])
+        s_in = torch.from_numpy(np.concatenate([in_mask, np.zeros(m - k, dtype=np.uint8)])).to(dev)
+        torch.cuda.synchronize()
+        ctx.gather_points_device(d_kp1, n1, d_kp2, n2, src, d_n.data_ptr(), m, s_c1.data_ptr(), s_c2.data_ptr(), s_st.data_ptr())
+        ctx.recover_pose_device(tv["E"][i], camera, s_c1.data_ptr(), s_c2.data_ptr(), d_n.data_ptr(), m, s_in.data_ptr(), s_pose.data_ptr(),
+                                s_mask.data_ptr())
+        ctx.disparity_device(d_kp1, n1, d_kp2, n2, src, d_n.data_ptr(), m, w, h, d_gt.data_ptr(), 4, s_disp.data_ptr(), s_work.data_ptr(),
+                             s_dstats.data_ptr())
+        ctx.synchronize()
+        assert int(s_st.item()) == 0
+        assert s_c1.cpu().numpy()[:2 * k].tobytes() == c1_b[o:o + k].tobytes() and s_c2.cpu().numpy()[:2 * k].tobytes() == c2_b[o:o + k].tobytes()
+        pose = s_pose.cpu().numpy().view(types.POSE_DTYPE)[0]
+        assert np.array_equal(pose["R"], tv["R"][i]) and np.array_equal(pose["t"], tv["t"][i]) and int(pose["n_good"]) == int(tv["n_pose"][i])
+        assert np.array_equal(s_mask.cpu().numpy()[:k], mask_b[o:o + k])
+        assert np.array_equal(s_disp.cpu().numpy().reshape(h, w), disp_b[i])
+        assert s_dstats.cpu().numpy().tobytes() == dstats_b[i].tobytes() and int(dstats_b[i]["count"]) > 100
+        # triangulation of the masked correspondences: the single-pair entry takes compacted coordinates
+        keep = mask_b[o:o + k] != 0
+        kk = int(keep.sum())
+        assert kk == int(tv["n_triangulated"][i]) and kk > 100
+        t_c1 = torch.from_numpy(c1_b[o:o + k][keep].reshape(-1).copy()).to(dev)
+        t_c2 = torch.from_numpy(c2_b[o:o + k][keep].reshape(-1).copy()).to(dev)
+        t_n = torch.tensor([kk], dtype=torch.int32, device=dev)
+        P1 = np.hstack([np.eye(3), np.zeros((3, 1))])
+        P2 = np.hstack([tv["R"][i], tv["t"][i].reshape(3, 1)])
+        torch.cuda.synchronize()
+        ctx.triangulate_device(camera, dist, P1, P2, t_c1.data_ptr(), t_c2.data_ptr(), t_n.data_ptr(), kk, s_pts.data_ptr(), s_tstats.data_ptr())
+        ctx.synchronize()
+        assert np.array_equal(s_pts.cpu().numpy().reshape(-1, 3)[:kk], p3_b[o:o + kk])
+        ts = s_tstats.cpu().numpy().view(types.TRIANGULATION_STATS_DTYPE)[0]
+        assert int(ts["count"]) == int(tv["n_finite"][i]) and int(ts["behind"]) == int(tv["n_behind"][i])
+        assert abs(ts["sum_sq_err1"] - tv["sum_sq_err1"][i]) <= 1e-12 * ts["sum_sq_err1"]   # (same terms, summed in another order)
+        assert abs(ts["sum_sq_err2"] - tv["sum_sq_err2"][i]) <= 1e-12 * ts["sum_sq_err2"]
+
+
+def test_config5_full_loop_from_a_dataset_file(pkg, oracle, synth, tmp_path):
+    """BASELINE config 5: two calibrated 2016 x 1512 views (the size of the reference's Bun* / PikaBun* / Che_* images) with the distortion
+    model, written as a GMSFRM01 file by the C writer, then -- in a FRESH PROCESS that reads it with gms_dataset_read --
+    descriptors -> gms_bfmatch_device -> matchGMS(true, true, 6.0) (FeatureMatchUtil.cpp:66-69) -> gather -> findEssentialMat(RANSAC, 0.7,
+    1.0) -> recoverPose -> undistort -> triangulate (SfMUtil.cpp:25-82). (i) the putative matches and the GMS survivors are
+    byte-identical to the oracle's; (ii) E, R, t within 1e-9 of the numpy restatement fed the same survivors; (iii) the
+    reprojection RMS of the GPU loop equals that of the oracle-fed loop to 1e-8 relative, and the pose is the scene's."""
+    io = importlib.import_module("sfm-gms_amd.io")
+    size = (2016, 1512)
+    sc = synth.make_two_view_scene(55, size=size, n_points=9000)
+    n = len(sc["frames"][0])
+    assert n > 5000
+    pairs = np.zeros(1, dtype=pkg.PAIR_DTYPE)
+    pairs[0] = (0, 1, n, 0, 0)
+    path, out = str(tmp_path / "config5.gmsf"), str(tmp_path / "config5.npz")
+    io.save_c(path, io.Dataset(sc["frames"], sc["sizes"], sc["descriptors"], sc["desc_kind"], pairs, None))
+    cmd = [sys.executable, os.path.join(ROOT, "tools", "gms_filter_file.py"), path, "--rot", "--scale", "--camera", *map(str, sc["camera"]),
+           "--dist", *map(str, sc["dist"]), "--prob", "0.7", "--out", out]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    z = np.load(out)
+    # (i) matcher and filter, exactly
+    want_m = oracle.bf_match(sc["descriptors"][0], sc["descriptors"][1], True)
+    assert z["matches"].tobytes() == want_m.tobytes() and (want_m["queryIdx"] == want_m["trainIdx"]).mean() > 0.6
+    rc, want, _, wres = oracle.match(size, size, sc["frames"][0], sc["frames"][1], want_m, True, True, 6.0)
+    k = len(want)
+    assert rc == 0 and z["results"][0].tobytes() == wres.tobytes() and z["out"][:k].tobytes() == want.tobytes() and k > 3000
+    assert line["kept"] == k and line["pairs"] == 1 and line["failed_pairs"] == 0
+    # (ii) the geometry against the restatement on the same survivors
+    _, w1, w2 = oracle.gather(sc["frames"][0], sc["frames"][1], want)
+    ref = sfm_ref.two_view(w1, w2, sc["camera"], sc["dist"], 0.7, 1.0)
+    tv = z["two_view"][0]
+    assert int(tv["status"]) == 0 and int(tv["n_points"]) == k and int(tv["n_ransac"]) == ref["n_ransac"] and int(tv["ransac_iters"]) == ref["iters"]
+    assert np.abs(tv["E"] - ref["E"]).max() < 1e-9 and np.abs(tv["R"] - ref["R"]).max() < 1e-9 and np.abs(tv["t"] - ref["t"]).max() < 1e-9
+    assert np.array_equal(z["mask"][:k], ref["mask"]) and int(tv["n_pose"]) == ref["n_pose"]
+    # (iii) reprojection error of the GPU loop = of the oracle-fed loop
+    kept = int((ref["mask"] != 0).sum())
+    assert int(tv["n_triangulated"]) == kept and int(tv["n_finite"]) == kept
+    rms_gpu = np.sqrt((tv["sum_sq_err1"] + tv["sum_sq_err2"]) / (2 * kept))
+    rms_ref = np.sqrt((ref["sum_sq_err1"] + ref["sum_sq_err2"]) / (2 * kept))
+    assert abs(rms_gpu - rms_ref) <= 1e-8 * rms_ref and rms_gpu * sc["camera"][0] < 1.0           # below a pixel
+    assert abs(line["reprojection_rms"][0] - np.sqrt(ref["sum_sq_err1"] / kept)) <= 1e-8 * line["reprojection_rms"][0]
+    cosang = (np.trace(tv["R"] @ sc["R"].T) - 1) / 2
+    tdir = sc["t"] / np.linalg.norm(sc["t"])
+    assert np.degrees(np.arccos(min(1.0, cosang))) < 0.3 and np.degrees(np.arccos(min(1.0, abs(float(tv["t"] @ tdir))))) < 3.0
