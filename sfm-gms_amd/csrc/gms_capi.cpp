@@ -51,13 +51,14 @@ namespace {
 // Diagnostic switches, read from the environment ONCE per process (never on the call path):
 //   GMS_DENSE=0          keep every pair on the hashed path
 //   GMS_BAND=0           keep large pairs on the HBM-slab kernel alone
+//   GMS_STREAM=0         rotation / scale hypotheses on pairs of 16 385 .. 65 536 matches: the tile kernels instead of the streamed byte-matrix kernels
 //   GMS_STAGGER_US=n     spread of the first dispatch round's start times at 10k matches per pair (0 = off)
 //   GMS_BAND_WS_BYTES=n  budget of the large-pair workspace (default 4 GiB); a batch is filtered in slices that fit it
 //   GMS_DEAL=0|1         never / always deal the matches to the lanes of the byte-matrix kernel (default: what the probe saw)
 //   GMS_SCALE_PROBE=0|1  never / always bound the finer scale hypotheses' inlier counts first (default: while it pays, see below)
 //   GMS_CHECK_PAIRS=0|1  never / always validate the pair table behind a launch (default: the first launch and every sixteenth)
 struct Knobs {
-    bool dense_on = true, band_on = true;
+    bool dense_on = true, band_on = true, stream_on = true;
     int stagger_us = -1, deal = -1, scale_probe = -1, check_pairs = -1;
     size_t band_ws_budget = (size_t)4 << 30;
 };
@@ -67,6 +68,7 @@ const Knobs& knobs()
         Knobs v;
         if (const char* e = std::getenv("GMS_DENSE")) v.dense_on = std::atoi(e) != 0;
         if (const char* e = std::getenv("GMS_BAND")) v.band_on = std::atoi(e) != 0;
+        if (const char* e = std::getenv("GMS_STREAM")) v.stream_on = std::atoi(e) != 0;
         if (const char* e = std::getenv("GMS_STAGGER_US")) v.stagger_us = std::atoi(e);
         if (const char* e = std::getenv("GMS_DEAL")) v.deal = std::atoi(e) != 0 ? 1 : 0;
         if (const char* e = std::getenv("GMS_SCALE_PROBE")) v.scale_probe = std::atoi(e) != 0 ? 1 : 0;
@@ -140,6 +142,7 @@ struct WsNeed {
     size_t partial = 0, big = 0, band = 0;
     size_t slice = 0, per_pair = 0;  // large pairs: pairs per slice of the batch, workspace bytes per pair
     int kpt = 0, mcap = 0;
+    bool stream = false;             // large pairs up to 65 536 matches: the streamed byte-matrix kernels
 };
 
 }  // namespace
@@ -203,8 +206,13 @@ int plan_workspace(const gms_ctx* c, int n_pairs, int max_m, bool rot, bool scal
         p.with_rotation = rot;
         p.with_scale = scale;
         right_grids(p.right_w, p.right_h);
-        w->per_pair = (!rot && !scale) ? gms::band_ws_bytes_per_pair(w->mcap, need_mask_ws)
-                                       : gms::tile_ws_bytes_per_pair(p, w->mcap, need_mask_ws);
+        // rotation and / or scale hypotheses on pairs up to 65 536 matches: the streamed byte-matrix kernels (2.6x the tile kernels at
+        // 50k matches with both, 1.3x with rotation alone); the default flags stay on the three-band kernels (register-resident lists:
+        // 566k against 513k pairs/s at 50k matches) -- measured with tools/config4_bench.py
+        w->stream = knobs().stream_on && max_m <= gms::stream_max_matches() && (rot || scale);
+        w->per_pair = w->stream ? gms::stream_ws_bytes_per_pair(p, w->mcap, need_mask_ws)
+                                : (!rot && !scale) ? gms::band_ws_bytes_per_pair(w->mcap, need_mask_ws)
+                                                   : gms::tile_ws_bytes_per_pair(p, w->mcap, need_mask_ws);
         size_t slice = knobs().band_ws_budget / w->per_pair;
         if (slice < 1) slice = 1;
         if (slice > (size_t)n_pairs) slice = (size_t)n_pairs;
@@ -348,7 +356,8 @@ int filter_launch(gms_ctx* c, hipStream_t st, const float* d_pts, const int64_t*
             ps.results = d_results + s0;
             ps.n_pairs = (n_pairs - s0 < (int)w.slice) ? n_pairs - s0 : (int)w.slice;
             const uint32_t* flags = nullptr;
-            if (plain) GMS_HIP(gms::launch_filter_band(ps, w.mcap, c->band_ws.p, &flags, st));
+            if (w.stream) GMS_HIP(gms::launch_filter_stream(ps, w.mcap, c->band_ws.p, &flags, st));
+            else if (plain) GMS_HIP(gms::launch_filter_band(ps, w.mcap, c->band_ws.p, &flags, st));
             else GMS_HIP(gms::launch_filter_tiles(ps, w.mcap, c->band_ws.p, &flags, st));
             ps.pair_flags = flags;
             const int wg = ps.n_pairs < c->n_cus ? ps.n_pairs : c->n_cus;
@@ -477,6 +486,7 @@ int gms_ctx_create(int device, gms_ctx** out_ctx)
     if (e == hipSuccess) e = hipMemset(c->probe_stats.p, 0, 64);
     if (e == hipSuccess) e = gms::init_filter_kernels();
     if (e == hipSuccess) e = gms::init_band_kernels();
+    if (e == hipSuccess) e = gms::init_stream_kernels();
     if (e == hipSuccess) e = gms::init_big_kernels();
     if (e != hipSuccess) {
         t_last_hip = (int)e;

@@ -1,0 +1,585 @@
+// gms_kernel_stream.hip -- pairs of 16 385 ... 65 536 matches (BASELINE config 4: 4K pairs, 50k features) under every flag
+// combination, on the BYTE matrix of gms_kernels.hip (dense_pair / dense_scales_pair): one 1024-thread workgroup per (pair, scale
+// hypothesis) keeps the scale's 400 x N_right motion matrix -- or a band of its left rows -- in the CU's LDS, one byte per entry.
+//
+// What a workgroup of the small-pair kernels keeps in registers (a code word per match) does not fit here, so the matches live in a
+// per-pair workspace as 8-byte ENTRIES, written once per launch by two small kernels and streamed by the filter:
+//   stream_index_kernel<0>   per match: its left point's code and its right point's scale code from the frame table (no float ->
+//                            cell arithmetic per pair: normalize_kernel did it per keypoint), the pair's half-cell histogram and the
+//                            number of matches per left-grid ROW;
+//   stream_index_kernel<1>   the same walk again, now placing every entry in the slot of its row: the entry array is sorted by the
+//                            left row of grid type 1, so that a band of left rows is a contiguous range of it (plus nLeft of every
+//                            cell under the four grid types, 16 bits each);
+//   stream_filter_kernel     grid (scale hypotheses, pairs). Per grid type and band: clear the band's rows, stream the band's range
+//                            of entries to bin them (one returning LDS atomic on the entry's byte, one atomicMax on the row header:
+//                            the running arg-max), verify the band's own cells under all rotations, stream again to mark
+//                            (an accepted match ORs its rotation bits into its byte of the scale's array, by its ORIGINAL index);
+//   stream_count_kernel      the scales' byte arrays counted by bit: run()'s return value per (scale, rotation);
+//   stream_select_kernel     getInlierMask's strict '>' over the (scale, rotation) counts in the reference's order, the winner's bit of
+//                            every match into the pair's mask;
+//   band_compact_kernel      (gms_kernel_band.hip) order-preserving copy-out by the mask.
+// Right grids: 10 x 10, 14 x 14 and 20 x 20 fit the LDS whole; 28 x 28 takes three bands of eight rows (+ a halo row either side),
+// 40 x 40 seven bands of three. A band streams only the rows it holds -- not the pair.
+// An entry that would exceed its byte (more than 255 matches in ONE (left cell, right cell) pair), a left cell above 65 535 matches or
+// a frame table without code arrays flag the pair for the HBM-slab kernel (gms_kernel_big.hip), which runs behind on flagged pairs
+// only. Bit-exactness rules are those of gms_kernels.hip (same codes, same arg-max and tie rules, same threshold arithmetic).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <type_traits>
+
+#include "gms_device_common.h"
+
+namespace gms {
+namespace {
+
+constexpr int kSMaxMatches = 1 << 16;                      // (an entry holds 26 bits of original index; beyond 65 536 matches the 16-bit band / tile kernels are the better fit: entries above 255 get likely)
+constexpr uint32_t kSMatrixBytes = kLeftN * (4u + 400u);   // 161 600: scale 0's matrix; every other scale's block is smaller
+constexpr uint32_t kSNleftOff = kSMatrixBytes;             // [400] u16: nLeft of every cell under the current grid type
+constexpr uint32_t kSRowOff = kSNleftOff + 2u * kLeftN;    // [24] u32: first entry of every left row (21 used: [20] = entries binned)
+constexpr uint32_t kSMiscOff = kSRowOff + 96u;             // [16] u32: [0..7] inlier counts per rotation, [8] overflow
+constexpr uint32_t kSLdsBytes = kSMiscOff + 64u;           // 162 560
+static_assert(kSLdsBytes <= kLdsBytes, "stream layout exceeds the LDS");
+static_assert(10u * 20u * (4u + 784u) <= kSMatrixBytes && 5u * 20u * (4u + 1600u) <= kSMatrixBytes, "the banded scales fit");
+
+// entry.x = [q : 5 | never, edgeX, edgeY : 3 | left cell under grid type 1 : 9 | original index, low 15 bits]
+// entry.y = [right cell on the 20 x 20 grid : 9 | on the 28 x 28 grid : 10 | low bit of the 40 x 40 cell's x, y : 2 | original index, bits 15..25]
+// (the low 8 bits of x are the dense code word's, the low 21 of y the frame table's scale code as it stands)
+constexpr int kSCellShift = 8, kSOrigShift = 17, kSOrigHiShift = 21;
+constexpr uint32_t kSFlagDomain = 1u, kSFlagGeneral = 2u;  // (the values gms_kernel_band.hip / gms_kernel_big.hip use)
+constexpr int kSItemsScales = 4 * (7 + 3 + 1 + 1 + 1);     // (scale, grid type, band) work items of a pair with scale hypotheses
+constexpr int kSRowBuckets = 21;                           // 20 left rows + "binned under no grid type"
+
+struct StreamWs {
+    uint2* entries;      // [n][mcap], sorted by left row
+    uint32_t* nfine;     // [n][1600] half-cell histogram
+    uint32_t* row_cnt;   // [n][32]: matches per row bucket; [n][32 + r]: fill cursors
+    uint16_t* nleft;     // [n][4][400]
+    uint32_t* counts;    // [n][5][8]
+    uint32_t* flags;     // [n]
+    uint32_t* state;     // [n][4]: best count, scale, rotation
+    uint8_t* rotbits;    // [n][scales][4 grid types][mcap]
+    uint8_t* bestmask;   // [n][mcap] (when the caller gave no mask array)
+};
+
+__device__ __forceinline__ uint32_t entry_orig(const uint2& e) { return (e.x >> kSOrigShift) | ((e.y >> kSOrigHiShift) << 15); }
+
+// E(r) - 3 = nr - r of the entry's right cell under scale hypothesis s (see dense_scales_pair: the coarse grids' cells are halves of
+// the fine ones', the 40 x 40 cell is twice the 20 x 20 one plus a stored bit)
+template <int S>
+__device__ __forceinline__ uint32_t right_cell(uint32_t aux)
+{
+    if constexpr (S == 0) return aux & 0x1FFu;
+    if constexpr (S == 3) return (aux >> 9) & 0x3FFu;
+    if constexpr (S == 4) {
+        const uint32_t c20 = aux & 0x1FFu, cy = (c20 * 3277u) >> 16, cx = c20 - cy * 20u;
+        return (2u * cy + ((aux >> 20) & 1u)) * 40u + 2u * cx + ((aux >> 19) & 1u);
+    }
+    if constexpr (S == 1 || S == 2) {
+        const uint32_t fine = S == 1 ? aux & 0x1FFu : (aux >> 9) & 0x3FFu, wf = S == 1 ? 20u : 28u;
+        const uint32_t fy = (fine * (S == 1 ? 3277u : 2341u)) >> 16, fx = fine - fy * wf;
+        return (fy >> 1) * (wf >> 1) + (fx >> 1);
+    }
+    return 0u;
+}
+
+}  // namespace
+
+// ---- per match: codes, histograms (PASS 0) / its slot in the row-sorted entry array (PASS 1) ---------------------------------------------
+template <int PASS>
+__global__ void __launch_bounds__(1024)
+stream_index_kernel(FilterParams p, StreamWs w, int mcap)
+{
+    __shared__ uint32_t hist[kFineN];
+    __shared__ uint32_t cnt_l[32], base_g[32], row_start[32];
+    const int pi = blockIdx.y, tid = threadIdx.x;
+    const gms_pair pr = p.pairs[pi];
+    const int m = pr.m;
+    const bool bad_pair = m < 0 || m > mcap || pr.frame_a < 0 || pr.frame_a >= p.n_frames || pr.frame_b < 0 || pr.frame_b >= p.n_frames;
+    if (bad_pair) {
+        if (PASS == 0 && blockIdx.x == 0 && tid == 0) atomicOr(&w.flags[pi], kSFlagDomain);
+        return;
+    }
+    const int64_t offA = p.frame_off[pr.frame_a], offB = p.frame_off[pr.frame_b];
+    const int nA = (int)(p.frame_off[pr.frame_a + 1] - offA), nB = (int)(p.frame_off[pr.frame_b + 1] - offB);
+    const int64_t total_kp = table_total_kp(p);
+    if (m > 0 && (nA <= 0 || nB <= 0)) {  // matches, but nothing valid to index
+        if (PASS == 0 && blockIdx.x == 0 && tid == 0) atomicOr(&w.flags[pi], kSFlagDomain);
+        return;
+    }
+    if (total_kp < 0 || offA + nA > total_kp || offB + nB > total_kp) {  // no code arrays to work from: the general kernel's pair
+        if (PASS == 0 && blockIdx.x == 0 && tid == 0) atomicOr(&w.flags[pi], kSFlagGeneral);
+        return;
+    }
+    if (PASS == 1 && (w.flags[pi] & (kSFlagDomain | kSFlagGeneral))) return;  // (written by pass 0)
+    uint32_t* rc = w.row_cnt + (size_t)pi * 64;
+    if (PASS == 1 && blockIdx.x == 0) {
+        // nLeft of every cell under the four grid types (16 bits: a cell above 65 535 matches flags the pair)
+        const uint32_t* __restrict__ nf = w.nfine + (size_t)pi * kFineN;
+        bool big = false;
+        for (int item = tid; item < 4 * kLeftN; item += 1024) {
+            const int g = item / kLeftN, cell = item - g * kLeftN;
+            const int hx0 = 2 * (cell % kLeftW) - (g & 1), hy0 = 2 * (cell / kLeftW) - (g >> 1);
+            uint32_t n = 0;
+#pragma unroll
+            for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 2; ++dx) {
+                    const int hx = hx0 + dx, hy = hy0 + dy;
+                    if (hx >= 0 && hy >= 0) n += nf[hy * kFineW + hx];
+                }
+            big |= n > 65535u;
+            w.nleft[(size_t)pi * 4 * kLeftN + item] = (uint16_t)n;
+        }
+        if (big) atomicOr(&w.flags[pi], kSFlagGeneral);
+    }
+    const int base = blockIdx.x * 4096;
+    if (base >= m) return;  // workgroup-uniform
+    const gms_dmatch* __restrict__ matches = p.matches + pr.match_off;
+    const uint16_t* __restrict__ lcode = reinterpret_cast<const uint16_t*>(p.pts + total_kp) + offA;
+    const uint32_t* __restrict__ scode = reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint16_t*>(p.pts + total_kp) + 2 * total_kp) + offB;
+
+    if (PASS == 0)
+        for (int j = tid; j < kFineN; j += 1024) hist[j] = 0;
+    if (tid < 32) cnt_l[tid] = 0;
+    if (PASS == 1 && tid == 0) {
+        uint32_t acc = 0;
+        for (int r = 0; r < kSRowBuckets; ++r) {
+            row_start[r] = acc;
+            acc += rc[r];
+        }
+    }
+    __syncthreads();
+    uint2 qt[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) qt[k] = *reinterpret_cast<const uint2*>(&matches[min(base + k * 1024 + tid, m - 1)]);
+    uint32_t ca[4], cb[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        ca[k] = lcode[min(qt[k].x, (uint32_t)(nA - 1))];
+        cb[k] = scode[min(qt[k].y, (uint32_t)(nB - 1))];
+    }
+    bool any_bad = false;
+    uint32_t rank[4], bucket[4];
+    uint2 ent[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int i = base + k * 1024 + tid;
+        const bool live = i < m;
+        const uint32_t cell = ca[k] >> 7;  // under grid type 1; 510 = binned under no grid type, 511 = outside the parity domain
+        const bool ok = qt[k].x < (uint32_t)nA && qt[k].y < (uint32_t)nB && cell != 511u && (cb[k] >> 31) == 0u;
+        const bool binned = live && ok && cell < 510u;
+        any_bad |= live && !ok;
+        bucket[k] = binned ? cell / (uint32_t)kLeftW : 20u;
+        rank[k] = live ? atomicAdd(&cnt_l[bucket[k]], 1u) : 0u;
+        if (PASS == 0 && binned) {
+            const uint32_t hx = 2u * (cell % (uint32_t)kLeftW) + (ca[k] & 1u), hy = 2u * (cell / (uint32_t)kLeftW) + ((ca[k] >> 2) & 1u);
+            atomicAdd(&hist[hy * kFineW + hx], 1u);
+        }
+        // the dense code word's low byte (q as it stands, the two edge bits one place up, "never" for what is not binned), the cell, the index
+        const uint32_t low = binned ? ((ca[k] & 31u) | ((ca[k] & 0x60u) << 1)) : (1u << 5);
+        ent[k].x = low | ((binned ? cell : 0u) << kSCellShift) | (((uint32_t)i & 0x7FFFu) << kSOrigShift);
+        ent[k].y = (cb[k] & 0x1FFFFFu) | (((uint32_t)i >> 15) << kSOrigHiShift);
+    }
+    // an index out of range, a point outside the parity domain or outside one of the right grids: the general kernel decides what the
+    // reference would make of the pair (a domain error, or -- a right coordinate of exactly 1.0 -- a wrapped cell it counts)
+    if (PASS == 0 && any_bad) atomicOr(&w.flags[pi], kSFlagGeneral);
+    __syncthreads();
+    if (PASS == 0) {
+        uint32_t* nf = w.nfine + (size_t)pi * kFineN;
+        for (int j = tid; j < kFineN; j += 1024)
+            if (hist[j]) atomicAdd(&nf[j], hist[j]);
+        if (tid < kSRowBuckets && cnt_l[tid]) atomicAdd(&rc[tid], cnt_l[tid]);
+        return;
+    }
+    // this block's entries of a row go behind whatever other blocks have placed there (order inside a row does not matter: every
+    // consumer is a commutative atomic, or a write to the entry's own bits)
+    if (tid < kSRowBuckets) base_g[tid] = cnt_l[tid] ? atomicAdd(&rc[32 + tid], cnt_l[tid]) : 0u;
+    __syncthreads();
+    uint2* ents = w.entries + (size_t)pi * mcap;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (base + k * 1024 + tid < m) ents[row_start[bucket[k]] + base_g[bucket[k]] + rank[k]] = ent[k];
+}
+
+// ---- one scale hypothesis of one pair --------------------------------------------------------------------------------------------------
+template <bool ROT, int S>
+__device__ __forceinline__ void stream_scale(const FilterParams& p, const StreamWs& w, uint32_t* smem, const int mcap, const int n_scales, const int pi,
+                                             const int g, const int band)
+{
+    constexpr int kChunk = 16;
+    const int tid = threadIdx.x;
+    const gms_pair pr = p.pairs[pi];
+    const int m = pr.m;
+    if (m <= 0 || m > mcap) return;
+    if (w.flags[pi] & (kSFlagDomain | kSFlagGeneral)) return;  // written by the index kernels
+    const uint2* __restrict__ ents = w.entries + (size_t)pi * mcap;
+    // the byte array of this (scale, grid type): a match is marked by the one band that owns its left row, so a byte has one writer
+    uint8_t* rb = w.rotbits + (((size_t)pi * n_scales + (n_scales == 5 ? S : 0)) * 4 + (size_t)g) * mcap;
+
+    const uint8_t* bytes = reinterpret_cast<const uint8_t*>(smem);
+    uint16_t* nleft = reinterpret_cast<uint16_t*>(reinterpret_cast<uint8_t*>(smem) + kSNleftOff);
+    uint32_t* row_start = smem + kSRowOff / 4;
+    uint32_t* misc = smem + kSMiscOff / 4;
+    if (tid == 0) {
+        const uint32_t* rc = w.row_cnt + (size_t)pi * 64;
+        uint32_t acc = 0;
+        for (int r = 0; r <= 20; ++r) {
+            row_start[r] = acc;
+            acc += r < 20 ? rc[r] : 0u;
+        }
+    }
+    if (tid < 16) misc[tid] = 0;
+
+    constexpr uint32_t wr = S == 0 ? 20u : S == 1 ? 10u : S == 2 ? 14u : S == 3 ? 28u : 40u, nr = wr * wr, stride = 4u + nr;  // (checked by the launcher)
+    constexpr uint32_t wr_magic = 65535u / wr + 1u;  // j / wr == (j * magic) >> 16 for j * wr < 65536
+    constexpr int band_rows = S == 4 ? 3 : S == 3 ? 8 : kLeftH;
+    const bool thr_fast = threshold_fast_ok(p.threshold_factor);
+    static_assert((kLeftH + band_rows - 1) / band_rows == (S == 4 ? 7 : S == 3 ? 3 : 1), "bands per scale as the item table assumes");
+
+    // One pass over the entries at positions [p_lo, p_hi): a thread takes p_lo rounded down to a multiple of 1024, plus tid, plus
+    // 1024 k -- kChunk entries loaded before the first is worked on. body(entry, slot in the chunk).
+    auto stream = [&](uint32_t p_lo, uint32_t p_hi, auto&& load_done, auto&& body) {
+        for (uint32_t pos0 = (p_lo & ~1023u) + (uint32_t)tid; pos0 < p_hi; pos0 += kChunk * 1024u) {
+            uint2 e[kChunk];
+#pragma unroll
+            for (int j = 0; j < kChunk; ++j) {
+                const uint32_t pos = pos0 + (uint32_t)j * 1024u;
+                e[j] = (pos >= p_lo && pos < p_hi) ? ents[pos] : make_uint2(1u << 5, 0u);  // (an entry binned under no grid type)
+            }
+            load_done();
+#pragma unroll
+            for (int j = 0; j < kChunk; ++j) body(e[j], j);
+        }
+    };
+
+    {
+        const int gx = g & 1, gy = g >> 1;
+        const uint32_t q_mask = (uint32_t)(gx + 20 * gy);                               // l = l1 + (q & q_mask)
+        const uint32_t out_mask = (1u << 5) | (gx ? 1u << 6 : 0u) | (gy ? 1u << 7 : 0u);  // never | x >= 20 | y >= 20 under this grid type
+        if (tid < kLeftN / 2)
+            reinterpret_cast<uint32_t*>(nleft)[tid] = reinterpret_cast<const uint32_t*>(w.nleft + ((size_t)pi * 4 + g) * kLeftN)[tid];
+        {
+            const int lo = band * band_rows, hi = min(lo + band_rows, kLeftH);          // own rows
+            const int hlo = max(lo - 1, 0), hhi = min(hi + 1, kLeftH);                  // rows held (own + halo)
+            const uint32_t cell0 = (uint32_t)(hlo * kLeftW), n_held = (uint32_t)((hhi - hlo) * kLeftW);
+            const uint32_t own0 = (uint32_t)(lo * kLeftW), n_own = (uint32_t)((hi - lo) * kLeftW);
+            {   // motion.setTo(0) for the rows held, headers included
+                const uint4 z4 = make_uint4(0, 0, 0, 0);
+                uint4* d4 = reinterpret_cast<uint4*>(smem);
+                for (uint32_t i = tid; i < (n_held * stride + 15u) / 16u; i += 1024) d4[i] = z4;
+            }
+            __syncthreads();
+            // ---- assignMatchPairs for the rows held: entries of grid-type-1 rows hlo - 1 (the y-shifted types move a match one row
+            //      down) .. hhi - 1. +1 on the entry's byte; the count it produced goes into the row's running arg-max.
+            {
+                uint32_t old[kChunk], at[kChunk], hdr[kChunk], key[kChunk];
+                stream(row_start[max(hlo - 1, 0)], row_start[hhi], [] {}, [&](const uint2& e, int j) {
+                    const uint32_t cw = e.x;
+                    const uint32_t l = ((cw >> kSCellShift) & 0x1FFu) + (cw & q_mask) - cell0;
+                    const bool in = (cw & out_mask) == 0u && l < n_held;
+                    const uint32_t er = nr + 3u - right_cell<S>(e.y);  // the byte's offset in its row
+                    const uint32_t row = __umul24(l, stride);
+                    at[j] = row + er;
+                    hdr[j] = in ? row : 0xFFFFFFFFu;
+                    key[j] = er;
+                    old[j] = 0u;
+                    if (in) old[j] = atomicAdd(lds_at(smem, at[j] & ~3u), 1u << ((at[j] << 3) & 31u));
+                    if (j == kChunk - 1) {
+                        __builtin_amdgcn_sched_barrier(0);  // all of the chunk's atomics are issued before any result is read
+#pragma unroll
+                        for (int c = 0; c < kChunk; ++c) {
+                            const uint32_t before = (old[c] >> ((at[c] << 3) & 31u)) & 255u;
+                            if (hdr[c] != 0xFFFFFFFFu) {
+                                if (before == 255u) misc[8] = 1u;  // the entry's byte has just wrapped
+                                atomicMax(lds_at(smem, hdr[c]), (before << 11) | key[c]);  // highest count, then lowest right cell
+                            }
+                        }
+                    }
+                });
+            }
+            __syncthreads();
+            if (misc[8] != 0u) {  // a (left cell, right cell) pair above 255 matches (workgroup-uniform): the general kernel's pair
+                if (tid == 0) atomicOr(&w.flags[pi], kSFlagGeneral);
+                return;
+            }
+            // ---- verifyCellPairs for the own cells (dense_scales_pair's: two lanes per cell without rotation, four lanes per cell and
+            //      two rotations per lane with)
+            {
+                constexpr int kNR = ROT ? 2 : 1;
+                constexpr int kLanesPerCell = ROT ? 4 : 2, kCellShift = ROT ? 2 : 1;
+                const int n_items = (int)n_own * kLanesPerCell;
+                for (int item = tid; item < ((n_items + 63) & ~63); item += 1024) {
+                    const bool live = item < n_items;
+                    const int i = (int)own0 + (live ? (item >> kCellShift) : 0);
+                    const int sub = item & (kLanesPerCell - 1);
+                    const int half = item & 1;  // !ROT only
+                    const int ix = i % kLeftW, iy = i / kLeftW;
+                    const uint32_t ni = live ? (uint32_t)nleft[i] : 0u;
+                    if (__ballot(ni != 0) == 0ull) continue;  // none of this wave's cells has a match under this grid type
+                    const uint32_t hdr = ((uint32_t)i - cell0) * (stride >> 2);
+                    const uint32_t best = smem[hdr];  // ((max count - 1) << 11) | E(j*), lowest j* among maxima
+                    const uint32_t ej = ni ? (best & 0x7FFu) : nr + 3u;
+                    const uint32_t j = nr + 3u - ej;
+                    const int jy = (int)((j * wr_magic) >> 16), jx = (int)j - jy * (int)wr;
+                    uint32_t score[kNR], tn[kNR], rpack[kNR];  // tn = (sum of nLeft << 4) | numpair
+#pragma unroll
+                    for (int jr = 0; jr < kNR; ++jr) {
+                        score[jr] = tn[jr] = 0;
+                        rpack[jr] = sub == 0 ? rotation_pack(jr) : sub == 1 ? rotation_pack(2 + jr) : sub == 2 ? rotation_pack(4 + jr) : rotation_pack(6 + jr);
+                    }
+#pragma unroll
+                    for (int c = 0; c < (ROT ? 8 : 4); ++c) {
+                        int ldx, ldy;
+                        if (ROT) {
+                            const int k = c < 4 ? c : c + 1;
+                            ldx = (k % 3) - 1; ldy = (k / 3) - 1;
+                        } else {
+                            ldx = half ? ((c + 5) % 3) - 1 : (c % 3) - 1;
+                            ldy = half ? ((c + 5) / 3) - 1 : (c / 3) - 1;
+                        }
+                        const int lx = ix + ldx, ly = iy + ldy;
+                        const bool okl = ni != 0 && (uint32_t)lx < (uint32_t)kLeftW && (uint32_t)ly < (uint32_t)kLeftH;
+                        const uint32_t ll = okl ? (uint32_t)(lx + ly * kLeftW) : (uint32_t)i;  // within one row of an own row: held
+                        const uint32_t nll = (uint32_t)nleft[ll];
+                        const uint32_t rowb = (ll - cell0) * stride;
+#pragma unroll
+                        for (int jr = 0; jr < kNR; ++jr) {
+                            int rdx = ldx, rdy = ldy;
+                            if (ROT) {
+                                rdx = (int)((rpack[jr] >> (4 * c)) & 3u) - 1;
+                                rdy = (int)((rpack[jr] >> (4 * c + 2)) & 3u) - 1;
+                            }
+                            const int rx = jx + rdx, ry = jy + rdy;
+                            const bool okp = okl && (uint32_t)rx < wr && (uint32_t)ry < wr;
+                            const uint32_t cnt = bytes[rowb + (okp ? nr + 3u - (uint32_t)(rx + ry * (int)wr) : 4u)];
+                            score[jr] += okp ? cnt : 0u;
+                            tn[jr] += okp ? ((nll << 4) | 1u) : 0u;
+                        }
+                    }
+                    uint32_t vbits = 0;
+                    if (!ROT) {
+                        score[0] += dpp_xor1(score[0]);
+                        tn[0] += dpp_xor1(tn[0]);
+                    }
+#pragma unroll
+                    for (int jr = 0; jr < kNR; ++jr) {
+                        const uint32_t sc = score[jr] + (best >> 11) + 1u, t = tn[jr] + ((ni << 4) | 1u);
+                        uint32_t pass = 0;
+                        if (ni != 0 && (ROT || half == 0)) pass = threshold_rejects(t >> 4, t & 15u, sc, p.threshold_factor, thr_fast) ? 0u : 1u;
+                        vbits |= pass << jr;
+                    }
+                    if (ROT) {  // the cell's four lanes hold rotations (0,1) (2,3) (4,5) (6,7): gather the quad's bit pairs
+                        const uint32_t b0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)vbits, 0x00, 0xF, 0xF, false);
+                        const uint32_t b1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)vbits, 0x55, 0xF, 0xF, false);
+                        const uint32_t b2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)vbits, 0xAA, 0xF, 0xF, false);
+                        const uint32_t b3 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)vbits, 0xFF, 0xF, 0xF, false);
+                        vbits = b0 | (b1 << 2) | (b2 << 4) | (b3 << 6);
+                    }
+                    if (ni != 0 && sub == 0) smem[hdr] = (ej << 8) | vbits;  // cellPairs[i] and the rotations that accept it
+                }
+            }
+            __syncthreads();
+            // ---- mark: cellPairs[l] == r for the entries whose left cell is one of the band's own; the rotations that accept the cell go
+            //      into the match's byte of this (scale, grid type)'s array, by the match's original index
+            stream(row_start[max(lo - 1, 0)], row_start[hi], [] {}, [&](const uint2& e, int) {
+                const uint32_t cw = e.x;
+                const uint32_t l = ((cw >> kSCellShift) & 0x1FFu) + (cw & q_mask);
+                if ((cw & out_mask) == 0u && l - own0 < n_own) {
+                    const uint32_t cr = smem[__umul24(l - cell0, stride) >> 2];
+                    const uint32_t x = cr ^ ((nr + 3u - right_cell<S>(e.y)) << 8);  // < 256: the same right cell, x = the rotations that accept
+                    if (x < 256u && x != 0u) rb[entry_orig(e)] = (uint8_t)x;
+                }
+            });
+        }
+    }
+}
+
+template <bool ROT>
+__global__ void __launch_bounds__(1024)
+stream_filter_kernel(FilterParams p, StreamWs w, int mcap, int n_scales)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    // One workgroup per (pair, scale, grid type, band of left rows): all independent (each clears its rows and writes its own cells'
+    // verdicts into its (scale, grid type)'s byte array). Items of a pair in the order 40 x 40 (seven bands x four grid types), 28 x 28
+    // (three x four), then the whole-matrix scales 0, 2, 1 (four each): 52 with scale hypotheses, 4 without.
+    // Workgroups are handed to the eight XCDs round-robin; the items of a pair all stream the pair's entry array, so they are dealt to
+    // ONE XCD (its L2 then serves every re-read): workgroup L = 8 slot + xcd works on pair 8 (slot / items) + xcd, item slot % items.
+    const int items = n_scales == 5 ? kSItemsScales : 4;
+    const int L = (int)blockIdx.x, n8 = p.n_pairs & ~7;
+    int pi, item;
+    if (L < n8 * items) {
+        const int slot = L >> 3;
+        pi = (slot / items) * 8 + (L & 7);
+        item = slot % items;
+    } else {  // the last n_pairs % 8 pairs
+        pi = n8 + (L - n8 * items) / items;
+        item = (L - n8 * items) % items;
+    }
+    if (n_scales != 5) {
+        stream_scale<ROT, 0>(p, w, smem, mcap, n_scales, pi, item & 3, 0);
+    } else if (item < 28) {
+        stream_scale<ROT, 4>(p, w, smem, mcap, n_scales, pi, item & 3, item >> 2);
+    } else if (item < 40) {
+        stream_scale<ROT, 3>(p, w, smem, mcap, n_scales, pi, (item - 28) & 3, (item - 28) >> 2);
+    } else if (item < 44) {
+        stream_scale<ROT, 0>(p, w, smem, mcap, n_scales, pi, item - 40, 0);
+    } else if (item < 48) {
+        stream_scale<ROT, 2>(p, w, smem, mcap, n_scales, pi, item - 44, 0);
+    } else {
+        stream_scale<ROT, 1>(p, w, smem, mcap, n_scales, pi, item - 48, 0);
+    }
+}
+
+// ---- run()'s return value per (scale, rotation): the bytes of the scales' arrays, counted by bit (grid: 16k-match tiles x scales x pairs)
+template <bool ROT>
+__global__ void __launch_bounds__(1024)
+stream_count_kernel(FilterParams p, StreamWs w, int mcap, int n_scales)
+{
+    __shared__ uint32_t cnt[8];
+    const int tile = blockIdx.x, s = blockIdx.y, pi = blockIdx.z, tid = threadIdx.x, lane = tid & 63;
+    const int m = p.pairs[pi].m;
+    if (m <= 0 || m > mcap || tile * 16384 >= m || (w.flags[pi] & (kSFlagDomain | kSFlagGeneral))) return;
+    constexpr int kNRot = ROT ? 8 : 1;
+    if (tid < 8) cnt[tid] = 0;
+    __syncthreads();
+    const int first = tile * 16384 + tid * 16;  // 16 consecutive bytes per thread (the arrays are 64-byte aligned, zero beyond m)
+    uint32_t wd[4] = {0u, 0u, 0u, 0u};
+    if (first < m) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {  // the mask of a hypothesis is the OR over the four grid types (run(), DLL@0x180048ae0)
+            const uint4 v = *reinterpret_cast<const uint4*>(w.rotbits + (((size_t)pi * n_scales + s) * 4 + g) * mcap + first);
+            wd[0] |= v.x;
+            wd[1] |= v.y;
+            wd[2] |= v.z;
+            wd[3] |= v.w;
+        }
+    }
+    uint32_t c[kNRot];
+#pragma unroll
+    for (int r = 0; r < kNRot; ++r) {
+        uint32_t acc = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc += (((wd[q] >> r) & 0x01010101u) * 0x01010101u) >> 24;  // bytes with bit r set
+        c[r] = acc;
+    }
+#pragma unroll
+    for (int r = 0; r < kNRot; ++r) {
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) c[r] += __shfl_xor(c[r], d);
+        if (lane == 0 && c[r]) atomicAdd(&cnt[r], c[r]);
+    }
+    __syncthreads();
+    if (tid < kNRot && cnt[tid]) atomicAdd(&w.counts[((size_t)pi * 5 + s) * 8 + tid], cnt[tid]);
+}
+
+// ---- getInlierMask over the scales' counts; the winner's bit of every match into the pair's mask --------------------------------------
+template <bool ROT>
+__global__ void __launch_bounds__(1024)
+stream_select_kernel(FilterParams p, StreamWs w, int mcap, int n_scales)
+{
+    const int tile = blockIdx.x, pi = blockIdx.y, tid = threadIdx.x;
+    const gms_pair pr = p.pairs[pi];
+    const int m = pr.m;
+    if (m <= 0 || m > mcap || (w.flags[pi] & (kSFlagDomain | kSFlagGeneral))) return;
+    constexpr int kNRot = ROT ? 8 : 1;
+    // scale outer, rotation inner, strict '>' from 0 (DLL@0x180047dc0): the first hypothesis with the largest count
+    uint32_t best = 0;
+    int bs = -1, br = -1;
+    for (int s = 0; s < n_scales; ++s)
+#pragma unroll
+        for (int r = 0; r < kNRot; ++r) {
+            const uint32_t c = w.counts[((size_t)pi * 5 + s) * 8 + r];
+            if (c > best) {
+                best = c;
+                bs = s;
+                br = r;
+            }
+        }
+    if (tile == 0 && tid == 0) {
+        w.state[pi * 4 + 0] = best;
+        w.state[pi * 4 + 1] = (uint32_t)bs;
+        w.state[pi * 4 + 2] = (uint32_t)(br + 1);
+    }
+    uint8_t* bm = p.mask ? p.mask + pr.match_off : w.bestmask + (size_t)pi * mcap;
+    const uint8_t* rb = w.rotbits + ((size_t)pi * n_scales + (bs < 0 ? 0 : bs)) * 4 * mcap;
+    for (int i = tile * 16384 + tid; i < min(m, (tile + 1) * 16384); i += 1024)
+        bm[i] = bs >= 0 ? ((rb[i] | rb[(size_t)mcap + i] | rb[2 * (size_t)mcap + i] | rb[3 * (size_t)mcap + i]) >> br) & 1u : 0u;
+}
+
+// ---- launch helpers ----------------------------------------------------------------------------------------------------------------------
+hipError_t init_stream_kernels()  // once per context: see init_filter_kernels
+{
+    const void* fns[] = {reinterpret_cast<const void*>(stream_filter_kernel<true>), reinterpret_cast<const void*>(stream_filter_kernel<false>)};
+    for (const void* fn : fns) {
+        const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
+int stream_max_matches() { return kSMaxMatches; }
+
+static size_t align16s(size_t x) { return (x + 15) & ~(size_t)15; }
+
+size_t stream_ws_bytes_per_pair(const FilterParams& p, int mcap, bool need_mask)
+{
+    const size_t n_scales = p.with_scale ? 5 : 1;
+    return (size_t)mcap * 8 + (size_t)kFineN * 4 + 64 * 4 + 4 * (size_t)kLeftN * 2 + 5 * 8 * 4 + 4 + 16 + 4 * n_scales * (size_t)mcap +
+           (need_mask ? (size_t)mcap : 0) + 128;  // (+ the alignment of the arrays of a slice)
+}
+
+// ws layout for n pairs: entries | nfine | row_cnt | counts | flags | state | nleft | rotbits | bestmask; *flags_out marks the pairs left
+// to launch_filter_big (bit 1)
+hipError_t launch_filter_stream(const FilterParams& p, int mcap, void* ws, const uint32_t** flags_out, hipStream_t stream)
+{
+    const int n = p.n_pairs;
+    if (n <= 0) return hipSuccess;
+    const int n_scales = p.with_scale ? 5 : 1;
+    static const int kGrid[5] = {20, 10, 14, 28, 40};  // the right grids the kernels are written for (setScale, DLL@0x180048c10)
+    for (int s = 0; s < n_scales; ++s)
+        if (p.right_w[s] != kGrid[s] || p.right_h[s] != kGrid[s]) return hipErrorInvalidValue;
+    StreamWs w;
+    char* q = reinterpret_cast<char*>(ws);
+    w.entries = reinterpret_cast<uint2*>(q);
+    q += align16s((size_t)n * mcap * 8);
+    char* zero_from = q;  // everything from here to the entries' end of rotbits starts at zero
+    w.nfine = reinterpret_cast<uint32_t*>(q);
+    q += (size_t)n * kFineN * 4;
+    w.row_cnt = reinterpret_cast<uint32_t*>(q);
+    q += (size_t)n * 64 * 4;
+    w.counts = reinterpret_cast<uint32_t*>(q);
+    q += (size_t)n * 5 * 8 * 4;
+    w.flags = reinterpret_cast<uint32_t*>(q);
+    q += align16s((size_t)n * 4);
+    w.state = reinterpret_cast<uint32_t*>(q);
+    q += (size_t)n * 16;
+    w.rotbits = reinterpret_cast<uint8_t*>(q);
+    q += align16s((size_t)n * n_scales * 4 * mcap);
+    char* zero_to = q;
+    w.nleft = reinterpret_cast<uint16_t*>(q);
+    q += align16s((size_t)n * 4 * kLeftN * 2);
+    w.bestmask = reinterpret_cast<uint8_t*>(q);
+    hipError_t e = hipMemsetAsync(zero_from, 0, (size_t)(zero_to - zero_from), stream);
+    if (e != hipSuccess) return e;
+    const dim3 ig((unsigned)((mcap + 4095) / 4096), (unsigned)n);
+    hipLaunchKernelGGL(stream_index_kernel<0>, ig, dim3(1024), 0, stream, p, w, mcap);
+    hipLaunchKernelGGL(stream_index_kernel<1>, ig, dim3(1024), 0, stream, p, w, mcap);
+    const bool rot = p.with_rotation != 0;
+    const dim3 fg((unsigned)(n_scales == 5 ? kSItemsScales : 4) * (unsigned)n), sg((unsigned)((mcap + 16383) / 16384), (unsigned)n);
+    const dim3 cg((unsigned)((mcap + 16383) / 16384), (unsigned)n_scales, (unsigned)n);
+    if (rot) {
+        hipLaunchKernelGGL(stream_filter_kernel<true>, fg, dim3(1024), kSLdsBytes, stream, p, w, mcap, n_scales);
+        hipLaunchKernelGGL(stream_count_kernel<true>, cg, dim3(1024), 0, stream, p, w, mcap, n_scales);
+        hipLaunchKernelGGL(stream_select_kernel<true>, sg, dim3(1024), 0, stream, p, w, mcap, n_scales);
+    } else {
+        hipLaunchKernelGGL(stream_filter_kernel<false>, fg, dim3(1024), kSLdsBytes, stream, p, w, mcap, n_scales);
+        hipLaunchKernelGGL(stream_count_kernel<false>, cg, dim3(1024), 0, stream, p, w, mcap, n_scales);
+        hipLaunchKernelGGL(stream_select_kernel<false>, sg, dim3(1024), 0, stream, p, w, mcap, n_scales);
+    }
+    e = launch_band_compact(p, mcap, w.flags, w.bestmask, w.state, stream);
+    *flags_out = w.flags;
+    return e != hipSuccess ? e : hipGetLastError();
+}
+
+}  // namespace gms

@@ -296,3 +296,49 @@ def test_slab_kernel_alone_whole_file_again():
     res = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-x", "-q", "-k", "not again"],
                          capture_output=True, text=True, timeout=1500, env=dict(os.environ, GMS_BAND="0"))
     assert res.returncode == 0, res.stdout[-3000:]
+
+
+def test_band_and_tile_kernels_whole_file_again():
+    """GMS_STREAM=0 (read once per process): pairs of 16 385 .. 65 536 matches with rotation / scale hypotheses skip the streamed
+    byte-matrix kernels (their default since round 3) and run on the 16-bit tile kernels, as larger pairs always do. Same bytes for
+    everything in this file."""
+    import os
+    import subprocess
+    import sys
+    res = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-x", "-q", "-k", "not again"],
+                         capture_output=True, text=True, timeout=1500, env=dict(os.environ, GMS_STREAM="0"))
+    assert res.returncode == 0, res.stdout[-3000:]
+
+
+def test_streamed_kernels_when_an_entry_leaves_its_byte(ctx, oracle, synth):
+    """40 000 matches, a third of them from one left cell to one right cell: that (left cell, right cell) entry passes 255 under every
+    grid type, the streamed byte-matrix kernels flag the pair and the HBM-slab kernel produces it -- same bytes; in a batch with a pair
+    the streamed kernels keep."""
+    import importlib
+    batch = importlib.import_module("sfm-gms_amd.batch")
+    pkg = importlib.import_module("sfm-gms_amd")
+    rng = np.random.default_rng(77)
+    size, n = (1920, 1080), 40000
+    xy1 = np.stack([rng.uniform(0, size[0] - 1, n), rng.uniform(0, size[1] - 1, n)], axis=1).astype(np.float32)
+    xy2 = np.clip(xy1 + rng.normal(0, 2.0, (n, 2)).astype(np.float32) + np.float32(5.0), 0, [size[0] - 1.01, size[1] - 1.01]).astype(np.float32)
+    hot = slice(0, n // 3)
+    xy1[hot] = np.stack([rng.uniform(965, 1050, n // 3), rng.uniform(545, 590, n // 3)], axis=1)   # inside one 96 x 54 cell
+    xy2[hot] = xy1[hot] + np.float32(3.0)
+    train = np.arange(n)
+    wrong = rng.uniform(size=n) < 0.3
+    train[wrong] = rng.integers(0, n, int(wrong.sum()))
+    kp1, kp2 = synth.make_keypoints(xy1), synth.make_keypoints(xy2)
+    m_hot = synth.make_matches(np.arange(n), train, rng)
+    cool1, cool2, m_cool = synth.make_pair(801, size1=size, n1=30000, inlier_frac=0.5)
+    frames = [kp1, kp2, cool1, cool2]
+    pairs = np.zeros(2, dtype=pkg.PAIR_DTYPE)
+    pairs[0], pairs[1] = (0, 1, n, 0, 0), (2, 3, 30000, 0, n)
+    matches = np.concatenate([m_hot, m_cool])
+    table = batch.FrameTable(ctx, frames, [size] * 4)
+    for rot, scale in ((False, False), (True, True)):
+        out, res, mask = batch.filter_pairs(ctx, table, pairs, matches, rot, scale, 6.0)
+        for i in range(2):
+            a, b, m, o = (int(pairs[k][i]) for k in ("frame_a", "frame_b", "m", "match_off"))
+            rc, want, wmask, wres = oracle.match(size, size, frames[a], frames[b], matches[o:o + m], rot, scale, 6.0)
+            assert rc == 0 and res[i].tobytes() == wres.tobytes() and np.array_equal(mask[o:o + m], wmask)
+            assert out[o:o + len(want)].tobytes() == want.tobytes() and len(want) > 5000
