@@ -49,6 +49,7 @@ def parse():
                     help="chunks kept resident in HBM (2.6 GB each at the defaults); more steps cycle through them")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the all-core CPU baseline (0 = every CPU this process may use)")
     ap.add_argument("--cpu-reps", type=int, default=5)
+    ap.add_argument("--cpu-oversubscribe", action="store_true", help="also time one thread per CPU of the affinity mask, beyond the cgroup's quota")
     ap.add_argument("--spatial-order", action="store_true",
                     help="diagnostic: keypoints listed cell by cell instead of in random order (LDS bank-conflict experiment, DESIGN.md 6)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg (profiling runs)")
@@ -183,11 +184,28 @@ def check_parity(wl, pkg, chunk_ids, rot, scale, sample=None):
     return checked, bad
 
 
+def cgroup_cpu_quota():
+    """The container's CPU time limit in CPUs (cgroup v2 cpu.max, v1 cfs quota / period), or None when unlimited / unreadable."""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else float(q) / float(per)
+    except Exception:
+        pass
+    try:
+        q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else q / per
+    except Exception:
+        return None
+
+
 def cpu_baseline(args, wl, pkg, rot, scale, budget_s):
     """The oracle (CPU restatement of the reference's matchGMS, one pair per thread) on the first pairs of chunk 0, at 1, 16 and
     all threads; median of --cpu-reps repetitions each, sample sizes chosen for about `budget_s` seconds of CPU work in all."""
     oracle = oracle_module()
-    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    affinity = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = cgroup_cpu_quota()  # CPUs' worth of time the container may use (a GPU box hands a one-GPU job a share of the host)
+    avail = affinity if quota is None else max(1, min(affinity, int(quota + 0.5)))
     all_threads = args.cpu_threads if args.cpu_threads > 0 else avail
     kp_all = np.concatenate(wl.frames)
     foff = wl.table.frame_off_host
@@ -213,7 +231,7 @@ def cpu_baseline(args, wl, pkg, rot, scale, budget_s):
     r_probe, n_probe = run(8, 1)
     per_leg = budget_s / 3.0 / (reps + 1)
     legs = {}
-    for threads in sorted({1, min(16, all_threads), all_threads}):
+    for threads in sorted({1, min(16, all_threads), all_threads, min(affinity, 256) if args.cpu_oversubscribe else 1}):
         n = int(min(wl.n_pairs, max(8 * threads, r_probe * per_leg * min(threads, avail) ** 0.9)))
         rate, n_used = run(n, threads)
         legs[threads] = {"pairs_per_s": rate, "pairs": n_used}
@@ -221,7 +239,8 @@ def cpu_baseline(args, wl, pkg, rot, scale, budget_s):
     return {"value": legs[best]["pairs_per_s"], "unit": "pairs/s", "cores": best, "kind": "port",
             "sample": f"first {legs[best]['pairs']} pairs of the rank's first chunk, oracle/gms_ref.c (per-thread reusable storage, atomic work "
                       f"counter), one pair per thread, median of {reps}",
-            "by_threads": {str(t): legs[t] for t in legs}, "cpus_available": avail, "host_cpus": os.cpu_count()}
+            "by_threads": {str(t): legs[t] for t in legs}, "cpus_available": avail, "cpu_affinity": affinity, "cgroup_cpu_quota": quota,
+            "host_cpus": os.cpu_count()}
 
 
 def bf_gms_leg(ctx, wl, pkg, stream, kind, n_frames=64, n_pairs=1024, steps=3):
@@ -301,6 +320,120 @@ def bf_gms_leg(ctx, wl, pkg, stream, kind, n_frames=64, n_pairs=1024, steps=3):
             "filter_ms_per_step": filter_ms, "mean_kept_per_pair": float(res["n_inliers"].mean()), "roofline": roof,
             "parity": {"pairs_checked": len(idx), "mismatches": bad, "bit_exact": bad == 0,
                        "rule": "matches and filtered output of the first and last pair vs oracle/bf_ref.c + oracle/gms_ref.c"}}
+
+
+def zoom_leg(ctx, pkg, stream, dev, n_frames=64, n_kp=10000, n_pairs=1024, steps=6):
+    """matchGMS(true, true, 6.0) on pairs whose true relative scale is sqrt 2 (synth.make_zoom_sequence: even frame -> odd frame): the
+    winner is scale hypothesis 3 (28 x 28 right grid), one of the scales the probe tries to bound out -- here it cannot."""
+    import torch
+    synth = importlib.import_module(PKG + ".synth")
+    batch = importlib.import_module(PKG + ".batch")
+    distmod = importlib.import_module(PKG + ".dist")
+    frames = synth.make_zoom_sequence(1000, n_frames, size=SIZE, n_kp=n_kp)
+    table = batch.FrameTable(ctx, frames, [SIZE] * n_frames, device=dev)
+    pairs = np.zeros(n_pairs, dtype=pkg.PAIR_DTYPE)
+    k = 0
+    for a in range(0, n_frames, 2):
+        for b in range(1, n_frames, 2):
+            if k < n_pairs:
+                pairs[k] = (a, b, n_kp, 0, k * n_kp)
+                k += 1
+    n_pairs = k
+    pairs = pairs[:n_pairs]
+    d_pairs = torch.from_numpy(pairs.view(np.uint8).reshape(-1)).to(dev)
+    d_matches = distmod.synth_matches_device(0, n_pairs, n_kp, 0.5, dev)
+    d_out = torch.zeros((n_pairs * n_kp, 4), dtype=torch.int32, device=dev)
+    d_res = torch.zeros((n_pairs, 4), dtype=torch.int32, device=dev)
+    ctx.reserve(n_pairs, n_kp, True, True)
+    out = {"workload": f"{n_pairs} pairs (even frame, odd frame) of a zooming sequence, true relative scale sqrt 2, 10k matches per pair, flags (true, true, 6.0)"}
+    for name, val in (("auto", -1), ("off", 0), ("on", 1)):
+        ctx.set_option(2, val)
+        torch.cuda.synchronize()
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+        with torch.cuda.stream(stream):
+            for s in range(-2, steps):
+                if s >= 0:
+                    ev[s][0].record(stream)
+                ctx.filter_device(table.d_pts.data_ptr(), table.d_frame_off.data_ptr(), n_frames, d_pairs.data_ptr(), n_pairs, n_kp,
+                                  d_matches.data_ptr(), d_out.data_ptr(), d_res.data_ptr(), None, True, True, 6.0)
+                if s >= 0:
+                    ev[s][1].record(stream)
+        torch.cuda.synchronize()
+        ms = float(np.median([a.elapsed_time(b) for a, b in ev]))
+        out[name] = {"pairs_per_s": n_pairs / (ms * 1e-3), "ms_per_launch": ms, "probe_mask": ctx.query(2)}
+    ctx.set_option(2, -1)
+    res = d_res.cpu().numpy().view(pkg.RESULT_DTYPE).reshape(-1)
+    out["winning_scales"] = {str(sc): int((res["best_scale"] == sc).sum()) for sc in range(-1, 5) if (res["best_scale"] == sc).any()}
+    oracle = oracle_module()
+    kp_all = np.concatenate(frames)
+    wh = np.array([SIZE] * n_frames, dtype=np.int32).reshape(-1)
+    bad = 0
+    idx = [0, n_pairs // 2, n_pairs - 1]
+    for i in idx:
+        sel = pairs[i:i + 1].copy()
+        sel["match_off"] = 0
+        m = d_matches[i * n_kp:(i + 1) * n_kp].cpu().numpy().view(np.uint8).reshape(-1).view(pkg.DMATCH_DTYPE)
+        failed, wout, wres, _ = oracle.batch(kp_all, table.frame_off_host, wh, sel, m, True, True, 6.0, 1)
+        kk = int(wres["n_inliers"][0])
+        got = d_out[i * n_kp:i * n_kp + kk].cpu().numpy().view(np.uint8).reshape(-1).view(pkg.DMATCH_DTYPE)
+        bad += 0 if (failed == 0 and res[i].tobytes() == wres[0].tobytes() and got.tobytes() == wout[:kk].tobytes()) else 1
+    out["parity"] = {"pairs_checked": len(idx), "mismatches": bad, "bit_exact": bad == 0}
+    return out
+
+
+def config4_leg(ctx, pkg, stream, dev, n_kp=50000, steps=5):
+    """BASELINE config 4: 3840 x 2160 pairs with 50k features, M = 50k putative matches per pair -- at its stated flags (rotation + scale
+    hypotheses, 8 rot x 5 scale x 4 grids; 64 pairs per launch) and at the default flags (256 pairs per launch), device-resident."""
+    import torch
+    synth = importlib.import_module(PKG + ".synth")
+    batch = importlib.import_module(PKG + ".batch")
+    distmod = importlib.import_module(PKG + ".dist")
+    size, n_frames = (3840, 2160), 24
+    frames = synth.make_sequence(1000, n_frames, size=size, n_kp=n_kp)
+    table = batch.FrameTable(ctx, frames, [size] * n_frames, device=dev)
+    oracle = oracle_module()
+    kp_all = np.concatenate(frames)
+    wh = np.array([size] * n_frames, dtype=np.int32).reshape(-1)
+    out = {"workload": f"config4: {size[0]} x {size[1]} pairs, {n_kp} keypoints per frame, M = {n_kp} putative matches per pair, device-resident"}
+    for tag, n_pairs, rot, scale in (("rot_scale", 64, True, True), ("default_flags", 256, False, False)):
+        pairs = distmod.pair_table(n_frames, 0, n_pairs, n_kp)
+        d_pairs = torch.from_numpy(pairs.view(np.uint8).reshape(-1)).to(dev)
+        d_matches = distmod.synth_matches_device(0, n_pairs, n_kp, 0.5, dev)
+        d_out = torch.zeros((n_pairs * n_kp, 4), dtype=torch.int32, device=dev)
+        d_res = torch.zeros((n_pairs, 4), dtype=torch.int32, device=dev)
+        ctx.reserve(n_pairs, n_kp, rot, scale)
+        torch.cuda.synchronize()
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+        with torch.cuda.stream(stream):
+            for s in range(-2, steps):
+                if s >= 0:
+                    ev[s][0].record(stream)
+                ctx.filter_device(table.d_pts.data_ptr(), table.d_frame_off.data_ptr(), n_frames, d_pairs.data_ptr(), n_pairs, n_kp,
+                                  d_matches.data_ptr(), d_out.data_ptr(), d_res.data_ptr(), None, rot, scale, 6.0)
+                if s >= 0:
+                    ev[s][1].record(stream)
+        torch.cuda.synchronize()
+        ms = float(np.median([a.elapsed_time(b) for a, b in ev]))
+        res = d_res.cpu().numpy().view(pkg.RESULT_DTYPE).reshape(-1)
+        kept = float(res["n_inliers"].astype(np.int64).sum())
+        alg = 32.0 * n_kp * n_pairs + 16.0 * kept
+        bad = 0
+        for i in (0, n_pairs - 1):
+            sel = pairs[i:i + 1].copy()
+            sel["match_off"] = 0
+            m = d_matches[i * n_kp:(i + 1) * n_kp].cpu().numpy().view(np.uint8).reshape(-1).view(pkg.DMATCH_DTYPE)
+            failed, wout, wres, _ = oracle.batch(kp_all, table.frame_off_host, wh, sel, m, rot, scale, 6.0, 1)
+            k = int(wres["n_inliers"][0])
+            got = d_out[i * n_kp:i * n_kp + k].cpu().numpy().view(np.uint8).reshape(-1).view(pkg.DMATCH_DTYPE)
+            bad += 0 if (failed == 0 and res[i].tobytes() == wres[0].tobytes() and got.tobytes() == wout[:k].tobytes()) else 1
+        out[tag] = {"flags": [rot, scale, 6.0], "pairs_per_launch": n_pairs, "value": n_pairs / (ms * 1e-3), "unit": "pairs/s", "ms_per_launch": ms,
+                    "mean_kept_per_pair": kept / n_pairs,
+                    "roofline": {"bound": "hbm", "achieved": alg / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                 "frac": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "traffic": None,
+                                 "kernel": "all kernels of the launch (HIP events around gms_filter_device)",
+                                 "kernel_ms_per_launch": ms, "algorithmic_bytes_per_launch": alg},
+                    "parity": {"pairs_checked": 2, "mismatches": bad, "bit_exact": bad == 0}}
+    return out
 
 
 def poses_leg(ctx, pkg, stream, dev, n_frames=46, n_kp=10000, n_pairs=1024, steps=3):
@@ -496,13 +629,23 @@ def main():
                                  "(FeatureMatchUtil.cpp:69 flags), 8 rot x 5 scale x 4 grids",
                      "pairs_per_step": n_sub, "value": n_sub * 8 / w2, "unit": "pairs/s", "ms_per_step": k2,
                      "scale_probe": {"mask": probe_mask, "note": "bit s set = scale hypothesis s was bounded by a probe before being "
-                                     "evaluated in the timed launches (the library's own choice, gms_ctx_query; GMS_SCALE_PROBE=0|1 forces it)"},
+                                     "evaluated in the timed launches (the library's own choice, gms_ctx_query; gms_ctx_set_option / GMS_SCALE_PROBE force it)"},
                      "roofline": {"bound": "hbm", "achieved": alg2 / (k2 * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                                   "frac": alg2 / (k2 * 1e-3) / 1e9 / HBM_PEAK_GBPS, "traffic": None,
                                   "kernel": "all kernels of the launch (HIP events around gms_filter_device)",
                                   "kernel_ms_per_launch": k2, "algorithmic_bytes_per_launch": alg2},
                      "parity": {"pairs_checked": c2, "mismatches": b2, "bit_exact": b2 == 0}}
             ok = ok and b2 == 0
+            # the scale probe is the library's own choice (it pays when most probed scales cannot win): the same launches with it
+            # forced off and on, here and on a sequence whose true relative scale is sqrt 2 (the probed scale wins: the probe cannot help)
+            extra["by_probe"] = {}
+            for name, val in (("off", 0), ("on", 1)):
+                ctx.set_option(2, val)
+                wv, kv = timed_steps(ctx, wl, stream, 6, 2, True, True, None, n_pairs=n_sub)
+                extra["by_probe"][name] = {"pairs_per_s": n_sub * 6 / wv, "ms_per_step": kv}
+            ctx.set_option(2, -1)
+            extra["zoom_sqrt2"] = zoom_leg(ctx, pkg, stream, dev)
+            ok = ok and extra["zoom_sqrt2"]["parity"]["bit_exact"]
             if not args.no_cpu:
                 extra["cpu_baseline"] = cpu_baseline(args, wl, pkg, True, True, budget_s=12.0)
                 extra["gpu_vs_cpu"] = extra["value"] / extra["cpu_baseline"]["value"]
@@ -511,6 +654,8 @@ def main():
             # (what the reference feeds)
             line["descriptors_to_filtered_matches"] = {k: bf_gms_leg(ctx, wl, pkg, stream, k) for k in ("orb", "sift")}
             ok = ok and all(v["parity"]["bit_exact"] for v in line["descriptors_to_filtered_matches"].values())
+            line["config4"] = config4_leg(ctx, pkg, stream, dev)
+            ok = ok and all(line["config4"][t]["parity"]["bit_exact"] for t in ("rot_scale", "default_flags"))
             # f3: the consumer behind the filter, batched (SfMUtil.cpp:25-82)
             line["descriptors_to_poses"] = poses_leg(ctx, pkg, stream, dev)
             ok = ok and line["descriptors_to_poses"]["parity"]["ok"]

@@ -118,6 +118,11 @@ int  gms_ctx_reserve(gms_ctx* ctx, int n_pairs, int max_m, int with_rotation, in
 #define GMS_QUERY_LAUNCHES          4 /* filter launches of the context so far                                             */
 #define GMS_QUERY_CUS               5 /* compute units of the context's device                                             */
 int  gms_ctx_query(gms_ctx* ctx, int what, int64_t* value);
+/* Forces one of those choices for the context's later launches (value 0 / 1), or hands it back to the library (-1, the default).
+ * Speed only: every variant produces the same bytes. The environment switches GMS_DEAL / GMS_SCALE_PROBE do the same process-wide. */
+#define GMS_OPTION_DEAL         1
+#define GMS_OPTION_SCALE_PROBE  2
+int  gms_ctx_set_option(gms_ctx* ctx, int option, int value);
 
 /* ---- device-resident batch path (throughput API) ---------------------------------------------
  * All d_* pointers are device pointers on the context's device; calls are stream-ordered on the

@@ -68,6 +68,10 @@ class GmsContext:
     def synchronize(self):
         _check(self._lib.gms_ctx_synchronize(self._h), self._lib, "synchronize")
 
+    def set_option(self, option, value):
+        """gms_ctx_set_option: option 1 = deal the matches to the lanes, 2 = probe scale hypotheses; value -1 (library's choice), 0, 1."""
+        _check(self._lib.gms_ctx_set_option(self._h, int(option), int(value)), self._lib, "gms_ctx_set_option")
+
     def query(self, what):
         """gms_ctx_query: 1 = last launch dealt, 2 = its scale-probe mask, 3 = its matches per thread, 4 = launches, 5 = CUs."""
         v = C.c_int64(0)

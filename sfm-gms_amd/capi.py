@@ -7,7 +7,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # Every symbol include/gms.h declares; tests check the built library exports all of them.
 EXPORTED_SYMBOLS = [
     "gms_match", "gms_match_ctx", "gms_ctx_create", "gms_ctx_destroy", "gms_ctx_set_stream",
-    "gms_ctx_synchronize", "gms_ctx_reserve", "gms_ctx_query", "gms_frame_table_bytes", "gms_normalize_device", "gms_filter_device",
+    "gms_ctx_synchronize", "gms_ctx_reserve", "gms_ctx_query", "gms_ctx_set_option", "gms_frame_table_bytes", "gms_normalize_device", "gms_filter_device",
     "gms_filter_host_batch", "gms_bf_prepared_bytes", "gms_bf_prepare_device", "gms_bfmatch_device", "gms_disparity_device",
     "gms_gather_points_device", "gms_triangulate_device", "gms_recover_pose_device",
     "gms_gather_points_batch_device", "gms_find_essential_batch_device", "gms_recover_pose_batch_device", "gms_triangulate_batch_device",
@@ -49,6 +49,7 @@ def load_library():
     lib.gms_ctx_synchronize.argtypes = [vp]
     lib.gms_ctx_reserve.argtypes = [vp, i32, i32, i32, i32]
     lib.gms_ctx_query.argtypes = [vp, i32, C.POINTER(i64)]
+    lib.gms_ctx_set_option.argtypes = [vp, i32, i32]
     lib.gms_filter_host_batch.argtypes = [vp, vp, vp, vp, i32, vp, i32, vp, i32, i32, dbl, vp, vp]
     lib.gms_bf_prepared_bytes.argtypes = [i32, i64, i32]
     lib.gms_bf_prepare_device.argtypes = [vp, i32, vp, vp, i32, i64, vp]

@@ -172,6 +172,7 @@ struct gms_ctx {
     hipEvent_t verdict_event = nullptr;
     bool verdict_pending = false;
     unsigned filter_launches = 0;  // every launch of the context (pair-table validation every sixteenth)
+    int opt_deal = -1, opt_probe = -1;  // gms_ctx_set_option: -1 = the library's own choice (and the environment switches), 0 / 1 = forced
     // Scale hypotheses: the kernels can bound a scale's inlier count before evaluating it (gms_kernels.hip, PROBE) and skip the
     // scale when it cannot win -- a gain when at least half of the probes let a scale skip, a loss otherwise. The kernels count
     // both in probe_stats (device); every sixteenth launch with scale hypotheses probes whatever the verdict and is followed by a
@@ -300,7 +301,8 @@ int filter_launch(gms_ctx* c, hipStream_t st, const float* d_pts, const int64_t*
         c->use_probe = c->verdict[1] != 0u ? 1 : 0;
         c->verdict_pending = false;
     }
-    p.dealt = (p.dense && kpt && (knobs().deal >= 0 ? knobs().deal != 0 : c->use_dealt != 0)) ? 1 : 0;
+    const int force_deal = c->opt_deal >= 0 ? c->opt_deal : knobs().deal, force_probe = c->opt_probe >= 0 ? c->opt_probe : knobs().scale_probe;
+    p.dealt = (p.dense && kpt && (force_deal >= 0 ? force_deal != 0 : c->use_dealt != 0)) ? 1 : 0;
     // First-round stagger: the spread is about one pair's duration on the path the launch will mostly take -- 26 us (byte
     // matrix) / 72 us (hashed) at 10k matches, in proportion to max_m -- in ticks of the 100 MHz wall clock. Only launches of
     // at least four dispatch rounds are staggered, and none with scale hypotheses on the byte matrix: a pair takes ten times as
@@ -318,8 +320,8 @@ int filter_launch(gms_ctx* c, hipStream_t st, const float* d_pts, const int64_t*
     p.probe_stats = nullptr;
     if (kpt && with_scale) {
         // the scales finer than 20 x 20 and the 14 x 14 one are probed (2, 3, 4); the measuring launches are left out of stream captures
-        const bool measuring = knobs().scale_probe < 0 && !capturing && (c->scale_launches++ & 15u) == 0u;
-        const bool on = knobs().scale_probe >= 0 ? knobs().scale_probe != 0 : (measuring || c->use_probe != 0);
+        const bool measuring = force_probe < 0 && !capturing && (c->scale_launches++ & 15u) == 0u;
+        const bool on = force_probe >= 0 ? force_probe != 0 : (measuring || c->use_probe != 0);
         p.probe_scales = on ? 0x1D : 0;  // every scale but 1, which the byte-matrix kernel evaluates first
         p.probe_stats = measuring ? (uint32_t*)c->probe_stats.p : nullptr;
     }
@@ -554,6 +556,17 @@ int gms_ctx_synchronize(gms_ctx* c)
         c->verdict_pending = false;
     }
     return GMS_OK;
+}
+
+int gms_ctx_set_option(gms_ctx* c, int option, int value)
+{
+    if (!c || value < -1 || value > 1) return GMS_ERR_BAD_ARG;
+    std::lock_guard<std::mutex> lock(c->mu);
+    switch (option) {
+    case GMS_OPTION_DEAL: c->opt_deal = value; return GMS_OK;
+    case GMS_OPTION_SCALE_PROBE: c->opt_probe = value; return GMS_OK;
+    default: return GMS_ERR_BAD_ARG;
+    }
 }
 
 int gms_ctx_query(gms_ctx* c, int what, int64_t* value)

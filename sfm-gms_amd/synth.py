@@ -208,3 +208,21 @@ def make_multi_view_scene(case_id, n_frames, size=(1920, 1080), n_kp=10000, came
     X = X[:n_kp]
     frames = [make_keypoints((project(X @ R.T + t) + rng.normal(0, noise_px, (n_kp, 2))).astype(np.float32)) for R, t in zip(Rs, ts)]
     return dict(frames=frames, sizes=[size] * n_frames, camera=camera, dist=dist, R=np.array(Rs), t=np.array(ts), X=X)
+
+
+def make_zoom_sequence(case_id, n_frames, size=(1920, 1080), n_kp=10000, zoom=2.0 ** 0.5, noise_px=1.5):
+    """A sequence whose odd frames see the scene of the even frames magnified by `zoom` about the image centre (a camera that zooms
+    between shots): a pair (even frame, odd frame) has true relative scale `zoom`, so with scale hypotheses the reference's winner is
+    the matching right grid (sqrt 2 -> 28 x 28), not the unscaled one. Keypoint i of every frame shows scene point i."""
+    rng = rng_for(case_id ^ 0x51A7)
+    w, h = size
+    half_w, half_h = 0.5 * w / zoom * 0.95, 0.5 * h / zoom * 0.95
+    base = np.stack([rng.uniform(-half_w, half_w, n_kp), rng.uniform(-half_h, half_h, n_kp)], axis=1)
+    frames = []
+    for f in range(n_frames):
+        s = zoom if f & 1 else 1.0
+        xy = base * s + np.array([w / 2.0, h / 2.0]) + rng.normal(0, noise_px, (n_kp, 2)) + np.array([0.3 * f, -0.2 * f])
+        xy[:, 0] = np.clip(xy[:, 0], 0, w - 1.001)
+        xy[:, 1] = np.clip(xy[:, 1], 0, h - 1.001)
+        frames.append(make_keypoints(xy.astype(np.float32)))
+    return frames

@@ -368,3 +368,39 @@ def test_overlapping_match_ranges_are_flagged(pkg, oracle, synth):
             assert (res["status"] == 0).all()
             out2, res2 = ctx.filter_host_batch(frames, [size] * len(frames), fixed, matches, False, False, 6.0)
             assert res2.tobytes() == res.tobytes()
+
+
+# ---- gms_ctx_set_option / gms_ctx_query: the library's bit-identical variants, forced ---------------------------------------------------
+def test_forced_variants_give_the_same_bytes(pkg, oracle, synth):
+    """gms_ctx_set_option forces the lane mapping of the byte-matrix kernel (option 1) and the scale probe (option 2); gms_ctx_query reports
+    what the last launch ran with. On a zooming sequence (true relative scale sqrt 2: the 28 x 28 hypothesis wins, the probe cannot bound
+    it out) and with the default flags: every variant returns the oracle's bytes."""
+    batch = importlib.import_module("sfm-gms_amd.batch")
+    size, n_kp = (1920, 1080), 6000
+    frames = synth.make_zoom_sequence(5, 6, size=size, n_kp=n_kp)
+    pairs = np.zeros(6, dtype=pkg.PAIR_DTYPE)
+    ms = []
+    for i, (a, b) in enumerate(((0, 1), (2, 3), (4, 5), (0, 3), (2, 5), (0, 2))):
+        mt = synth.sequence_matches(900 + i, n_kp, n_kp, 0.5)
+        pairs[i] = (a, b, n_kp, 0, i * n_kp)
+        ms.append(mt)
+    matches = np.concatenate(ms)
+    with pkg.GmsContext(0) as ctx:
+        table = batch.FrameTable(ctx, frames, [size] * len(frames))
+        failed, wout, wres, _ = _oracle_batch(oracle, frames, [size] * len(frames), table.frame_off_host, pairs, matches, True, True)
+        assert failed == 0 and (wres["best_scale"][:5] == 3).all() and wres["best_scale"][5] in (0, 1)   # sqrt 2 between an even and an odd frame
+        for val in (0, 1, -1):
+            ctx.set_option(2, val)
+            out, res, _ = batch.filter_pairs(ctx, table, pairs, matches, True, True, 6.0, want_mask=False)
+            _same(pairs, out, res, wout, wres)
+            if val >= 0:
+                assert (ctx.query(2) != 0) == bool(val)
+        failed, wout, wres, _ = _oracle_batch(oracle, frames, [size] * len(frames), table.frame_off_host, pairs, matches, False, False)
+        for val in (0, 1, -1):
+            ctx.set_option(1, val)
+            out, res, _ = batch.filter_pairs(ctx, table, pairs, matches, False, False, 6.0, want_mask=False)
+            _same(pairs, out, res, wout, wres)
+            if val >= 0:
+                assert ctx.query(1) == val and ctx.query(3) == 10
+        with pytest.raises(pkg.GmsError):
+            ctx.set_option(7, 1)
