@@ -184,18 +184,7 @@ pose_votes_kernel(PoseModel pm, const float2* __restrict__ coords1, const float2
     if (i < n && (in_mask == nullptr || in_mask[i] != 0)) {
         const double x1 = ((double)coords1[i].x - pm.cx) / pm.fx, y1 = ((double)coords1[i].y - pm.cy) / pm.fy;
         const double x2 = ((double)coords2[i].x - pm.cx) / pm.fx, y2 = ((double)coords2[i].y - pm.cy) / pm.fy;
-        const double P0[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
-        for (int h = 0; h < 4; ++h) {
-            const double* P = pm.P[h];
-            double Q[4];
-            tv::dlt_point(P0, P, x1, y1, x2, y2, Q);
-            bool ok = Q[2] * Q[3] > 0.0;
-            const double qx = Q[0] / Q[3], qy = Q[1] / Q[3], qz = Q[2] / Q[3];
-            ok = ok && qz < pm.dist_thresh;
-            const double z2 = P[8] * qx + P[9] * qy + P[10] * qz + P[11];
-            ok = ok && z2 > 0.0 && z2 < pm.dist_thresh;
-            bits |= ok ? 1u << h : 0u;
-        }
+        bits = tv::pose_votes(pm.P, pm.dist_thresh, x1, y1, x2, y2);
     }
     if (i < n) votes[i] = (uint8_t)bits;
 #pragma unroll

@@ -18,8 +18,10 @@
 
 #if defined(__HIPCC__)
 #define GMS_HD __host__ __device__ __forceinline__
+#define GMS_UNROLL _Pragma("unroll")
 #else
 #define GMS_HD inline
+#define GMS_UNROLL
 #endif
 
 namespace gms {
@@ -205,8 +207,11 @@ GMS_HD void constraint_matrix(const Mem& basis, Mem& A, Mem& eet /* [60] */)
         const int minors[3][5] = {{0, 4, 8, 5, 7}, {1, 3, 8, 5, 6}, {2, 3, 7, 4, 6}};  // entry, then (p q - r s) as flat indices of E
         for (int t = 0; t < 3; ++t) {
             double quad[10];
+GMS_UNROLL
             for (int i = 0; i < 10; ++i) quad[i] = 0.0;
+GMS_UNROLL
             for (int a = 0; a < 4; ++a)
+GMS_UNROLL
                 for (int b = 0; b < 4; ++b) {
                     const double v = basis(a * 9 + minors[t][1]) * basis(b * 9 + minors[t][2]) - basis(a * 9 + minors[t][3]) * basis(b * 9 + minors[t][4]);
                     // lin_lin with run-time a, b: the table is symmetric and tiny
@@ -214,7 +219,9 @@ GMS_HD void constraint_matrix(const Mem& basis, Mem& A, Mem& eet /* [60] */)
                     quad[qi] += v;
                 }
             const double sg = t == 1 ? -1.0 : 1.0;
+GMS_UNROLL
             for (int qi = 0; qi < 10; ++qi)
+GMS_UNROLL
                 for (int l = 0; l < 4; ++l) A(quad_lin(qi, l)) += sg * quad[qi] * basis(l * 9 + minors[t][0]);
         }
     }
@@ -296,15 +303,15 @@ GMS_HD void reduced_system(const Mem& A, Mem& B)
 }
 
 // det B(z) as a polynomial of degree <= 10, coefficients lowest power first in c[0..10].
-template <class Mem>
-GMS_HD void determinant_poly(const Mem& B, double c[11])
+template <class Mem, class MemC>
+GMS_HD void determinant_poly(const Mem& B, MemC& c)
 {
     // entry (i, j) has degree deg_j = {3, 3, 4}; p(i, j, k) = coefficient of z^k
     auto p = [&](int i, int j, int k) -> double {
         const int deg = j == 2 ? 4 : 3;
         return (k < 0 || k > deg) ? 0.0 : B(i * 13 + 4 * j + (deg - k));
     };
-    for (int k = 0; k <= 10; ++k) c[k] = 0.0;
+    for (int k = 0; k <= 10; ++k) c(k) = 0.0;
     const int perm[6][3] = {{0, 1, 2}, {1, 2, 0}, {2, 0, 1}, {0, 2, 1}, {1, 0, 2}, {2, 1, 0}};  // column of rows 0, 1, 2
     for (int t = 0; t < 6; ++t) {
         const double sg = t < 3 ? 1.0 : -1.0;
@@ -315,49 +322,51 @@ GMS_HD void determinant_poly(const Mem& B, double c[11])
             if (pa == 0.0) continue;
             for (int b = 0; b <= d1; ++b) {
                 const double pab = pa * p(1, j1, b);
-                for (int e = 0; e <= d2; ++e) c[a + b + e] += pab * p(2, j2, e);
+                for (int e = 0; e <= d2; ++e) c(a + b + e) += pab * p(2, j2, e);
             }
         }
     }
 }
 
-// All roots of a real polynomial of degree n <= 10 (c lowest power first, c[n] != 0) by Aberth's simultaneous iteration in complex
-// fp64; re / im receive n roots. Real roots are polished by Newton afterwards (caller). Returns the iterations used.
-GMS_HD int aberth_roots(const double* c, int n, double* re, double* im)
+// All roots of a real polynomial of degree n <= 10 (c lowest power first, c(n) != 0) by Aberth's simultaneous iteration in complex
+// fp64; re / im receive n roots. Real roots are polished by Newton afterwards (caller). The arrays are indexed at run time: they
+// live behind accessors (LDS on the device: a lane's private arrays would sit in scratch memory, a round trip per access).
+template <class MemC, class MemR>
+GMS_HD int aberth_roots(const MemC& c, int n, MemR& re, MemR& im)
 {
-    const double an = c[n];
+    const double an = c(n);
     // Fujiwara's bound on the root moduli
     double radius = 0.0;
     for (int k = 1; k <= n; ++k) {
-        const double q = fabs(c[n - k] / an) * (k == n ? 0.5 : 1.0);
+        const double q = fabs(c(n - k) / an) * (k == n ? 0.5 : 1.0);
         if (q > 0.0) radius = fmax(radius, pow(q, 1.0 / k));
     }
     radius = 2.0 * radius;
     if (!(radius > 0.0)) radius = 1.0;
-    const double centre = -c[n - 1] / (an * n);
+    const double centre = -c(n - 1) / (an * n);
     for (int k = 0; k < n; ++k) {
         const double ang = 6.283185307179586 * k / n + 0.4;
-        re[k] = centre + 0.5 * radius * cos(ang);
-        im[k] = 0.5 * radius * sin(ang);
+        re(k) = centre + 0.5 * radius * cos(ang);
+        im(k) = 0.5 * radius * sin(ang);
     }
     int it = 0;
-    for (; it < 100; ++it) {
+    for (; it < 48; ++it) {  // (cubic convergence: a dozen iterations as a rule; the roots that matter are polished afterwards)
         double worst = 0.0;
         for (int i = 0; i < n; ++i) {
-            const double zr = re[i], zi = im[i];
+            const double zr = re(i), zi = im(i);
             // p(z), p'(z) by Horner
             double pr = an, pi = 0.0, dr = 0.0, di = 0.0;
             for (int k = n - 1; k >= 0; --k) {
                 const double ndr = dr * zr - di * zi + pr, ndi = dr * zi + di * zr + pi;
                 dr = ndr;
                 di = ndi;
-                const double npr = pr * zr - pi * zi + c[k], npi = pr * zi + pi * zr;
+                const double npr = pr * zr - pi * zi + c(k), npi = pr * zi + pi * zr;
                 pr = npr;
                 pi = npi;
             }
             const double dd = dr * dr + di * di;
             if (dd == 0.0) {  // on a critical point: nudge
-                re[i] = zr + 1e-8 * (1.0 + fabs(zr));
+                re(i) = zr + 1e-8 * (1.0 + fabs(zr));
                 worst = 1.0;
                 continue;
             }
@@ -367,7 +376,7 @@ GMS_HD int aberth_roots(const double* c, int n, double* re, double* im)
             double sr = 0.0, si = 0.0;
             for (int j = 0; j < n; ++j) {
                 if (j == i) continue;
-                const double er = zr - re[j], ei = zi - im[j];
+                const double er = zr - re(j), ei = zi - im(j);
                 const double ee = er * er + ei * ei;
                 if (ee == 0.0) continue;
                 sr += er / ee;
@@ -381,12 +390,12 @@ GMS_HD int aberth_roots(const double* c, int n, double* re, double* im)
                 stepr = (wr * qr + wi * qi) / qq;
                 stepi = (wi * qr - wr * qi) / qq;
             }
-            re[i] = zr - stepr;
-            im[i] = zi - stepi;
+            re(i) = zr - stepr;
+            im(i) = zi - stepi;
             const double rel = sqrt(stepr * stepr + stepi * stepi) / fmax(1.0, sqrt(zr * zr + zi * zi));
             worst = fmax(worst, rel);
         }
-        if (worst < 1e-15) break;
+        if (worst < 1e-12) break;
     }
     return it;
 }
@@ -503,45 +512,49 @@ GMS_HD int five_point(const double x1[5], const double y1[5], const double x2[5]
     constraint_matrix(m.basis, m.A, m.work);
     if (!eliminate_10x20(m.A)) return 0;
     reduced_system(m.A, m.work);  // B = work[0..38]
-    double c[11];
+    // the constraint matrix has done its work: its storage now holds the run-time indexed arrays of the root finder
+    struct Sub {
+        Mem* base;
+        int off;
+        GMS_HD double& operator()(int i) const { return (*base)(off + i); }
+    };
+    Sub c{&m.A, 0}, re{&m.A, 16}, im{&m.A, 32}, zs{&m.A, 48};
     determinant_poly(m.work, c);
     double cmax = 0.0;
     bool finite = true;
     for (int k = 0; k <= 10; ++k) {
-        finite = finite && isfinite(c[k]);
-        cmax = fmax(cmax, fabs(c[k]));
+        finite = finite && isfinite(c(k));
+        cmax = fmax(cmax, fabs(c(k)));
     }
     if (!finite || cmax == 0.0) return 0;
     int n = 10;
-    while (n > 0 && c[n] == 0.0) --n;
+    while (n > 0 && c(n) == 0.0) --n;
     if (n == 0) return 0;
-    double re[10], im[10];
     aberth_roots(c, n, re, im);
     // the real roots (|imag| < 1e-10), polished by two Newton steps on the real polynomial
-    double zs[10];
     int nz = 0;
     for (int i = 0; i < n; ++i) {
-        if (!(fabs(im[i]) < 1e-10) || !isfinite(re[i])) continue;
-        double z = re[i];
+        if (!(fabs(im(i)) < 1e-10) || !isfinite(re(i))) continue;
+        double z = re(i);
         for (int s = 0; s < 2; ++s) {
-            double pv = c[n], dv = 0.0;
+            double pv = c(n), dv = 0.0;
             for (int k = n - 1; k >= 0; --k) {
                 dv = dv * z + pv;
-                pv = pv * z + c[k];
+                pv = pv * z + c(k);
             }
             if (dv != 0.0 && isfinite(pv / dv)) z -= pv / dv;
         }
         int pos = nz;
-        while (pos > 0 && zs[pos - 1] > z) {
-            zs[pos] = zs[pos - 1];
+        while (pos > 0 && zs(pos - 1) > z) {
+            zs(pos) = zs(pos - 1);
             --pos;
         }
-        zs[pos] = z;
+        zs(pos) = z;
         ++nz;
     }
     int count = 0;
     for (int i = 0; i < nz; ++i) {
-        const double z = zs[i];
+        const double z = zs(i);
         // B(z): 3 x 3; its null vector (x, y, 1) up to scale = the largest of the three row cross products
         double bz[3][3];
         for (int r = 0; r < 3; ++r) {
@@ -726,11 +739,13 @@ GMS_HD void dlt_point(const double* Pa, const double* Pb, double x1, double y1, 
             S[a][b] = A[0][a] * A[0][b] + A[1][a] * A[1][b] + A[2][a] * A[2][b] + A[3][a] * A[3][b];
             V[a][b] = a == b ? 1.0 : 0.0;
         }
+    // sweeps until the off-diagonal mass is below rounding relative to the diagonal (it falls quadratically: five or six sweeps)
+    const double tr0 = S[0][0] + S[1][1] + S[2][2] + S[3][3];
     for (int sweep = 0; sweep < 12; ++sweep) {
         double off = 0.0;
         for (int a = 0; a < 4; ++a)
             for (int b = a + 1; b < 4; ++b) off += S[a][b] * S[a][b];
-        if (off < 1e-300) break;
+        if (off <= 1e-36 * tr0 * tr0) break;
         for (int p = 0; p < 3; ++p)
             for (int q = p + 1; q < 4; ++q) {
                 if (S[p][q] == 0.0) continue;
@@ -757,6 +772,38 @@ GMS_HD void dlt_point(const double* Pa, const double* Pb, double x1, double y1, 
     int best = 0;
     for (int k = 1; k < 4; ++k) best = S[k][k] < S[best][best] ? k : best;
     for (int k = 0; k < 4; ++k) X[k] = best == 0 ? V[k][0] : best == 1 ? V[k][1] : best == 2 ? V[k][2] : V[k][3];
+}
+
+// cv::recoverPose's cheirality test of one correspondence under the four candidate poses (R1, t), (R2, t), (R1, -t), (R2, -t): bit h set
+// = positive depth below the threshold in both cameras. P[h] = [R | t] row-major 3 x 4, P[h + 2] = [R | -t]. The DLT matrix of (R, -t)
+// is that of (R, t) with its last column negated, so its null vector is (X, -w): two decompositions serve four hypotheses.
+GMS_HD unsigned pose_votes(const double P[4][12], double dist_thresh, double x1, double y1, double x2, double y2)
+{
+    const double P0[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+    unsigned bits = 0;
+    for (int h = 0; h < 2; ++h) {
+        double Q[4];
+        dlt_point(P0, P[h], x1, y1, x2, y2, Q);
+        const double qx = Q[0] / Q[3], qy = Q[1] / Q[3], qz = Q[2] / Q[3];
+        const double z2 = P[h][8] * qx + P[h][9] * qy + P[h][10] * qz + P[h][11];
+        // (R, t): Q as it stands
+        if (Q[2] * Q[3] > 0.0 && qz < dist_thresh && z2 > 0.0 && z2 < dist_thresh) bits |= 1u << h;
+        // (R, -t): (X, -w) -- the point mirrored through the first camera, the second depth negated
+        if (-(Q[2] * Q[3]) > 0.0 && -qz < dist_thresh && -z2 > 0.0 && -z2 < dist_thresh) bits |= 1u << (h + 2);
+    }
+    return bits;
+}
+
+// the same test for ONE hypothesis (the winner, when the mask is written)
+GMS_HD bool pose_vote_one(const double P[4][12], int h, double dist_thresh, double x1, double y1, double x2, double y2)
+{
+    const double P0[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+    double Q[4];
+    dlt_point(P0, P[h & 1], x1, y1, x2, y2, Q);
+    const double sg = h < 2 ? 1.0 : -1.0;
+    const double qz = sg * (Q[2] / Q[3]);
+    const double z2 = sg * (P[h & 1][8] * (Q[0] / Q[3]) + P[h & 1][9] * (Q[1] / Q[3]) + P[h & 1][10] * (Q[2] / Q[3]) + P[h & 1][11]);
+    return sg * (Q[2] * Q[3]) > 0.0 && qz < dist_thresh && z2 > 0.0 && z2 < dist_thresh;
 }
 
 }  // namespace tv

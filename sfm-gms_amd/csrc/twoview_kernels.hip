@@ -291,24 +291,13 @@ recover_pose_batch_kernel(double fx, double fy, double cx, double cy, double dis
     }
     __syncthreads();
     const bool ok = s_ok != 0;
-    const double P0[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
-    // one hypothesis on one correspondence: positive depth below the threshold in both cameras
-    auto passes = [&](int h, double x1, double y1, double x2, double y2) -> bool {
-        double Q[4];
-        tv::dlt_point(P0, s_P[h], x1, y1, x2, y2, Q);
-        bool good = Q[2] * Q[3] > 0.0;
-        const double qx = Q[0] / Q[3], qy = Q[1] / Q[3], qz = Q[2] / Q[3];
-        good = good && qz < dist_thresh;
-        const double z2 = s_P[h][8] * qx + s_P[h][9] * qy + s_P[h][10] * qz + s_P[h][11];
-        return good && z2 > 0.0 && z2 < dist_thresh;
-    };
     for (int base = 0; base < n && ok; base += kTvThreads) {
         const int i = base + tid;
         unsigned bits = 0;
         if (i < n && (!use_in_mask || mk[i] != 0)) {
             const double x1 = ((double)c1[i].x - cx) / fx, y1 = ((double)c1[i].y - cy) / fy;
             const double x2 = ((double)c2[i].x - cx) / fx, y2 = ((double)c2[i].y - cy) / fy;
-            for (int h = 0; h < 4; ++h) bits |= passes(h, x1, y1, x2, y2) ? 1u << h : 0u;
+            bits = tv::pose_votes(s_P, dist_thresh, x1, y1, x2, y2);
         }
         for (int h = 0; h < 4; ++h) {
             const unsigned long long b = __ballot((bits >> h) & 1u);
@@ -343,7 +332,7 @@ recover_pose_batch_kernel(double fx, double fy, double cx, double cy, double dis
         if (ok && in != 0) {
             const double x1 = ((double)c1[i].x - cx) / fx, y1 = ((double)c1[i].y - cy) / fy;
             const double x2 = ((double)c2[i].x - cx) / fx, y2 = ((double)c2[i].y - cy) / fy;
-            out = passes(w, x1, y1, x2, y2) ? in : (uint8_t)0;
+            out = tv::pose_vote_one(s_P, w, dist_thresh, x1, y1, x2, y2) ? in : (uint8_t)0;
         }
         mk[i] = out;
     }
