@@ -51,7 +51,7 @@ namespace {
 // Diagnostic switches, read from the environment ONCE per process (never on the call path):
 //   GMS_DENSE=0          keep every pair on the hashed path
 //   GMS_BAND=0           keep large pairs on the HBM-slab kernel alone
-//   GMS_STREAM=0         rotation / scale hypotheses on pairs of 16 385 .. 65 536 matches: the tile kernels instead of the streamed byte-matrix kernels
+//   GMS_STREAM=0         pairs of 16 385 .. 65 536 matches: the 16-bit band / tile kernels instead of the streamed byte-matrix kernels
 //   GMS_STAGGER_US=n     spread of the first dispatch round's start times at 10k matches per pair (0 = off)
 //   GMS_BAND_WS_BYTES=n  budget of the large-pair workspace (default 4 GiB); a batch is filtered in slices that fit it
 //   GMS_DEAL=0|1         never / always deal the matches to the lanes of the byte-matrix kernel (default: what the probe saw)
@@ -172,6 +172,10 @@ struct gms_ctx {
     hipEvent_t verdict_event = nullptr;
     bool verdict_pending = false;
     unsigned filter_launches = 0;  // every launch of the context (pair-table validation every sixteenth)
+    // verdict[2] counts the pairs the streamed byte-matrix kernels had to hand on (an entry above 255, a cell above 65 535): when it has
+    // moved since the last look, the next 64 launches of large pairs take the 16-bit band / tile kernels instead, then the streamed ones get another try
+    uint32_t overflow_seen = 0;
+    int stream_penalty = 0;
     int opt_deal = -1, opt_probe = -1;  // gms_ctx_set_option: -1 = the library's own choice (and the environment switches), 0 / 1 = forced
     // Scale hypotheses: the kernels can bound a scale's inlier count before evaluating it (gms_kernels.hip, PROBE) and skip the
     // scale when it cannot win -- a gain when at least half of the probes let a scale skip, a loss otherwise. The kernels count
@@ -190,7 +194,7 @@ struct gms_ctx {
 
 namespace {
 
-int plan_workspace(const gms_ctx* c, int n_pairs, int max_m, bool rot, bool scale, bool need_mask_ws, WsNeed* w)
+int plan_workspace(const gms_ctx* c, int n_pairs, int max_m, bool rot, bool scale, bool need_mask_ws, bool allow_stream, WsNeed* w)
 {
     *w = WsNeed();
     w->kpt = gms::filter_pick_kpt(max_m);  // 0: too large for the register + LDS kernel
@@ -207,11 +211,10 @@ int plan_workspace(const gms_ctx* c, int n_pairs, int max_m, bool rot, bool scal
         p.with_rotation = rot;
         p.with_scale = scale;
         right_grids(p.right_w, p.right_h);
-        // rotation and / or scale hypotheses on pairs up to 65 536 matches: the streamed byte-matrix kernels (2.6x the tile kernels at
-        // 50k matches with both, 1.3x with rotation alone); the default flags stay on the three-band kernels (register-resident lists:
-        // 566k against 513k pairs/s at 50k matches) -- measured with tools/config4_bench.py
-        w->stream = knobs().stream_on && max_m <= gms::stream_max_matches() && (rot || scale);
-        w->per_pair = w->stream ? gms::stream_ws_bytes_per_pair(p, w->mcap, need_mask_ws)
+        // pairs up to 65 536 matches: the streamed byte-matrix kernels -- one workgroup per (pair, scale, grid type, band) with scale
+        // hypotheses, one per pair without (tools/config4_bench.py has both against the 16-bit band / tile kernels)
+        w->stream = knobs().stream_on && max_m <= gms::stream_max_matches() && allow_stream;
+        w->per_pair = w->stream ? std::max(gms::stream_ws_bytes_per_pair(p, w->mcap, need_mask_ws), scale ? (size_t)0 : gms::stream_dense_ws_bytes_per_pair(w->mcap))
                                 : (!rot && !scale) ? gms::band_ws_bytes_per_pair(w->mcap, need_mask_ws)
                                                    : gms::tile_ws_bytes_per_pair(p, w->mcap, need_mask_ws);
         size_t slice = knobs().band_ws_budget / w->per_pair;
@@ -264,12 +267,23 @@ int filter_launch(gms_ctx* c, hipStream_t st, const float* d_pts, const int64_t*
     if (n_pairs == 0) return GMS_OK;
     if (!d_frame_off || !d_pairs || !d_results) return GMS_ERR_BAD_ARG;
     if (max_m > 0 && (!d_matches || !d_out || !d_pts)) return GMS_ERR_BAD_ARG;
-    WsNeed w;
-    GMS_TRY(plan_workspace(c, n_pairs, max_m, with_rotation != 0, with_scale != 0, d_mask == nullptr, &w));
-    GMS_TRY(grow_workspace(c, w, st));
-    const bool uses_ws = w.partial || w.big || w.band;
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     const bool capturing = hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone;
+    if (gms::filter_pick_kpt(max_m) == 0 && !capturing) {
+        // large pairs: the streamed kernels' report of pairs they could not keep (read without waiting: it only steers which of two
+        // bit-identical paths runs)
+        const uint32_t now = ((volatile uint32_t*)c->verdict)[2];
+        if (now != c->overflow_seen) {
+            c->overflow_seen = now;
+            c->stream_penalty = 64;
+        } else if (c->stream_penalty > 0) {
+            --c->stream_penalty;
+        }
+    }
+    WsNeed w;
+    GMS_TRY(plan_workspace(c, n_pairs, max_m, with_rotation != 0, with_scale != 0, d_mask == nullptr, c->stream_penalty == 0, &w));
+    GMS_TRY(grow_workspace(c, w, st));
+    const bool uses_ws = w.partial || w.big || w.band;
     if (uses_ws && !capturing && c->ws_pending && c->ws_stream != st) GMS_HIP(hipStreamWaitEvent(st, c->ws_event, 0));
 
     gms::FilterParams p{};
@@ -318,6 +332,10 @@ int filter_launch(gms_ctx* c, hipStream_t st, const float* d_pts, const int64_t*
 #endif
     p.probe_scales = 0;
     p.probe_stats = nullptr;
+    {
+        void* dflag = nullptr;
+        p.overflow_events = hipHostGetDevicePointer(&dflag, c->verdict, 0) == hipSuccess ? (uint32_t*)dflag + 2 : nullptr;
+    }
     if (kpt && with_scale) {
         // the scales finer than 20 x 20 and the 14 x 14 one are probed (2, 3, 4); the measuring launches are left out of stream captures
         const bool measuring = force_probe < 0 && !capturing && (c->scale_launches++ & 15u) == 0u;
@@ -358,7 +376,10 @@ int filter_launch(gms_ctx* c, hipStream_t st, const float* d_pts, const int64_t*
             ps.results = d_results + s0;
             ps.n_pairs = (n_pairs - s0 < (int)w.slice) ? n_pairs - s0 : (int)w.slice;
             const uint32_t* flags = nullptr;
-            if (w.stream) GMS_HIP(gms::launch_filter_stream(ps, w.mcap, c->band_ws.p, &flags, st));
+            // streamed byte matrix: one workgroup per (pair, scale, grid type, band) with scale hypotheses -- and without them when the
+            // slice has fewer pairs than the chip has CUs (four workgroups per pair then) --, else one workgroup per pair
+            if (w.stream && (with_scale || ps.n_pairs < c->n_cus)) GMS_HIP(gms::launch_filter_stream(ps, w.mcap, c->band_ws.p, &flags, st));
+            else if (w.stream) GMS_HIP(gms::launch_filter_stream_dense(ps, w.mcap, c->band_ws.p, &flags, st));
             else if (plain) GMS_HIP(gms::launch_filter_band(ps, w.mcap, c->band_ws.p, &flags, st));
             else GMS_HIP(gms::launch_filter_tiles(ps, w.mcap, c->band_ws.p, &flags, st));
             ps.pair_flags = flags;
@@ -483,6 +504,7 @@ int gms_ctx_create(int device, gms_ctx** out_ctx)
     if (e == hipSuccess) {
         c->verdict[0] = 0;
         c->verdict[1] = 1;
+        c->verdict[2] = 0;
     }
     if (e == hipSuccess) e = c->probe_stats.reserve(64);
     if (e == hipSuccess) e = hipMemset(c->probe_stats.p, 0, 64);
@@ -588,11 +610,14 @@ int gms_ctx_reserve(gms_ctx* c, int n_pairs, int max_m, int with_rotation, int w
     if (!c || n_pairs < 0 || max_m < 0) return GMS_ERR_BAD_ARG;
     std::lock_guard<std::mutex> lock(c->mu);
     GMS_HIP(hipSetDevice(c->device));
-    WsNeed w, w2;
-    // with and without a caller-provided mask array: the larger of the two
-    GMS_TRY(plan_workspace(c, n_pairs, max_m, with_rotation != 0, with_scale != 0, true, &w));
-    GMS_TRY(plan_workspace(c, n_pairs, max_m, with_rotation != 0, with_scale != 0, false, &w2));
-    w.band = std::max(w.band, w2.band);
+    WsNeed w;
+    // with and without a caller-provided mask array, on the streamed and on the band / tile kernels (the library picks per launch): the largest
+    GMS_TRY(plan_workspace(c, n_pairs, max_m, with_rotation != 0, with_scale != 0, true, true, &w));
+    for (int variant = 1; variant < 4; ++variant) {
+        WsNeed w2;
+        GMS_TRY(plan_workspace(c, n_pairs, max_m, with_rotation != 0, with_scale != 0, (variant & 1) == 0, (variant & 2) == 0, &w2));
+        w.band = std::max(w.band, w2.band);
+    }
     GMS_TRY(grow_workspace(c, w, c->stream));
     return grow_pose_ws(c, (size_t)max_m + 48, c->stream);  // gms_recover_pose_device on a pair of this size
 }
@@ -795,7 +820,10 @@ int gms_filter_host_batch(gms_ctx* c, const gms_keypoint* kp, const int64_t* fra
     }
     {   // the workspaces for the largest chunk, once, so that no launch below has to grow them mid-pipeline
         WsNeed w;
-        GMS_TRY(plan_workspace(c, (int)cap_p, max_m, with_rotation != 0, with_scale != 0, true, &w));
+        GMS_TRY(plan_workspace(c, (int)cap_p, max_m, with_rotation != 0, with_scale != 0, true, true, &w));
+        WsNeed w2;
+        GMS_TRY(plan_workspace(c, (int)cap_p, max_m, with_rotation != 0, with_scale != 0, true, false, &w2));
+        w.band = std::max(w.band, w2.band);
         GMS_TRY(grow_workspace(c, w, c->lane[0].stream));
     }
 

@@ -31,6 +31,7 @@
 #include "gms_device_common.h"
 
 namespace gms {
+static size_t align16s(size_t x) { return (x + 15) & ~(size_t)15; }
 namespace {
 
 constexpr int kSMaxMatches = 1 << 16;                      // (an entry holds 26 bits of original index; beyond 65 536 matches the 16-bit band / tile kernels are the better fit: entries above 255 get likely)
@@ -300,7 +301,9 @@ __device__ __forceinline__ void stream_scale(const FilterParams& p, const Stream
             }
             __syncthreads();
             if (misc[8] != 0u) {  // a (left cell, right cell) pair above 255 matches (workgroup-uniform): the general kernel's pair
-                if (tid == 0) atomicOr(&w.flags[pi], kSFlagGeneral);
+                if (tid == 0) {
+                    if (!(atomicOr(&w.flags[pi], kSFlagGeneral) & kSFlagGeneral) && p.overflow_events) atomicAdd(p.overflow_events, 1u);
+                }
                 return;
             }
             // ---- verifyCellPairs for the own cells (dense_scales_pair's: two lanes per cell without rotation, four lanes per cell and
@@ -507,10 +510,364 @@ stream_select_kernel(FilterParams p, StreamWs w, int mcap, int n_scales)
         bm[i] = bs >= 0 ? ((rb[i] | rb[(size_t)mcap + i] | rb[2 * (size_t)mcap + i] | rb[3 * (size_t)mcap + i]) >> br) & 1u : 0u;
 }
 
+// ================================================================================================================================
+// No scale hypotheses (the default flags of DisparityUtil.cpp:149,299, or rotation alone): ONE workgroup per pair, dense_pair() of
+// gms_kernels.hip with the per-match code words in an L2-resident scratch array instead of registers -- the 400 x 400 byte matrix
+// fills the LDS, zeroed once per pair (every match takes its own increment back after each grid type), the row headers carry the
+// running arg-max under a grid-type tag. What is different at this size:
+//   * nLeft is 16 bits per cell, from a 32-bit half-cell histogram that lives in the matrix area before the matrix does;
+//   * an entry that would pass 255 (the increment that wraps its byte notices) or a cell above 65 535 matches sends the pair to the
+//     HBM-slab kernel before anything is written out, and is reported (p.overflow_events): a context that keeps meeting such pairs
+//     goes back to the 16-bit band kernels for a while (gms_capi.cpp);
+//   * a match's rotation bits ride in its code word (read-modify-write by the one thread that owns index i = tid + 1024 k);
+//   * copy-out: three sweeps over the code words (counts per rotation, survivors per 64-match chunk + scan, records).
+// code word: [qx | qy | never | edgeX | edgeY | E(r) : 9 | left cell under grid type 1 : 9 | inlier-under-rotation bits : 8]
+// ================================================================================================================================
+namespace {
+constexpr int kDEShiftS = 5, kDCellShiftS = 14, kDAccShiftS = 23;
+constexpr uint32_t kDRow = 4u + 400u;                       // header dword + one byte per right cell (offset E(r) = 403 - r)
+constexpr uint32_t kDSNleftOff = kLeftN * kDRow;            // 161 600: [400] u16
+constexpr uint32_t kDSMiscOff = kDSNleftOff + 2u * kLeftN;  // [32] u32: [0..7] rotation counts, [8] bad input, [9] entry / cell too big, [16..31] wave totals
+constexpr uint32_t kDSLdsBytes = kDSMiscOff + 128u;         // 162 528
+static_assert(kDSLdsBytes <= kLdsBytes, "stream-dense layout exceeds the LDS");
+constexpr int kKeyCountShift = 11, kKeyTagShift = 27;       // row header while binning: grid type << 27 | (count - 1) << 11 | E
+}  // namespace
+
+template <bool ROT>
+__global__ void __launch_bounds__(1024)
+stream_dense_kernel(FilterParams p, uint32_t* __restrict__ codes_ws, uint16_t* __restrict__ nleft_ws, uint32_t* __restrict__ flags, int mcap)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    constexpr int kNRot = ROT ? 8 : 1;
+    constexpr int kC = 8;  // code words a thread has in flight (16: no faster)
+    const int pi = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const gms_pair pr = p.pairs[pi];
+    const int m = pr.m;
+    uint8_t* bytes = reinterpret_cast<uint8_t*>(smem);
+    uint16_t* nleft = reinterpret_cast<uint16_t*>(bytes + kDSNleftOff);
+    uint32_t* misc = smem + kDSMiscOff / 4;
+    const int64_t total_kp = table_total_kp(p);
+    bool general = m <= 0 || m > mcap || pr.frame_a < 0 || pr.frame_a >= p.n_frames || pr.frame_b < 0 || pr.frame_b >= p.n_frames || total_kp < 0;
+    int64_t offA = 0, offB = 0;
+    int nA = 0, nB = 0;
+    if (!general) {
+        offA = p.frame_off[pr.frame_a];
+        offB = p.frame_off[pr.frame_b];
+        nA = (int)(p.frame_off[pr.frame_a + 1] - offA);
+        nB = (int)(p.frame_off[pr.frame_b + 1] - offB);
+        general = nA <= 0 || nB <= 0 || offA + nA > total_kp || offB + nB > total_kp;
+    }
+    if (general) {  // (workgroup-uniform) nothing this kernel can take: the general kernel decides what the pair is
+        if (tid == 0) atomicOr(&flags[pi], kSFlagGeneral);
+        return;
+    }
+    const gms_dmatch* __restrict__ matches = p.matches + pr.match_off;
+    const uint16_t* __restrict__ lcode = reinterpret_cast<const uint16_t*>(p.pts + total_kp) + offA;
+    const uint16_t* __restrict__ rcode = reinterpret_cast<const uint16_t*>(p.pts + total_kp) + total_kp + offB;
+    uint32_t* __restrict__ codes = codes_ws + (size_t)pi * mcap;
+    uint16_t* __restrict__ nl_g = nleft_ws + (size_t)pi * 4 * kLeftN;
+    const int kpt = (m + 1023) >> 10;
+
+    // ---- the code words and the half-cell histogram (u32, one dword per half cell: [cell][qx + 2 qy], in the still unused matrix area)
+    uint32_t* hist = smem;
+    for (int j = tid; j < kFineN; j += 1024) hist[j] = 0;
+    if (tid < 32) misc[tid] = 0;
+    __syncthreads();
+    {
+        bool any_bad = false;
+        for (int k0 = 0; k0 < kpt; k0 += kC) {
+            uint2 qt[kC];
+#pragma unroll
+            for (int j = 0; j < kC; ++j) qt[j] = *reinterpret_cast<const uint2*>(&matches[min((k0 + j) * 1024 + tid, m - 1)]);
+            uint32_t ca[kC], cb[kC];
+#pragma unroll
+            for (int j = 0; j < kC; ++j) {
+                ca[j] = lcode[min(qt[j].x, (uint32_t)(nA - 1))];
+                cb[j] = rcode[min(qt[j].y, (uint32_t)(nB - 1))];
+            }
+#pragma unroll
+            for (int j = 0; j < kC; ++j) {
+                const int i = (k0 + j) * 1024 + tid;
+                const bool live = i < m;
+                const uint32_t cell = ca[j] >> 7, e0 = cb[j] & 0x1FFu;  // cell: 510 = binned under no grid type, 511 = outside the parity domain
+                const bool ok = qt[j].x < (uint32_t)nA && qt[j].y < (uint32_t)nB && cell != 511u && (cb[j] >> 15) == 0u && e0 != 0u;
+                const bool binned = live && ok && cell < 510u;
+                any_bad |= live && !ok;
+                const uint32_t qx = ca[j] & 1u, qy = (ca[j] >> 2) & 1u;
+                if (binned) atomicAdd(&hist[cell * 4u + qx + 2u * qy], 1u);
+                const uint32_t cw = binned ? (qx | (qy << 1) | (((ca[j] >> 5) & 3u) << 3) | (e0 << kDEShiftS) | (cell << kDCellShiftS)) : (1u << 2);
+                if (live) codes[i] = cw;
+            }
+        }
+        if (any_bad) misc[8] = 1;
+    }
+    __syncthreads();
+    if (misc[8] != 0) {  // an index out of range, a point outside the parity domain or outside the right grid: the general kernel's pair
+        if (tid == 0) atomicOr(&flags[pi], kSFlagGeneral);
+        return;
+    }
+    for (int item = tid; item < 4 * kLeftN; item += 1024) {
+        const int g = item / kLeftN, cell = item - g * kLeftN;
+        const int hx0 = 2 * (cell % kLeftW) - (g & 1), hy0 = 2 * (cell / kLeftW) - (g >> 1);
+        uint32_t n = 0;
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) {
+                const int hx = hx0 + dx, hy = hy0 + dy;
+                if (hx >= 0 && hy >= 0) n += hist[(((hy >> 1) * kLeftW + (hx >> 1)) << 2) + (hx & 1) + ((hy & 1) << 1)];
+            }
+        if (n > 65535u) misc[9] = 1;
+        nl_g[item] = (uint16_t)n;
+    }
+    __syncthreads();
+    if (misc[9] != 0) {  // a cell above 65 535 matches
+        if (tid == 0) {
+            atomicOr(&flags[pi], kSFlagGeneral);
+            if (p.overflow_events) atomicAdd(p.overflow_events, 1u);
+        }
+        return;
+    }
+    {   // motion.setTo(0), once: every grid type leaves the matrix as it found it
+        const uint4 z4 = make_uint4(0, 0, 0, 0);
+        uint4* d4 = reinterpret_cast<uint4*>(smem);
+        for (uint32_t i = tid; i < kDSNleftOff / 16u; i += 1024) d4[i] = z4;
+    }
+    const bool thr_fast = threshold_fast_ok(p.threshold_factor);
+
+    for (int g = 0; g < 4; ++g) {
+        const uint32_t gx = (uint32_t)(g & 1), gy = (uint32_t)(g >> 1);
+        const uint32_t out_mask = (1u << 2) | (gx << 3) | (gy << 4);  // never | x >= 20 | y >= 20 under this grid type (DLL@0x180047d3d)
+        const uint32_t tag = (uint32_t)g << kKeyTagShift;
+        if (tid < kLeftN / 2) reinterpret_cast<uint32_t*>(nleft)[tid] = reinterpret_cast<const uint32_t*>(nl_g + g * kLeftN)[tid];
+        __syncthreads();  // (the matrix clear / the previous grid type's undo and side-table reset are complete)
+        // ---- assignMatchPairs
+        for (int k0 = 0; k0 < kpt; k0 += kC) {
+            uint32_t cw[kC];
+#pragma unroll
+            for (int j = 0; j < kC; ++j) {
+                const int i = (k0 + j) * 1024 + tid;
+                cw[j] = i < m ? codes[i] : (1u << 2);
+            }
+            uint32_t old[kC], at[kC];
+#pragma unroll
+            for (int j = 0; j < kC; ++j) {
+                const uint32_t l = ((cw[j] >> kDCellShiftS) & 0x1FFu) + (cw[j] & gx) + 20u * ((cw[j] >> 1) & gy);
+                at[j] = __umul24(l, kDRow) + ((cw[j] >> kDEShiftS) & 0x1FFu);
+                old[j] = 0;
+                if ((cw[j] & out_mask) == 0u) old[j] = atomicAdd(lds_at(smem, at[j] & ~3u), 1u << ((at[j] << 3) & 31u));
+            }
+            __builtin_amdgcn_sched_barrier(0);  // all of the chunk's atomics are issued before any result is read
+#pragma unroll
+            for (int j = 0; j < kC; ++j) {
+                if ((cw[j] & out_mask) != 0u) continue;
+                const uint32_t e = (cw[j] >> kDEShiftS) & 0x1FFu, row = at[j] - e;
+                const uint32_t before = (old[j] >> ((at[j] << 3) & 31u)) & 255u;
+                if (before == 255u) misc[9] = 1;  // the entry's byte has just wrapped: more than 255 matches in one (left cell, right cell) pair
+                atomicMax(lds_at(smem, row), tag | (before << kKeyCountShift) | e);  // highest count, then lowest right cell
+            }
+        }
+        __syncthreads();
+        if (misc[9] != 0) {  // (workgroup-uniform) the general kernel's pair; nothing has been written out
+            if (tid == 0) {
+                atomicOr(&flags[pi], kSFlagGeneral);
+                if (p.overflow_events) atomicAdd(p.overflow_events, 1u);
+            }
+            return;
+        }
+        // ---- verifyCellPairs (dense_pair's: two lanes per cell without rotation, one lane per (cell, rotation) with)
+        {
+            constexpr int kItems = ROT ? kLeftN * 8 : kLeftN * 2;
+            for (int item = tid; item < ((kItems + 63) & ~63); item += 1024) {
+                const bool live = item < kItems;
+                const int i = live ? (ROT ? (item >> 3) : (item >> 1)) : 0;
+                const int rot = ROT ? (item & 7) : 0;
+                const int half = item & 1;  // !ROT only
+                const int ix = i % kLeftW, iy = i / kLeftW;
+                const uint32_t ni = live ? (uint32_t)nleft[i] : 0u;
+                if (__ballot(ni != 0) == 0ull) continue;  // none of this wave's cells has a match under this grid type
+                const uint32_t best = smem[i * (kDRow / 4)] & ((1u << kKeyTagShift) - 1u);  // ((max count - 1) << 11) | E(j*), lowest j* among maxima
+                const uint32_t ej = ni ? (best & 0x7FFu) : 403u;
+                const int j = 403 - (int)ej;
+                const int jx = j % 20, jy = j / 20;
+                uint32_t score = 0, tsum = 0, np = 0;
+#pragma unroll
+                for (int c = 0; c < (ROT ? 8 : 4); ++c) {
+                    int ldx, ldy, rdx, rdy;
+                    if (ROT) {
+                        const int k = c < 4 ? c : c + 1;
+                        constexpr int kRingIndex[9] = {0, 1, 2, 7, -1, 3, 6, 5, 4};  // position -> ring index
+                        const int q = rotated_position(rot, kRingIndex[k]);
+                        ldx = (k % 3) - 1; ldy = (k / 3) - 1;
+                        rdx = position_dx(q); rdy = position_dy(q);
+                    } else {
+                        ldx = half ? ((c + 5) % 3) - 1 : (c % 3) - 1;  // lane 0: neighbours 0..3, lane 1: 5..8
+                        ldy = half ? ((c + 5) / 3) - 1 : (c / 3) - 1;
+                        rdx = ldx; rdy = ldy;
+                    }
+                    const int lx = ix + ldx, ly = iy + ldy, rx = jx + rdx, ry = jy + rdy;
+                    const bool okl = ni != 0 && (uint32_t)lx < (uint32_t)kLeftW && (uint32_t)ly < (uint32_t)kLeftH;  // ll != -1
+                    const bool okp = okl && (uint32_t)rx < 20u && (uint32_t)ry < 20u;                                 // rr != -1
+                    const uint32_t ll = okl ? (uint32_t)(lx + ly * kLeftW) : 0u;
+                    const uint32_t at = ll * kDRow + (okp ? (uint32_t)(403 - (rx + ry * 20)) : 4u);
+                    const uint32_t cnt = bytes[at];
+                    score += okp ? cnt : 0u;
+                    tsum += okp ? (uint32_t)nleft[ll] : 0u;
+                    np += okp ? 1u : 0u;
+                }
+                if (!ROT) {
+                    score += dpp_xor1(score);
+                    tsum += dpp_xor1(tsum);
+                    np += dpp_xor1(np);
+                }
+                score += (best >> kKeyCountShift) + 1u;  // centre pair (k = 4): ll = i, rr = j*, the arg-max count itself
+                tsum += ni;
+                np += 1u;
+                uint32_t pass = 0;
+                if (ni != 0 && (ROT || half == 0)) pass = threshold_rejects(tsum, np, score, p.threshold_factor, thr_fast) ? 0u : 1u;
+                uint32_t vbits = pass;
+                bool writer = ni != 0 && half == 0;
+                if (ROT) {
+                    const unsigned long long bal = __ballot(pass);
+                    vbits = (uint32_t)(bal >> (lane & 56)) & 0xFFu;
+                    writer = ni != 0 && (lane & 7) == 0;
+                }
+                // every lane of the cell has read the header above (same wave, program order): it now holds cellPairs[i]
+                if (writer) smem[i * (kDRow / 4)] = (ej << 8) | vbits;
+            }
+        }
+        __syncthreads();
+        // ---- mark inliers (cellPairs[l] == r, all rotations at once) and take this grid type's increments back
+        for (int k0 = 0; k0 < kpt; k0 += kC) {
+            uint32_t cw[kC];
+#pragma unroll
+            for (int j = 0; j < kC; ++j) {
+                const int i = (k0 + j) * 1024 + tid;
+                cw[j] = i < m ? codes[i] : (1u << 2);
+            }
+#pragma unroll
+            for (int j = 0; j < kC; ++j) {
+                if ((cw[j] & out_mask) != 0u) continue;
+                const uint32_t l = ((cw[j] >> kDCellShiftS) & 0x1FFu) + (cw[j] & gx) + 20u * ((cw[j] >> 1) & gy);
+                const uint32_t e = (cw[j] >> kDEShiftS) & 0x1FFu, row = __umul24(l, kDRow);
+                const uint32_t x = smem[row >> 2] ^ (e << 8);  // < 256: the same right cell, x = the rotations that accept the cell
+                if (g < 3) bytes[row + e] = 0;                 // (every reader of the entry is past the barrier: see dense_pair)
+                if (x < 256u && ((cw[j] >> kDAccShiftS) | x) != (cw[j] >> kDAccShiftS)) codes[(k0 + j) * 1024 + tid] = cw[j] | (x << kDAccShiftS);
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- run()'s return value per rotation, getInlierMask's strict '>' over the rotations (one scale)
+    int winner = 0;
+    if (ROT) {
+        uint32_t cnt[kNRot];
+#pragma unroll
+        for (int r = 0; r < kNRot; ++r) cnt[r] = 0;
+        for (int k = 0; k < kpt; ++k) {
+            const int i = k * 1024 + tid;
+            const uint32_t acc = i < m ? codes[i] >> kDAccShiftS : 0u;
+#pragma unroll
+            for (int r = 0; r < kNRot; ++r) cnt[r] += (uint32_t)__popcll(__ballot((acc >> r) & 1u));
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int r = 0; r < kNRot; ++r)
+                if (cnt[r]) atomicAdd(&misc[r], cnt[r]);
+        }
+        __syncthreads();
+        uint32_t best_count = 0;
+        winner = -1;
+#pragma unroll
+        for (int r = 0; r < kNRot; ++r) {
+            const uint32_t c = misc[r];
+            if (c > best_count) {
+                best_count = c;
+                winner = r;
+            }
+        }
+    }
+    // ---- copy-out: survivors per chunk of 64 consecutive matches (chunk k * 16 + wave), scanned; then the records, in input order
+    uint32_t* cnt_tab = smem;  // in the matrix area (every reader of the matrix is past the barrier above)
+    uint32_t* wave_tot = misc + 16;
+    for (int k = 0; k < kpt; ++k) {
+        const int i = k * 1024 + tid;
+        const bool keep = winner >= 0 && i < m && ((codes[i] >> (kDAccShiftS + max(winner, 0))) & 1u) != 0u;
+        const unsigned long long b = __ballot(keep);
+        if (lane == 0) cnt_tab[k * 16 + wave] = (uint32_t)__popcll(b);
+    }
+    __syncthreads();
+    uint32_t total = 0;
+    {
+        const int n_chunks = kpt * 16;  // <= 1024: one scan entry per thread
+        const uint32_t c = tid < n_chunks ? cnt_tab[tid] : 0u;
+        uint32_t incl = c;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t t = __shfl_up(incl, d);
+            if (lane >= d) incl += t;
+        }
+        if (lane == 63) wave_tot[wave] = incl;
+        __syncthreads();
+        uint32_t off = 0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) {
+            const uint32_t tw = wave_tot[w];
+            off += w < wave ? tw : 0u;
+            total += tw;
+        }
+        if (tid < n_chunks) cnt_tab[tid] = off + incl - c;
+    }
+    __syncthreads();
+    gms_dmatch* __restrict__ out = p.out + pr.match_off;
+    uint8_t* mask_out = p.mask ? p.mask + pr.match_off : nullptr;
+    for (int k = 0; k < kpt; ++k) {
+        const int i = k * 1024 + tid;
+        const bool keep = winner >= 0 && i < m && ((codes[i] >> (kDAccShiftS + max(winner, 0))) & 1u) != 0u;
+        const unsigned long long b = __ballot(keep);
+        if (i < m && mask_out) mask_out[i] = keep ? 1 : 0;
+        if (keep) {
+            const uint32_t pos = cnt_tab[k * 16 + wave] + (uint32_t)__popcll(b & ((1ull << lane) - 1ull));
+            *reinterpret_cast<uint4*>(&out[pos]) = *reinterpret_cast<const uint4*>(&matches[i]);
+        }
+    }
+    if (tid == 0) {
+        gms_pair_result r;
+        r.n_inliers = (int)total;
+        r.best_scale = total ? 0 : -1;
+        r.best_rot = total ? winner + 1 : -1;
+        r.status = GMS_OK;
+        p.results[pi] = r;
+    }
+}
+
+size_t stream_dense_ws_bytes_per_pair(int mcap) { return (size_t)mcap * 4 + 4 * (size_t)kLeftN * 2 + 4 + 64; }
+
+// ws layout for n pairs: codes [n][mcap] u32 | nleft [n][4][400] u16 | flags [n]; *flags_out marks the pairs left to launch_filter_big (bit 1)
+hipError_t launch_filter_stream_dense(const FilterParams& p, int mcap, void* ws, const uint32_t** flags_out, hipStream_t stream)
+{
+    const int n = p.n_pairs;
+    if (n <= 0) return hipSuccess;
+    if (p.right_w[0] != 20 || p.right_h[0] != 20 || p.with_scale) return hipErrorInvalidValue;
+    char* q = reinterpret_cast<char*>(ws);
+    uint32_t* codes = reinterpret_cast<uint32_t*>(q);
+    q += align16s((size_t)n * mcap * 4);
+    uint16_t* nleft = reinterpret_cast<uint16_t*>(q);
+    q += align16s((size_t)n * 4 * kLeftN * 2);
+    uint32_t* flags = reinterpret_cast<uint32_t*>(q);
+    hipError_t e = hipMemsetAsync(flags, 0, (size_t)n * 4, stream);
+    if (e != hipSuccess) return e;
+    if (p.with_rotation) hipLaunchKernelGGL(stream_dense_kernel<true>, dim3((unsigned)n), dim3(1024), kDSLdsBytes, stream, p, codes, nleft, flags, mcap);
+    else hipLaunchKernelGGL(stream_dense_kernel<false>, dim3((unsigned)n), dim3(1024), kDSLdsBytes, stream, p, codes, nleft, flags, mcap);
+    *flags_out = flags;
+    return hipGetLastError();
+}
+
 // ---- launch helpers ----------------------------------------------------------------------------------------------------------------------
 hipError_t init_stream_kernels()  // once per context: see init_filter_kernels
 {
-    const void* fns[] = {reinterpret_cast<const void*>(stream_filter_kernel<true>), reinterpret_cast<const void*>(stream_filter_kernel<false>)};
+    const void* fns[] = {reinterpret_cast<const void*>(stream_filter_kernel<true>), reinterpret_cast<const void*>(stream_filter_kernel<false>),
+                         reinterpret_cast<const void*>(stream_dense_kernel<true>), reinterpret_cast<const void*>(stream_dense_kernel<false>)};
     for (const void* fn : fns) {
         const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes);
         if (e != hipSuccess) return e;
@@ -520,7 +877,6 @@ hipError_t init_stream_kernels()  // once per context: see init_filter_kernels
 
 int stream_max_matches() { return kSMaxMatches; }
 
-static size_t align16s(size_t x) { return (x + 15) & ~(size_t)15; }
 
 size_t stream_ws_bytes_per_pair(const FilterParams& p, int mcap, bool need_mask)
 {

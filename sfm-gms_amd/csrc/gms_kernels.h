@@ -43,6 +43,7 @@ struct FilterParams {
     int dealt;                  // byte-matrix kernel: deal the matches to the lanes (inputs in spatial order; see dense_pair)
     int probe_scales;           // scale hypotheses: bit s set = bound scale s's inlier count first and skip the scale when it cannot win
     uint32_t* probe_stats;      // optional device counters: [0] scales probed, [1] scales the probe let skip
+    uint32_t* overflow_events;  // streamed byte-matrix kernels: a word (pinned host memory) that counts the pairs they had to hand on because an entry left its byte
     int dense;                  // try the byte-matrix path first (no scale hypotheses only); the general path is the fallback
     double threshold_factor;
     int right_w[5], right_h[5]; // setScale (DLL@0x180048c10): cvRound(20 * ratio[s])
@@ -87,6 +88,9 @@ hipError_t init_stream_kernels();
 int        stream_max_matches();
 size_t     stream_ws_bytes_per_pair(const FilterParams& p, int mcap, bool need_mask);
 hipError_t launch_filter_stream(const FilterParams& p, int mcap, void* ws, const uint32_t** flags_out, hipStream_t stream);
+// the same size class without scale hypotheses: one workgroup per pair, dense_pair() with the code words streamed from an L2-resident array
+size_t     stream_dense_ws_bytes_per_pair(int mcap);
+hipError_t launch_filter_stream_dense(const FilterParams& p, int mcap, void* ws, const uint32_t** flags_out, hipStream_t stream);
 // brute-force descriptor matcher (bf_kernels.hip)
 size_t     bf_prepared_bytes(int kind, int64_t total, int n_frames);
 hipError_t launch_bf_prepare(int kind, const void* d_desc, const int64_t* d_frame_off, int n_frames, int64_t total, void* d_prep,

@@ -8,7 +8,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
-CASES = [(50000, 64, 1, 1), (50000, 256, 1, 1), (50000, 256, 0, 0), (50000, 64, 1, 0), (50000, 64, 0, 1), (20000, 256, 1, 1), (20000, 256, 0, 0)]
+CASES = [(50000, 64, 1, 1), (50000, 256, 1, 1), (50000, 256, 0, 0), (50000, 64, 0, 0), (50000, 64, 1, 0), (50000, 256, 1, 0), (50000, 64, 0, 1), (20000, 256, 1, 1), (20000, 256, 0, 0)]
 
 
 def main():
