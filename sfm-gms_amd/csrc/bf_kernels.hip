@@ -194,8 +194,10 @@ bf_ham_prepare_kernel(const uint16_t* __restrict__ desc, int64_t total, uint2* _
 //   Hamming  rows = 256 x FP4 (128 B), v_mfma_scale_f32_32x32x64_f8f6f4 with both formats FP4 and unit scales (four per block and
 //            accumulator, at twice the int8 rate). hamming = |a| + |b| - 2 a.b over 0/1 elements: the B operand is the query row
 //            times -2 (FP4 holds -2 exactly: every nibble 0x2 -> 0xC); the accumulator starts from the train row's popcount PLUS
-//            (row inside the block) / 32, so it ends as |a| - 2 a.b + row / 32 -- exact in fp32 -- and the plain minimum already is
-//            "smallest distance, then lowest row": integer part = distance - |b|, fraction = the row. No second pass.
+//            (train row mod 32768) / 32768, so it ends as |a| - 2 a.b + row / 32768 -- |value| < 512 with 15 fraction bits: exact
+//            in fp32 -- and the plain minimum over ALL the accumulators a lane ever sees already is "smallest distance, then
+//            lowest row": integer part = distance - |b|, fraction = the row. One v_min3 per two values is the whole bookkeeping;
+//            nothing is compared per block. Frames beyond 32768 rows fold the running minimum once per 32768 rows (kHamChunk).
 //   L2       rows = 128 x int8 (128 B), v_mfma_i32_32x32x32_i8 (four per block and accumulator; the bf16 form needs eight at half the
 //            rate). With a' = a - 128 and the query side as ~b' = 127 - b (a bytewise NOT: both fit int8 for every value 0..255),
 //            a - b = (a' + 1) + ~b', so d^2 = w(a) + 2 a'.~b' + [sum ~b'^2 + 2 sum ~b'] with w(a) = sum (a' + 1)^2; the bracket is
@@ -222,6 +224,7 @@ constexpr uint32_t kMfmaLdsBytes = kNormOff + 2u * kStepRows * 4u;   // 75 776: 
 constexpr int kQueriesPerBlock = 256;            // 4 waves x 64 query columns
 constexpr int kKSteps = 4;                       // MFMAs per (tile, accumulator): 4 x 32 bytes of a row
 constexpr int kFp4UnitScale = 0x7F7F7F7F;        // E8M0 127 = 2^0 in every byte
+constexpr int kHamChunk = 32768;                 // Hamming: train rows whose index rides in one fp32 fraction (a multiple of kStepRows)
 
 // L2, the exact search of a 32-row block, eight queries per wave: the eight lanes of a group (lane >> 3) hold the 16-byte pieces
 // (lane & 7) of the group's query and walk the 32 rows of the group's OWN block, so a group's load is one whole 128-byte row.
@@ -306,9 +309,9 @@ bf_mfma_kernel(const uint4* __restrict__ rows, const uint32_t* __restrict__ norm
             else bq[c][s] = make_uint4(~r4.x, ~r4.y, ~r4.z, ~r4.w);
         }
     }
-    Val bestv[2] = {kBig, kBig};    // the smallest block minimum so far (Hamming: with the row fraction) ...
-    Val bestd[2] = {kBig, kBig};    // ... Hamming: its integer part
-    int bestt[2] = {0, 0};          // ... and the block (of 32 train rows) it came from: the first one that reached it
+    Val bestv[2] = {kBig, kBig};    // L2: the smallest block minimum so far ...
+    Val bestd[2] = {kBig, kBig};    // Hamming: the smallest distance part (distance - |b|) of the chunks folded so far ...
+    int bestt[2] = {0, 0};          // L2: the block (of 32 train rows) bestv came from, the first one that reached it; Hamming: bestd's train row
     int ties[2] = {0, 0};           // L2: in how many later blocks the minimal P was seen again ...
     int bestt2[2] = {0, 0};         // ... and the last of them
     int whalf[2] = {half, half};    // L2: which lane half's rows of the winning block hold the minimum (2 = either)
@@ -329,13 +332,9 @@ bf_mfma_kernel(const uint4* __restrict__ rows, const uint32_t* __restrict__ norm
         };
         sg.v0 = piece(0); sg.v1 = piece(1); sg.v2 = piece(2); sg.v3 = piece(3);
         sg.v4 = piece(4); sg.v5 = piece(5); sg.v6 = piece(6); sg.v7 = piece(7);
-        const int r = st * kStepRows + tid;
-        Val nv = kBig;
-        if (r < f.nB) {
-            if constexpr (HAM) nv = __uint_as_float(nrmB[r]) + (float)(tid & 31) * (1.0f / 32.0f);   // popcount + row inside the block / 32
-            else nv = (int32_t)nrmB[r] >> 1;                                                          // floor(w / 2)
-        }
-        sg.nv = __builtin_bit_cast(uint32_t, nv);
+        // (the norm stays raw here: turning it into the accumulator's start value would wait for it -- and with it for the eight
+        //  row loads just issued -- a whole memory latency before the step's products; stage_store does that a step later)
+        sg.nv = nrmB[min(st * kStepRows + tid, f.nB - 1)];
         return sg;
     };
     auto stage_store = [&](int st, const Stage& sg) {
@@ -346,7 +345,13 @@ bf_mfma_kernel(const uint4* __restrict__ rows, const uint32_t* __restrict__ norm
         };
         put(0, sg.v0); put(1, sg.v1); put(2, sg.v2); put(3, sg.v3);
         put(4, sg.v4); put(5, sg.v5); put(6, sg.v6); put(7, sg.v7);
-        reinterpret_cast<uint32_t*>(lds + kNormOff)[(st & 1) * kStepRows + tid] = sg.nv;
+        const int r = st * kStepRows + tid;
+        Val nv = kBig;
+        if (r < f.nB) {
+            if constexpr (HAM) nv = __uint_as_float(sg.nv) + (float)(r & (kHamChunk - 1)) * (1.0f / (float)kHamChunk);   // popcount + row / 32768
+            else nv = (int32_t)sg.nv >> 1;                                                                            // floor(w / 2)
+        }
+        reinterpret_cast<Val*>(lds + kNormOff)[(st & 1) * kStepRows + tid] = nv;
     };
     // ---- the main loop, scheduled by hand in the source (scheduling barriers keep the compiler from re-ordering it).
     // A BLOCK = 32 train rows x the wave's 64 query columns = two accumulators (c0: columns 0..31, c1: 32..63), eight MFMAs in four
@@ -387,22 +392,26 @@ bf_mfma_kernel(const uint4* __restrict__ rows, const uint32_t* __restrict__ norm
             mn[1] = min(mn[1], bl.c1[reg]);
         }
     };
-    auto block_compare = [&](int blk) {   // the first block that reached the minimum stays
+    auto block_compare = [&](int blk) {   // L2: the first block that reached the minimum stays (Hamming: mn simply keeps running)
+        if constexpr (!HAM) {
 #pragma unroll
-        for (int c = 0; c < 2; ++c) {
-            if constexpr (HAM) {
-                const float d = floorf(mn[c]);   // equal distances: the earlier block holds the lower rows
-                const bool lt = d < bestd[c];
-                bestd[c] = lt ? d : bestd[c];
-                bestv[c] = lt ? mn[c] : bestv[c];
-                bestt[c] = lt ? blk : bestt[c];
-            } else {
+            for (int c = 0; c < 2; ++c) {
                 const bool lt = mn[c] < bestv[c], eq = mn[c] == bestv[c];
                 ties[c] = lt ? 0 : ties[c] + (eq ? 1 : 0);
                 bestt2[c] = eq ? blk : bestt2[c];
                 bestv[c] = lt ? mn[c] : bestv[c];
                 bestt[c] = lt ? blk : bestt[c];
+                mn[c] = kBig;
             }
+        }
+    };
+    auto ham_fold = [&](int chunk) {   // Hamming: the running minimum of a chunk of kHamChunk rows into (distance part, row)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const float d = floorf((float)mn[c]);   // equal distances: the earlier chunk holds the lower rows
+            const bool lt = d < (float)bestd[c];
+            bestt[c] = lt ? chunk * kHamChunk + (int)(((float)mn[c] - d) * (float)kHamChunk) : bestt[c];
+            bestd[c] = lt ? (Val)d : bestd[c];
             mn[c] = kBig;
         }
     };
@@ -417,51 +426,65 @@ bf_mfma_kernel(const uint4* __restrict__ rows, const uint32_t* __restrict__ norm
 #pragma unroll
     for (int reg = 0; reg < 16; ++reg) done.c0[reg] = done.c1[reg] = kBig;
     for (int st = 0; st < n_steps; ++st) {
+        if constexpr (HAM) {
+            if (st != 0 && (st & (kHamChunk / kStepRows - 1)) == 0) {   // a new chunk of rows (rare): settle the one before, lagging block included
+                min_regs(done, 0, 16);
+                ham_fold(st / (kHamChunk / kStepRows) - 1);
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) done.c0[reg] = done.c1[reg] = kBig;
+            }
+        }
+#if !defined(BF_DIAG) || BF_DIAG != 2
         if (st + 1 < n_steps) stage_store(st + 1, sv);
         if (st + 2 < n_steps) sv = stage_load(st + 2);
-        uint4 a_next = lds_a(st, 0, 0);
+#endif
+        // the four A pieces of a block are read a whole block ahead (LDS latency under load is several MFMAs long)
+        uint4 a_cur[kKSteps], a_nxt[kKSteps];
+#pragma unroll
+        for (int s = 0; s < kKSteps; ++s) a_cur[s] = lds_a(st, 0, s);
         uint4 n0 = lds_n(st, 0, 0), n1 = lds_n(st, 0, 1), n2 = lds_n(st, 0, 2), n3 = lds_n(st, 0, 3);
 #pragma unroll
         for (int blk = 0; blk < 2 * kSub; ++blk) {
             Block cur;
             {   // k-step 0; `done`'s last MFMAs are still in the pipe: the comparison of the block before `done` goes here
-                const uint4 a = a_next;
                 const Acc nrm = as_acc(n0, n1, n2, n3);
-                cur.c1 = mfma(a, bq[1][0], nrm);
-                cur.c0 = mfma(a, bq[0][0], nrm);
-                a_next = lds_a(st, blk, 1);
+                cur.c1 = mfma(a_cur[0], bq[1][0], nrm);
+                cur.c0 = mfma(a_cur[0], bq[0][0], nrm);
+                if (blk + 1 < 2 * kSub) a_nxt[0] = lds_a(st, blk + 1, 0);
                 block_compare(st * 2 * kSub + blk - 2);
                 __builtin_amdgcn_sched_barrier(0);
             }
 #pragma unroll
             for (int s = 1; s < kKSteps; ++s) {
-                const uint4 a = a_next;
-                cur.c0 = mfma(a, bq[0][s], cur.c0);
-                cur.c1 = mfma(a, bq[1][s], cur.c1);
-                if (s + 1 < kKSteps) a_next = lds_a(st, blk, s + 1);
-                else if (blk + 1 < 2 * kSub) a_next = lds_a(st, blk + 1, 0);
+                cur.c0 = mfma(a_cur[s], bq[0][s], cur.c0);
+                cur.c1 = mfma(a_cur[s], bq[1][s], cur.c1);
                 if (blk + 1 < 2 * kSub) {
-                    if (s == 1) n0 = lds_n(st, blk + 1, 0);
-                    if (s == 2) n1 = lds_n(st, blk + 1, 1);
-                    if (s == 3) { n2 = lds_n(st, blk + 1, 2); n3 = lds_n(st, blk + 1, 3); }
+                    a_nxt[s] = lds_a(st, blk + 1, s);
+                    if (s == 1) { n0 = lds_n(st, blk + 1, 0); n1 = lds_n(st, blk + 1, 1); }
+                    if (s == 2) { n2 = lds_n(st, blk + 1, 2); n3 = lds_n(st, blk + 1, 3); }
                 }
                 min_regs(done, s == 1 ? 0 : (s == 2 ? 6 : 11), s == 1 ? 6 : (s == 2 ? 11 : 16));
                 __builtin_amdgcn_sched_barrier(0);
             }
             done = cur;
+#pragma unroll
+            for (int s = 0; s < kKSteps; ++s) a_cur[s] = a_nxt[s];
         }
+#if !defined(BF_DIAG) || BF_DIAG != 1   // (BF_DIAG: timing-only diagnostic builds with wrong results, never the product -- DESIGN.md section 7)
         __syncthreads();
+#endif
     }
     block_compare(n_steps * 2 * kSub - 2);
     min_regs(done, 0, 16);
     block_compare(n_steps * 2 * kSub - 1);
+    if constexpr (HAM) ham_fold((n_steps - 1) / (kHamChunk / kStepRows));
     // ---- the two halves of the wave hold disjoint row sets of the same query
     gms_dmatch* __restrict__ out = matches + pr.match_off;
     if constexpr (HAM) {
         int rowi[2];
 #pragma unroll
         for (int c = 0; c < 2; ++c) {   // lower distance, then lower row
-            rowi[c] = bestt[c] * 32 + (int)((bestv[c] - bestd[c]) * 32.0f);
+            rowi[c] = bestt[c];
             const float od = __shfl_xor(bestd[c], 32);
             const int orow = __shfl_xor(rowi[c], 32);
             const bool take = od < bestd[c] || (od == bestd[c] && orow < rowi[c]);

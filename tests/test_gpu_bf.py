@@ -69,6 +69,34 @@ def test_hamming_10k_config2(ctx, pkg, oracle, synth):
         _check(oracle, descs, pairs, got, True)
 
 
+def test_hamming_frames_beyond_one_row_chunk(ctx, pkg, oracle, synth):
+    """The matrix-core kernel carries (train row mod 32768) in the accumulator's fraction and settles the running minimum once per
+    32768 rows: equal distances in two chunks keep the lower row, a strictly smaller one in a later chunk wins, and the row right at
+    the boundary is found."""
+    rng = np.random.default_rng(8)
+    n_t, n_q = 70000, 300
+    train = rng.integers(0, 256, (n_t, 32), dtype=np.uint8)
+    query = rng.integers(0, 256, (n_q, 32), dtype=np.uint8)
+    for q in range(0, 60):         # the same row in chunk 0 and chunk 1 (and chunk 2): the first wins
+        train[100 + q] = train[40000 + q] = train[66000 + q] = query[q]
+    for q in range(60, 120):       # one bit off in chunk 0, exact in chunk 2
+        train[200 + q] = query[q]
+        train[200 + q, 0] ^= 1
+        train[66000 + q] = query[q]
+    for q in range(120, 180):      # exact around the boundaries themselves
+        train[32768 - 30 + (q - 120)] = query[q]
+    for q in range(180, 240):
+        train[65536 - 30 + (q - 180)] = query[q]
+    descs = [query, train]
+    batch, table, dt = _tables(ctx, pkg, synth, descs, pkg.GMS_DESC_HAMMING256, size=(3840, 2160))
+    pairs = _pairs(pkg, [n_q, n_t], [(0, 1)])
+    got = batch.match_pairs(ctx, dt, pairs)
+    _check(oracle, descs, pairs, got, True)
+    want = np.concatenate([100 + np.arange(60), 66000 + np.arange(60, 120), 32768 - 30 + np.arange(60), 65536 - 30 + np.arange(60)])
+    assert (got["trainIdx"][:240] == want).all()
+    assert (got["distance"][:240] == 0).all()
+
+
 def test_l2_sift_like_rows_on_the_matrix_cores(ctx, pkg, oracle, synth):
     rng = np.random.default_rng(4)
     counts = [1, 31, 64, 65, 257, 1000, 3000, 777]

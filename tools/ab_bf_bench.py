@@ -10,7 +10,7 @@ __file__ = {root!r} + '/tools/bf_bench.py'
 exec(open(__file__).read())
 """
 for rnd in range(2):
-    for lib in ('libgms_hip_base.so','libgms_hip.so'):
+    for lib in (sys.argv[1:] or ['libgms_hip_base.so','libgms_hip.so']):
         for kind in ('orb','sift'):
             r = subprocess.run([sys.executable, '-c', code.format(root=ROOT, kind=kind, lib=ROOT+'/sfm-gms_amd/csrc/'+lib)], capture_output=True, text=True)
             import json

@@ -28,6 +28,8 @@ while n_frames * (n_frames - 1) // 2 < n_pairs:
 ctx = pkg.GmsContext(0)
 frames = synth.make_sequence(1000, n_frames, size=size, n_kp=n_kp)
 descs = synth.sequence_descriptors(1000, n_frames, n_kp, kind, outlier_frac=0.5)
+if os.environ.get("BF_ZERO") == "1":   # diagnostic: all-zero rows draw less power -- how far the clock under load limits the kernel
+    descs = [np.zeros_like(x) for x in descs]
 table = batch.FrameTable(ctx, frames, [size] * n_frames)
 dt = batch.DescriptorTable(ctx, table, descs, pkg.GMS_DESC_HAMMING256 if kind == "orb" else pkg.GMS_DESC_L2_F32X128)
 pairs = d.pair_table(n_frames, 0, n_pairs, n_kp)
