@@ -351,6 +351,30 @@ void gms_dataset_free(gms_dataset* d);
 /* ---- introspection --------------------------------------------------------------------------- */
 int         gms_max_matches(void);        /* largest m per pair this build accepts                 */
 int         gms_last_hip_error(void);     /* last hipError_t seen by this thread's calls           */
+/* ---- keypoint source ---------------------------------------------------------------------
+ * Stands where the reference calls OpenCV's detectors (FeatureMatchUtil.cpp:9-12 SIFT::create(10000)->detectAndCompute;
+ * DisparityUtil.cpp:108,123-138 ORB::create(), detectAndCompute / compute at every pixel). NOT cv::ORB: a single-scale FAST-9 +
+ * steered-BRIEF detector of this library's own, in integer arithmetic (definition: DESIGN.md section 7b; CPU statement
+ * oracle/detect_ref.c). Same records out: cv::KeyPoint {pt, size 31, angle = 11.25 * direction bin, response = FAST score, octave 0,
+ * class_id -1} and one 32-byte row per keypoint for NORM_HAMMING -- what gms_normalize_device / gms_bf_prepare_device take.
+ * Images: 8-bit grey, row-major, pitch = width, n_images of one size back to back in device memory. Keypoints sit at least
+ * GMS_DETECT_BORDER pixels from every edge. */
+#define GMS_DETECT_BORDER 16
+size_t gms_detect_workspace_bytes(int width, int height, int n_images, int max_keypoints);
+
+/* detectAndCompute for a batch: per image the max_keypoints strongest FAST-9 corners with score > threshold (equal scores in raster
+ * order), written in raster order: d_keypoints[i * max_keypoints ..], d_descriptors[(i * max_keypoints ..) * 32], d_counts[i].
+ * Errors: GMS_ERR_BAD_ARG (NULL, width/height outside (32, 65535], threshold outside [0, 254], workspace too small). */
+int gms_detect_batch_device(gms_ctx* ctx, const uint8_t* d_images, int n_images, int width, int height, int threshold, int max_keypoints,
+                            void* d_workspace, size_t workspace_bytes, gms_keypoint* d_keypoints, uint8_t* d_descriptors, int32_t* d_counts);
+
+/* Feature2D::compute on ONE image (DisparityUtil.cpp:123-133, a keypoint per pixel): direction (written to angle) and row at each
+ * of the caller's n keypoints. A keypoint off the integer pixel grid or inside the border sets *d_status = 1 and keeps its row
+ * (OpenCV would have dropped the keypoint and renumbered the rest; here the caller keeps control of the indices).
+ * Workspace: gms_detect_workspace_bytes(width, height, 1, 0). */
+int gms_describe_device(gms_ctx* ctx, const uint8_t* d_image, int width, int height, gms_keypoint* d_keypoints, int n,
+                        void* d_workspace, size_t workspace_bytes, uint8_t* d_descriptors, int32_t* d_status);
+
 const char* gms_error_string(int code);
 const char* gms_version(void);
 

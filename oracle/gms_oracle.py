@@ -66,6 +66,14 @@ def load():
     lib.bf_ref_hamming256.restype = i32
     lib.bf_ref_l2.argtypes = [vp, i32, vp, i32, i32, vp]
     lib.bf_ref_l2.restype = i32
+    lib.det_ref_detect.argtypes = [vp, i32, i32, i32, i32, vp, vp]
+    lib.det_ref_detect.restype = i32
+    lib.det_ref_describe.argtypes = [vp, i32, i32, vp, i32, vp]
+    lib.det_ref_describe.restype = i32
+    lib.det_ref_maps.argtypes = [vp, i32, i32, vp, vp]
+    lib.det_ref_maps.restype = None
+    lib.det_ref_pattern.argtypes = [vp]
+    lib.det_ref_pattern.restype = None
     _lib = lib
     return lib
 
@@ -85,6 +93,46 @@ def bf_match(query, train, hamming):
         rc = lib.bf_ref_l2(q.ctypes.data, len(q), t.ctypes.data, len(t), q.shape[1], out.ctypes.data)
     assert rc == 0
     return out[: len(q)]
+
+
+def detect(image, threshold=20, max_keypoints=10000):
+    """oracle/detect_ref.c: the build's own FAST-9 + steered-BRIEF keypoint source on an 8-bit grey image -> (keypoints, [n, 32] rows)."""
+    lib = load()
+    img = np.ascontiguousarray(image, dtype=np.uint8)
+    h, w = img.shape
+    kp = np.zeros(max(max_keypoints, 1), dtype=KEYPOINT_DTYPE)
+    desc = np.zeros((max(max_keypoints, 1), 32), dtype=np.uint8)
+    n = lib.det_ref_detect(img.ctypes.data, w, h, int(threshold), int(max_keypoints), kp.ctypes.data, desc.ctypes.data)
+    return kp[:n].copy(), desc[:n].copy()
+
+
+def describe(image, keypoints):
+    """oracle/detect_ref.c: directions and descriptors at given integer keypoints (Feature2D::compute). Returns (rc, keypoints, rows)."""
+    lib = load()
+    img = np.ascontiguousarray(image, dtype=np.uint8)
+    h, w = img.shape
+    kp = np.ascontiguousarray(keypoints, dtype=KEYPOINT_DTYPE).copy()
+    desc = np.zeros((max(len(kp), 1), 32), dtype=np.uint8)
+    rc = lib.det_ref_describe(img.ctypes.data, w, h, kp.ctypes.data, len(kp), desc.ctypes.data)
+    return rc, kp, desc[: len(kp)]
+
+
+def detect_maps(image):
+    """(FAST score image, 5 x 5 box sums) of oracle/detect_ref.c."""
+    lib = load()
+    img = np.ascontiguousarray(image, dtype=np.uint8)
+    h, w = img.shape
+    score = np.zeros((h, w), dtype=np.uint8)
+    box = np.zeros((h, w), dtype=np.uint16)
+    lib.det_ref_maps(img.ctypes.data, w, h, score.ctypes.data, box.ctypes.data)
+    return score, box
+
+
+def detect_pattern():
+    lib = load()
+    pat = np.zeros((256, 4), dtype=np.int8)
+    lib.det_ref_pattern(pat.ctypes.data)
+    return pat
 
 
 def match(size1, size2, kp1, kp2, matches, with_rotation=False, with_scale=False, threshold_factor=6.0):

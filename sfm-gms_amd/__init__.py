@@ -10,7 +10,7 @@ The directory name has a dash (it is fixed by the project layout), so load it wi
 ``importlib.import_module("sfm-gms_amd")``.
 """
 from .types import (KEYPOINT_DTYPE, DMATCH_DTYPE, PAIR_DTYPE, RESULT_DTYPE, GmsError,  # noqa: F401
-                    GMS_DESC_HAMMING256, GMS_DESC_L2_F32X128)
+                    GMS_DESC_HAMMING256, GMS_DESC_L2_F32X128, GMS_DETECT_BORDER)
 from .capi import load_library, library_path, EXPORTED_SYMBOLS  # noqa: F401
 from .api import matchGMS, GmsContext  # noqa: F401
 from .sharding import all_pairs_count, pair_from_index, shard_range  # noqa: F401
@@ -18,5 +18,5 @@ from .sharding import all_pairs_count, pair_from_index, shard_range  # noqa: F40
 __all__ = [
     "KEYPOINT_DTYPE", "DMATCH_DTYPE", "PAIR_DTYPE", "RESULT_DTYPE", "GmsError",
     "load_library", "library_path", "EXPORTED_SYMBOLS", "matchGMS", "GmsContext",
-    "all_pairs_count", "pair_from_index", "shard_range", "GMS_DESC_HAMMING256", "GMS_DESC_L2_F32X128",
+    "all_pairs_count", "pair_from_index", "shard_range", "GMS_DESC_HAMMING256", "GMS_DESC_L2_F32X128", "GMS_DETECT_BORDER",
 ]

@@ -215,6 +215,17 @@ class GmsContext:
                                                     d_filtered, d_results, d_gt or None, int(gt_stride), int(disp_ratio), d_disparity,
                                                     int(map_stride), d_work, d_stats), self._lib, "gms_disparity_batch_device")
 
+    def detect_workspace_bytes(self, width, height, n_images, max_keypoints):
+        return int(self._lib.gms_detect_workspace_bytes(int(width), int(height), int(n_images), int(max_keypoints)))
+
+    def detect_batch_device(self, d_images, n_images, width, height, threshold, max_keypoints, d_ws, ws_bytes, d_kp, d_desc, d_counts):
+        _check(self._lib.gms_detect_batch_device(self._h, d_images, int(n_images), int(width), int(height), int(threshold), int(max_keypoints),
+                                                 d_ws, int(ws_bytes), d_kp, d_desc, d_counts), self._lib, "gms_detect_batch_device")
+
+    def describe_device(self, d_image, width, height, d_kp, n, d_ws, ws_bytes, d_desc, d_status):
+        _check(self._lib.gms_describe_device(self._h, d_image, int(width), int(height), d_kp, int(n), d_ws, int(ws_bytes), d_desc, d_status),
+               self._lib, "gms_describe_device")
+
     def selftest_five_point(self, x1, x2):
         """gms_selftest_five_point: x1, x2 [n_samples, 5, 2] normalised points -> list of [k, 3, 3] model arrays, one per sample."""
         x1 = np.asarray(x1, dtype=np.float64).reshape(-1, 5, 2)

@@ -70,6 +70,52 @@ class DescriptorTable:
                                 f.d_frame_off.data_ptr(), f.n_frames, d_pairs, n_pairs, max_query, d_matches)
 
 
+def detect_images(ctx, images, threshold=20, max_keypoints=10000, device=None):
+    """gms_detect_batch_device on a stack of equally sized 8-bit grey images [n, H, W] (host array or device tensor): returns
+    (keypoints_per_image, rows_per_image) as host arrays -- KEYPOINT_DTYPE records in raster order and uint8 [n_i, 32] rows."""
+    dev = torch.device(device if device is not None else f"cuda:{ctx.device}")
+    imgs = images if torch.is_tensor(images) else torch.from_numpy(np.ascontiguousarray(images, dtype=np.uint8))
+    if imgs.dim() == 2:
+        imgs = imgs[None]
+    imgs = imgs.to(dev).contiguous()
+    n, h, w = imgs.shape
+    nb = ctx.detect_workspace_bytes(w, h, n, max_keypoints)
+    if nb == 0:
+        raise ValueError("bad image size")
+    d_ws = torch.zeros(nb, dtype=torch.uint8, device=dev)
+    d_kp = torch.zeros(max(n * max_keypoints, 1) * 28, dtype=torch.uint8, device=dev)
+    d_desc = torch.zeros(max(n * max_keypoints, 1) * 32, dtype=torch.uint8, device=dev)
+    d_counts = torch.zeros(n, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize(dev)
+    ctx.detect_batch_device(imgs.data_ptr(), n, w, h, threshold, max_keypoints, d_ws.data_ptr(), nb, d_kp.data_ptr(), d_desc.data_ptr(),
+                            d_counts.data_ptr())
+    ctx.synchronize()
+    counts = d_counts.cpu().numpy()
+    kp = d_kp.cpu().numpy()[: n * max_keypoints * 28].view(KEYPOINT_DTYPE).reshape(n, max_keypoints)
+    desc = d_desc.cpu().numpy()[: n * max_keypoints * 32].reshape(n, max_keypoints, 32)
+    return [kp[i, : counts[i]].copy() for i in range(n)], [desc[i, : counts[i]].copy() for i in range(n)]
+
+
+def describe_image(ctx, image, keypoints, device=None):
+    """gms_describe_device: directions and 32-byte rows at the given integer keypoints of one image -> (status, keypoints, rows)."""
+    dev = torch.device(device if device is not None else f"cuda:{ctx.device}")
+    img = torch.from_numpy(np.ascontiguousarray(image, dtype=np.uint8)).to(dev)
+    h, w = img.shape
+    kp = np.ascontiguousarray(keypoints, dtype=KEYPOINT_DTYPE)
+    nb = ctx.detect_workspace_bytes(w, h, 1, 0)
+    if nb == 0:
+        raise ValueError("bad image size")
+    d_ws = torch.zeros(nb, dtype=torch.uint8, device=dev)
+    d_kp = _to_dev(kp, dev) if len(kp) else torch.zeros(28, dtype=torch.uint8, device=dev)
+    d_desc = torch.zeros(max(len(kp), 1) * 32, dtype=torch.uint8, device=dev)
+    d_status = torch.zeros(1, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize(dev)
+    ctx.describe_device(img.data_ptr(), w, h, d_kp.data_ptr(), len(kp), d_ws.data_ptr(), nb, d_desc.data_ptr(), d_status.data_ptr())
+    ctx.synchronize()
+    out_kp = d_kp.cpu().numpy()[: len(kp) * 28].view(KEYPOINT_DTYPE).copy() if len(kp) else kp
+    return int(d_status.item()), out_kp, d_desc.cpu().numpy()[: len(kp) * 32].reshape(-1, 32)
+
+
 def match_pairs(ctx, descs, pairs, use_prepared=True):
     """Brute-force matches of `pairs` (PAIR_DTYPE; m = keypoints of frame_a) as a host DMATCH_DTYPE array laid out by match_off."""
     dev = descs.frames.device

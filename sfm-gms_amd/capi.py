@@ -13,6 +13,7 @@ EXPORTED_SYMBOLS = [
     "gms_gather_points_batch_device", "gms_find_essential_batch_device", "gms_recover_pose_batch_device", "gms_triangulate_batch_device",
     "gms_two_view_batch_device", "gms_disparity_batch_device", "gms_dataset_write", "gms_dataset_read", "gms_dataset_free", "gms_max_matches",
     "gms_last_hip_error", "gms_error_string", "gms_version", "gms_selftest_threshold", "gms_selftest_five_point",
+    "gms_detect_workspace_bytes", "gms_detect_batch_device", "gms_describe_device",
 ]
 
 _lib = None
@@ -68,6 +69,10 @@ def load_library():
     lib.gms_filter_device.argtypes = [vp, vp, vp, i32, vp, i32, i32, vp, i32, i32, dbl, vp, vp, vp]
     lib.gms_selftest_threshold.argtypes = [vp, vp, vp, vp, dbl, i32, vp]
     lib.gms_selftest_five_point.argtypes = [vp, vp, i32, vp, vp]
+    lib.gms_detect_workspace_bytes.argtypes = [i32, i32, i32, i32]
+    lib.gms_detect_workspace_bytes.restype = C.c_size_t
+    lib.gms_detect_batch_device.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp, C.c_size_t, vp, vp, vp]
+    lib.gms_describe_device.argtypes = [vp, vp, i32, i32, vp, i32, vp, C.c_size_t, vp, vp]
     lib.gms_max_matches.argtypes = []
     lib.gms_last_hip_error.argtypes = []
     lib.gms_error_string.argtypes = [i32]

@@ -1088,6 +1088,42 @@ int gms_disparity_batch_device(gms_ctx* c, const gms_keypoint* d_kp, const int64
     return GMS_OK;
 }
 
+size_t gms_detect_workspace_bytes(int width, int height, int n_images, int max_keypoints)
+{
+    return gms::detect_workspace_bytes(width, height, n_images, max_keypoints);
+}
+
+static bool detect_image_ok(int width, int height)
+{
+    return width > 2 * GMS_DETECT_BORDER && height > 2 * GMS_DETECT_BORDER && width <= 65535 && height <= 65535;
+}
+
+int gms_detect_batch_device(gms_ctx* c, const uint8_t* d_images, int n_images, int width, int height, int threshold, int max_keypoints,
+                            void* d_workspace, size_t workspace_bytes, gms_keypoint* d_keypoints, uint8_t* d_descriptors, int32_t* d_counts)
+{
+    if (!c || n_images < 0 || max_keypoints < 0 || threshold < 0 || threshold > 254 || !detect_image_ok(width, height)) return GMS_ERR_BAD_ARG;
+    if (n_images == 0) return GMS_OK;
+    if (!d_images || !d_workspace || !d_counts || (max_keypoints > 0 && (!d_keypoints || !d_descriptors))) return GMS_ERR_BAD_ARG;
+    if (workspace_bytes < gms::detect_workspace_bytes(width, height, n_images, max_keypoints)) return GMS_ERR_BAD_ARG;
+    std::lock_guard<std::mutex> lock(c->mu);
+    GMS_HIP(hipSetDevice(c->device));
+    GMS_HIP(gms::launch_detect(d_images, n_images, width, height, threshold, max_keypoints, d_workspace, d_keypoints, d_descriptors, d_counts,
+                               c->stream));
+    return GMS_OK;
+}
+
+int gms_describe_device(gms_ctx* c, const uint8_t* d_image, int width, int height, gms_keypoint* d_keypoints, int n,
+                        void* d_workspace, size_t workspace_bytes, uint8_t* d_descriptors, int32_t* d_status)
+{
+    if (!c || n < 0 || !detect_image_ok(width, height) || !d_image || !d_workspace || !d_status) return GMS_ERR_BAD_ARG;
+    if (n > 0 && (!d_keypoints || !d_descriptors)) return GMS_ERR_BAD_ARG;
+    if (workspace_bytes < gms::detect_workspace_bytes(width, height, 1, 0)) return GMS_ERR_BAD_ARG;
+    std::lock_guard<std::mutex> lock(c->mu);
+    GMS_HIP(hipSetDevice(c->device));
+    GMS_HIP(gms::launch_describe(d_image, width, height, d_keypoints, n, d_workspace, d_descriptors, d_status, c->stream));
+    return GMS_OK;
+}
+
 int gms_selftest_five_point(gms_ctx* c, const double* pts, int n_samples, double* models, int32_t* counts)
 {
     if (!c || n_samples < 0 || (n_samples > 0 && (!pts || !models || !counts))) return GMS_ERR_BAD_ARG;

@@ -125,6 +125,12 @@ hipError_t launch_disparity_batch(const gms_keypoint* d_kp, const int64_t* d_fra
                                   int n_pairs, int max_m, const gms_dmatch* d_filtered, const gms_pair_result* d_results, const uint8_t* d_gt,
                                   int64_t gt_stride, int disp_ratio, uint8_t* d_disparity, int64_t map_stride, uint32_t* d_work,
                                   gms_disparity_stats* d_stats, hipStream_t stream);
+// keypoint source (detect_kernels.hip)
+size_t     detect_workspace_bytes(int w, int h, int n_images, int max_keypoints);
+hipError_t launch_detect(const uint8_t* d_images, int n_images, int w, int h, int threshold, int max_keypoints, void* d_ws,
+                         gms_keypoint* d_kp, uint8_t* d_desc, int32_t* d_counts, hipStream_t stream);
+hipError_t launch_describe(const uint8_t* d_image, int w, int h, gms_keypoint* d_kp, int n, void* d_ws, uint8_t* d_desc, int32_t* d_status,
+                           hipStream_t stream);
 hipError_t launch_threshold(const int32_t* d_T, const int32_t* d_n, const int32_t* d_score, double factor,
                             int count, uint8_t* d_out, hipStream_t stream);
 

@@ -15,6 +15,7 @@ assert PAIR_DTYPE.itemsize == 24 and RESULT_DTYPE.itemsize == 16
 
 GMS_OK, GMS_ERR_BAD_ARG, GMS_ERR_DOMAIN, GMS_ERR_HIP, GMS_ERR_NO_DEVICE, GMS_ERR_CAPACITY = 0, -1, -2, -3, -4, -5
 GMS_ERR_NOT_RESERVED, GMS_ERR_IO, GMS_ERR_NO_MODEL = -6, -7, -8
+GMS_DETECT_BORDER = 16   # include/gms.h: keypoints of gms_detect_batch_device sit at least this far from every edge
 
 
 class GmsError(RuntimeError):
