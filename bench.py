@@ -199,6 +199,12 @@ def cgroup_cpu_quota():
         return None
 
 
+def cpu_threads_available():
+    affinity = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = cgroup_cpu_quota()
+    return affinity if quota is None else max(1, min(affinity, int(quota + 0.5)))
+
+
 def cpu_baseline(args, wl, pkg, rot, scale, budget_s):
     """The oracle (CPU restatement of the reference's matchGMS, one pair per thread) on the first pairs of chunk 0, at 1, 16 and
     all threads; median of --cpu-reps repetitions each, sample sizes chosen for about `budget_s` seconds of CPU work in all."""
@@ -292,9 +298,9 @@ def bf_gms_leg(ctx, wl, pkg, stream, kind, n_frames=64, n_pairs=1024, steps=3):
     desc_h = d_desc.cpu().numpy()
     kp_all = np.concatenate(frames)
     wh = np.array([SIZE] * n_frames, dtype=np.int32).reshape(-1)
-    bad = 0
-    idx = [0, n_pairs - 1]
-    for i in idx:
+    idx = sorted(set(int(v) for v in np.linspace(0, n_pairs - 1, 16)))      # sixteen pairs spread over the launch, first and last included
+
+    def check(i):   # (the C oracle releases the GIL: the sixteen checks run on the box's cores side by side)
         a, b = int(pairs["frame_a"][i]), int(pairs["frame_b"][i])
         want_m = oracle.bf_match(desc_h[a * n_kp:(a + 1) * n_kp], desc_h[b * n_kp:(b + 1) * n_kp], kind == "orb")
         got_m = d_matches[i * n_kp:(i + 1) * n_kp].cpu().numpy().view(np.uint8).reshape(-1).view(pkg.DMATCH_DTYPE)
@@ -303,8 +309,10 @@ def bf_gms_leg(ctx, wl, pkg, stream, kind, n_frames=64, n_pairs=1024, steps=3):
         failed, wout, wres, _ = oracle.batch(kp_all, table.frame_off_host, wh, sel, want_m, False, False, 6.0, 1)
         k = int(wres["n_inliers"][0])
         got_o = d_out[i * n_kp:i * n_kp + k].cpu().numpy().view(np.uint8).reshape(-1).view(pkg.DMATCH_DTYPE)
-        if failed or got_m.tobytes() != want_m.tobytes() or res[i].tobytes() != wres[0].tobytes() or got_o.tobytes() != wout[:k].tobytes():
-            bad += 1
+        return bool(failed or got_m.tobytes() != want_m.tobytes() or res[i].tobytes() != wres[0].tobytes() or got_o.tobytes() != wout[:k].tobytes())
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=min(16, cpu_threads_available())) as pool:
+        bad = int(sum(pool.map(check, idx)))
     evals = float(n_pairs) * n_kp * n_kp
     if kind == "orb":  # hamming = |a| + |b| - 2 a.b over the 256 bits as 0/1 FP4 elements on v_mfma_scale_f32_32x32x64_f8f6f4: 2 x 256 ops per evaluation
         roof = {"bound": "mfma", "achieved": evals * 512 / (match_ms * 1e-3) / 1e12, "peak": 10000.0, "unit": "TFLOP/s (fp4)",
@@ -319,7 +327,7 @@ def bf_gms_leg(ctx, wl, pkg, stream, kind, n_frames=64, n_pairs=1024, steps=3):
             "value": n_pairs * steps / wall, "unit": "pairs/s", "pairs_per_step": n_pairs, "matcher_ms_per_step": match_ms,
             "filter_ms_per_step": filter_ms, "mean_kept_per_pair": float(res["n_inliers"].mean()), "roofline": roof,
             "parity": {"pairs_checked": len(idx), "mismatches": bad, "bit_exact": bad == 0,
-                       "rule": "matches and filtered output of the first and last pair vs oracle/bf_ref.c + oracle/gms_ref.c"}}
+                       "rule": "matches and filtered output of sixteen pairs spread over the launch vs oracle/bf_ref.c + oracle/gms_ref.c"}}
 
 
 def zoom_leg(ctx, pkg, stream, dev, n_frames=64, n_kp=10000, n_pairs=1024, steps=6):
@@ -538,6 +546,58 @@ def poses_leg(ctx, pkg, stream, dev, n_frames=46, n_kp=10000, n_pairs=1024, step
                                "is an import library in the reference)"}}
 
 
+def pixels_leg(ctx, pkg, stream, dev, n_images=32, max_kp=10000, threshold=20, steps=5):
+    """f2: pixels resident in HBM -> keypoints + 32-byte rows for a batch of 1080p frames (the place of SIFT::create(10000)->
+    detectAndCompute, FeatureMatchUtil.cpp:9-12): gms_detect_batch_device, FAST-9 + steered BRIEF of the library's own. Synthetic
+    textured frames; image 0 and the last image checked against the CPU statement of the definition (oracle/detect_ref.c)."""
+    import torch
+    synth = importlib.import_module(PKG + ".synth")
+    imgs = synth.make_textured_images(5, n_images, size=SIZE)
+    w, h = SIZE
+    d_imgs = torch.from_numpy(imgs).to(dev)
+    nb = ctx.detect_workspace_bytes(w, h, n_images, max_kp)
+    d_ws = torch.zeros(nb, dtype=torch.uint8, device=dev)
+    d_kp = torch.zeros(n_images * max_kp * 28, dtype=torch.uint8, device=dev)
+    d_desc = torch.zeros(n_images * max_kp * 32, dtype=torch.uint8, device=dev)
+    d_counts = torch.zeros(n_images, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+
+    def run():
+        ctx.detect_batch_device(d_imgs.data_ptr(), n_images, w, h, threshold, max_kp, d_ws.data_ptr(), nb, d_kp.data_ptr(), d_desc.data_ptr(),
+                                d_counts.data_ptr())
+    with torch.cuda.stream(stream):
+        run()
+        ctx.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        for _ in range(steps):
+            run()
+        e1.record(stream)
+        ctx.synchronize()
+    ms = e0.elapsed_time(e1) / steps
+    counts = d_counts.cpu().numpy()
+    kp = d_kp.cpu().numpy().view(importlib.import_module(PKG + ".types").KEYPOINT_DTYPE).reshape(n_images, max_kp)
+    desc = d_desc.cpu().numpy().reshape(n_images, max_kp, 32)
+    oracle = oracle_module()
+    bad = 0
+    for i in (0, n_images - 1):
+        wk, wr = oracle.detect(imgs[i], threshold, max_kp)
+        same = len(wk) == counts[i] and wk.tobytes() == kp[i, :counts[i]].tobytes() and wr.tobytes() == desc[i, :counts[i]].tobytes()
+        bad += 0 if same else 1
+    algo = float(n_images) * w * h + float(counts.sum()) * 60.0     # pixels in, records + rows out
+    return {"workload": f"{n_images} frames of {w} x {h} (synthetic textured), threshold {threshold}, at most {max_kp} keypoints per frame",
+            "value": n_images / (ms * 1e-3), "unit": "frames/s", "ms_per_step": ms, "mpixels_per_s": n_images * w * h / (ms * 1e-3) / 1e6,
+            "mean_keypoints_per_frame": float(counts.mean()),
+            "roofline": {"bound": "hbm", "achieved": algo / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": algo / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "traffic": None,
+                         "kernel": "all seven kernels of the launch (HIP events around gms_detect_batch_device)",
+                         "algorithmic_bytes_per_launch": algo,
+                         "note": "1 byte per pixel in, 60 bytes per keypoint out; the launch also writes and re-reads 4 bytes per pixel of "
+                                 "score / candidate / box-sum planes"},
+            "parity": {"images_checked": 2, "mismatches": bad, "bit_exact": bad == 0,
+                       "rule": "keypoint records, their order and the descriptor bits vs oracle/detect_ref.c (the definition; not cv::ORB)"}}
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -661,6 +721,9 @@ def main():
             # f3: the consumer behind the filter, batched (SfMUtil.cpp:25-82)
             line["descriptors_to_poses"] = poses_leg(ctx, pkg, stream, dev)
             ok = ok and line["descriptors_to_poses"]["parity"]["ok"]
+            # f2: the keypoint source in front of the matcher
+            line["pixels_to_keypoints"] = pixels_leg(ctx, pkg, stream, dev)
+            ok = ok and line["pixels_to_keypoints"]["parity"]["bit_exact"]
         print(json.dumps(line))
         sys.stdout.flush()
     distmod.barrier(dist)

@@ -94,6 +94,32 @@ __device__ __forceinline__ int64_t table_total_kp(const FilterParams& p)
     return (magic.x == kTableMagic0 && magic.y == kTableMagic1) ? total : (int64_t)-1;
 }
 
+// A value every lane of the wave holds alike (read through a pointer the compiler cannot prove read-only, so it arrives by vector
+// load): moved to scalar registers, where it costs no vector register for the rest of the kernel.
+// (inline assembly with a scalar-register result: the builtin is folded away once the compiler has proven the value uniform, and the
+//  value then stays in the vector registers it was loaded into)
+__device__ __forceinline__ int uniform(int v)
+{
+    int s;
+    asm volatile("v_readfirstlane_b32 %0, %1" : "=s"(s) : "v"(v));
+    return s;
+}
+__device__ __forceinline__ int64_t uniform(int64_t v)
+{
+    const uint32_t lo = (uint32_t)uniform((int)(uint32_t)v), hi = (uint32_t)uniform((int)(uint32_t)((uint64_t)v >> 32));
+    return (int64_t)(((uint64_t)hi << 32) | lo);
+}
+__device__ __forceinline__ gms_pair uniform(const gms_pair& pr)
+{
+    gms_pair u;
+    u.frame_a = uniform(pr.frame_a);
+    u.frame_b = uniform(pr.frame_b);
+    u.m = uniform(pr.m);
+    u.reserved = 0;
+    u.match_off = uniform(pr.match_off);
+    return u;
+}
+
 // lane ^ 1 exchange on the VALU (DPP quad_perm [1,0,3,2]), no LDS round trip
 __device__ __forceinline__ uint32_t dpp_xor1(uint32_t x)
 {

@@ -267,7 +267,7 @@ __device__ __forceinline__ void hash_pair(const FilterParams& p, uint32_t* smem,
     const int lane = tid & 63;
     const int wave = tid >> 6;
 
-    const gms_pair pr = p.pairs[pair_idx];
+    const gms_pair pr = uniform(p.pairs[pair_idx]);
     const int m = pr.m;
     const gms_dmatch* __restrict__ matches = p.matches + pr.match_off;
 
@@ -938,13 +938,13 @@ __device__ __forceinline__ bool dense_pair(const FilterParams& p, uint32_t* smem
     const int m_stride = dealt ? (NT / 64) * 8 : NT;
     auto match_of = [&](int k) -> int { return m_base + k * m_stride; };
 
-    const gms_pair pr = p.pairs[pair_idx];
+    const gms_pair pr = uniform(p.pairs[pair_idx]);
     const int m = pr.m;
     if (p.with_scale || p.right_w[0] != kDenseRightW || p.right_h[0] != kDenseRightW || m <= 0 || m > kMcap ||
         pr.frame_a < 0 || pr.frame_a >= p.n_frames || pr.frame_b < 0 || pr.frame_b >= p.n_frames)
         return false;
-    const int64_t offA = p.frame_off[pr.frame_a], offB = p.frame_off[pr.frame_b];
-    const int nA = (int)(p.frame_off[pr.frame_a + 1] - offA), nB = (int)(p.frame_off[pr.frame_b + 1] - offB);
+    const int64_t offA = uniform(p.frame_off[pr.frame_a]), offB = uniform(p.frame_off[pr.frame_b]);
+    const int nA = (int)(uniform(p.frame_off[pr.frame_a + 1]) - offA), nB = (int)(uniform(p.frame_off[pr.frame_b + 1]) - offB);
     if (nA <= 0 || nB <= 0) return false;
     const gms_dmatch* __restrict__ matches = p.matches + pr.match_off;
     // the frame table's code words (written by normalize_kernel behind the points): frame A's left codes, frame B's right codes
@@ -1482,7 +1482,7 @@ __device__ __forceinline__ bool dense_scales_pair(const FilterParams& p, uint32_
     const int lane = tid & 63;
     const int wave = tid >> 6;
 
-    const gms_pair pr = p.pairs[pair_idx];
+    const gms_pair pr = uniform(p.pairs[pair_idx]);
     const int m = pr.m;
     if (!p.with_scale || m <= 0 || m > kMcap || pr.frame_a < 0 || pr.frame_a >= p.n_frames || pr.frame_b < 0 ||
         pr.frame_b >= p.n_frames)

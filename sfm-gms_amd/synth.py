@@ -226,3 +226,25 @@ def make_zoom_sequence(case_id, n_frames, size=(1920, 1080), n_kp=10000, zoom=2.
         xy[:, 1] = np.clip(xy[:, 1], 0, h - 1.001)
         frames.append(make_keypoints(xy.astype(np.float32)))
     return frames
+
+
+def make_textured_images(case_id, n_images, size=(1920, 1080), n_boxes=9000, noise=3):
+    """8-bit grey test images with corners to find: overlapping random rectangles of random grey levels plus a little noise;
+    image i + 1 is image i's scene shifted by a few pixels (a sequence, not independent frames). Returns uint8 [n, H, W]."""
+    rng = rng_for(case_id ^ 0x1A6E)
+    w, h = size
+    pad = 4 * n_images + 8
+    canvas = np.full((h + pad, w + pad), 128, dtype=np.int16)
+    x0 = rng.integers(0, w + pad - 4, n_boxes)
+    y0 = rng.integers(0, h + pad - 4, n_boxes)
+    bw = rng.integers(6, 60, n_boxes)
+    bh = rng.integers(6, 60, n_boxes)
+    lv = rng.integers(20, 236, n_boxes)
+    for i in range(n_boxes):
+        canvas[y0[i]:y0[i] + bh[i], x0[i]:x0[i] + bw[i]] = lv[i]
+    out = np.empty((n_images, h, w), dtype=np.uint8)
+    for i in range(n_images):
+        dx, dy = 3 * i, i
+        view = canvas[dy:dy + h, dx:dx + w] + rng.integers(-noise, noise + 1, (h, w), dtype=np.int16)
+        out[i] = np.clip(view, 0, 255).astype(np.uint8)
+    return out
