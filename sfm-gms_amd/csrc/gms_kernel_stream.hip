@@ -30,6 +30,18 @@
 
 #include "gms_device_common.h"
 
+// Diagnostic build only (-DGMS_PHASE_TIMING, libgms_hip_diag.so; tools/stream_phase_timing.py): thread 0 of every stream_filter_kernel
+// workgroup leaves the shader-clock cycles of its phases in p.diag[workgroup][phase]. No stamp exists in the product build.
+#ifdef GMS_PHASE_TIMING
+#define GMS_SSTAMP_DECL unsigned long long sph_[8] = {0}; unsigned long long st_prev_ = __builtin_readcyclecounter();
+#define GMS_SSTAMP(k) do { unsigned long long t_ = __builtin_readcyclecounter(); sph_[k] += t_ - st_prev_; st_prev_ = t_; } while (0)
+#define GMS_SSTAMP_FLUSH do { if (threadIdx.x == 0 && p.diag) { for (int k_ = 0; k_ < 8; ++k_) p.diag[(size_t)blockIdx.x * 8 + k_] = sph_[k_]; } } while (0)
+#else
+#define GMS_SSTAMP_DECL
+#define GMS_SSTAMP(k)
+#define GMS_SSTAMP_FLUSH
+#endif
+
 namespace gms {
 static size_t align16s(size_t x) { return (x + 15) & ~(size_t)15; }
 namespace {
@@ -209,6 +221,7 @@ __device__ __forceinline__ void stream_scale(const FilterParams& p, const Stream
                                              const int g, const int band)
 {
     constexpr int kChunk = 16;
+    GMS_SSTAMP_DECL
     const int tid = threadIdx.x;
     const gms_pair pr = p.pairs[pi];
     const int m = pr.m;
@@ -268,9 +281,11 @@ __device__ __forceinline__ void stream_scale(const FilterParams& p, const Stream
             {   // motion.setTo(0) for the rows held, headers included
                 const uint4 z4 = make_uint4(0, 0, 0, 0);
                 uint4* d4 = reinterpret_cast<uint4*>(smem);
+                GMS_SSTAMP(0);   // start: pair, flags, row counts
                 for (uint32_t i = tid; i < (n_held * stride + 15u) / 16u; i += 1024) d4[i] = z4;
             }
             __syncthreads();
+            GMS_SSTAMP(1);   // clear + barrier
             // ---- assignMatchPairs for the rows held: entries of grid-type-1 rows hlo - 1 (the y-shifted types move a match one row
             //      down) .. hhi - 1. +1 on the entry's byte; the count it produced goes into the row's running arg-max.
             {
@@ -300,6 +315,7 @@ __device__ __forceinline__ void stream_scale(const FilterParams& p, const Stream
                 });
             }
             __syncthreads();
+            GMS_SSTAMP(2);   // bin + barrier
             if (misc[8] != 0u) {  // a (left cell, right cell) pair above 255 matches (workgroup-uniform): the general kernel's pair
                 if (tid == 0) {
                     if (!(atomicOr(&w.flags[pi], kSFlagGeneral) & kSFlagGeneral) && p.overflow_events) atomicAdd(p.overflow_events, 1u);
@@ -383,6 +399,7 @@ __device__ __forceinline__ void stream_scale(const FilterParams& p, const Stream
                 }
             }
             __syncthreads();
+            GMS_SSTAMP(3);   // verify + barrier
             // ---- mark: cellPairs[l] == r for the entries whose left cell is one of the band's own; the rotations that accept the cell go
             //      into the match's byte of this (scale, grid type)'s array, by the match's original index
             stream(row_start[max(lo - 1, 0)], row_start[hi], [] {}, [&](const uint2& e, int) {
@@ -394,6 +411,8 @@ __device__ __forceinline__ void stream_scale(const FilterParams& p, const Stream
                     if (x < 256u && x != 0u) rb[entry_orig(e)] = (uint8_t)x;
                 }
             });
+            GMS_SSTAMP(4);   // mark
+            GMS_SSTAMP_FLUSH;
         }
     }
 }
