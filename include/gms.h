@@ -19,6 +19,7 @@
 #ifndef MI355_GMS_H
 #define MI355_GMS_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus

@@ -429,6 +429,9 @@ GMS_HD void polish_solution(const Mem& basis, double& x, double& y, double& z)
                 r[1 + 3 * a + b] = 2.0 * (G[3 * a] * E[b] + G[3 * a + 1] * E[3 + b] + G[3 * a + 2] * E[6 + b]) - tr * E[3 * a + b];
     };
     double E[9], r[10];
+#if defined(TV_DIAG) && TV_DIAG == 1   // (timing-only diagnostic builds: tools/fivepoint_bench.py)
+    return;
+#endif
     eval(x, y, z, E, r);
     double r2 = 0.0;
     for (int k = 0; k < 10; ++k) r2 += r[k] * r[k];
@@ -530,7 +533,13 @@ GMS_HD int five_point(const double x1[5], const double y1[5], const double x2[5]
     int n = 10;
     while (n > 0 && c(n) == 0.0) --n;
     if (n == 0) return 0;
+#if defined(TV_DIAG) && TV_DIAG == 2
+    return 0;
+#endif
     aberth_roots(c, n, re, im);
+#if defined(TV_DIAG) && TV_DIAG == 3
+    return 0;
+#endif
     // the real roots (|imag| < 1e-10), polished by two Newton steps on the real polynomial
     int nz = 0;
     for (int i = 0; i < n; ++i) {

@@ -18,4 +18,19 @@ for name, c in cases.domain_error_cases().items():
 synth = importlib.import_module("sfm-gms_amd.synth")
 d = synth.sequence_descriptors(5, 2, 400, "orb"); gms_oracle.bf_match(d[0], d[1], True)
 d = synth.sequence_descriptors(5, 2, 400, "sift"); gms_oracle.bf_match(d[0], d[1], False)
-print("asan/ubsan clean:", n, "filter calls + matcher calls")
+# the multi-threaded driver with its per-thread scratch (the cpu_baseline leg of bench.py) and the keypoint source's statement
+frames = synth.make_sequence(7, 6, size=(1280, 720), n_kp=1500)
+dist = importlib.import_module("sfm-gms_amd.dist")
+pairs = dist.pair_table(6, 0, 12, 1500)
+matches = np.concatenate([dist.synth_matches_host(k, 1500, 0.5) for k in range(12)])
+foff = np.arange(7, dtype=np.int64) * 1500
+wh = np.array([(1280, 720)] * 6, dtype=np.int32).reshape(-1)
+for rot, scale in ((False, False), (True, True)):
+    failed, out, res, _ = gms_oracle.batch(np.concatenate(frames), foff, wh, pairs, matches, rot, scale, 6.0, 4)
+    assert failed == 0; n += 12
+imgs = synth.make_textured_images(3, 1, size=(320, 200))
+kp, rows = gms_oracle.detect(imgs[0], 15, 400)
+assert len(kp) > 50 and gms_oracle.describe(imgs[0], kp)[2].tobytes() == rows.tobytes()
+kp2, _ = gms_oracle.detect(imgs[0], 15, 40)
+assert len(kp2) == 40
+print("asan/ubsan clean:", n, "filter calls (one-shot and 4-thread batch) + matcher calls + detector calls")
