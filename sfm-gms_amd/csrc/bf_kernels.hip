@@ -216,12 +216,13 @@ constexpr int kTileRows = 64;                    // train rows per LDS tile
 constexpr uint32_t kRowBytes = 128u;             // a prepared row, either kind
 constexpr uint32_t kRowPitch = kRowBytes + 16u;  // + 16 B: the rows a ds_read_b128 touches spread over the banks
 constexpr uint32_t kTileBytes = kTileRows * kRowPitch;               // 9216
-constexpr int kSub = 4;                          // tiles per staging step (one workgroup barrier per step)
-constexpr int kStepRows = kSub * kTileRows;      // 256: one norm per thread
-constexpr uint32_t kStepBytes = kSub * kTileBytes;                   // 36 864
+constexpr int kSub = 2;                          // tiles per staging step (one workgroup barrier per step)
+constexpr int kStepRows = kSub * kTileRows;      // 128
+constexpr uint32_t kStepBytes = kSub * kTileBytes;                   // 18 432
 constexpr uint32_t kNormOff = 2u * kStepBytes;                       // two steps' tiles, then two steps' norms
-constexpr uint32_t kMfmaLdsBytes = kNormOff + 2u * kStepRows * 4u;   // 75 776: two workgroups per CU
-constexpr int kQueriesPerBlock = 256;            // 4 waves x 64 query columns
+constexpr uint32_t kMfmaLdsBytes = kNormOff + 2u * kStepRows * 4u;   // 37 888
+constexpr int kNQ = 4;                           // 32-column query sets (= accumulators) per wave: 128 query columns
+constexpr int kQueriesPerBlock = 4 * 32 * kNQ;   // 512: 4 waves x 128 query columns
 constexpr int kKSteps = 4;                       // MFMAs per (tile, accumulator): 4 x 32 bytes of a row
 constexpr int kFp4UnitScale = 0x7F7F7F7F;        // E8M0 127 = 2^0 in every byte
 constexpr int kHamChunk = 32768;                 // Hamming: train rows whose index rides in one fp32 fraction (a multiple of kStepRows)
@@ -282,8 +283,7 @@ bf_mfma_kernel(const uint4* __restrict__ rows, const uint32_t* __restrict__ norm
     const int col = lane & 31, half = lane >> 5;
     const Val kBig = HAM ? (Val)3.0e38f : (Val)0x3FFFFFFF;
     if (f.nB <= 0) {  // nothing to match against: the reference's matcher returns no match for the row
-        const int q = q0 + tid;
-        if (q < f.m) {
+        for (int q = q0 + tid; q < min(f.m, q0 + kQueriesPerBlock); q += 256) {
             gms_dmatch m;
             m.queryIdx = q;
             m.trainIdx = -1;
@@ -294,13 +294,13 @@ bf_mfma_kernel(const uint4* __restrict__ rows, const uint32_t* __restrict__ norm
         return;
     }
 
-    // ---- this wave's 64 query columns as B operands, resident for the whole kernel:
+    // ---- this wave's 128 query columns as B operands, resident for the whole kernel:
     //      bq[c][s] = transformed Q[32 c + col][bytes 32 s + 16 half .. + 16)
-    uint4 bq[2][kKSteps];
-    int qrow[2];
+    uint4 bq[kNQ][kKSteps];
+    int qrow[kNQ];
 #pragma unroll
-    for (int c = 0; c < 2; ++c) {
-        qrow[c] = q0 + wave * 64 + c * 32 + col;
+    for (int c = 0; c < kNQ; ++c) {
+        qrow[c] = q0 + wave * (32 * kNQ) + c * 32 + col;
         const uint4* src = rows + (size_t)(f.offA + min(qrow[c], f.m - 1)) * (kRowBytes / 16);
 #pragma unroll
         for (int s = 0; s < kKSteps; ++s) {
@@ -309,21 +309,26 @@ bf_mfma_kernel(const uint4* __restrict__ rows, const uint32_t* __restrict__ norm
             else bq[c][s] = make_uint4(~r4.x, ~r4.y, ~r4.z, ~r4.w);
         }
     }
-    Val bestv[2] = {kBig, kBig};    // L2: the smallest block minimum so far ...
-    Val bestd[2] = {kBig, kBig};    // Hamming: the smallest distance part (distance - |b|) of the chunks folded so far ...
-    int bestt[2] = {0, 0};          // L2: the block (of 32 train rows) bestv came from, the first one that reached it; Hamming: bestd's train row
-    int ties[2] = {0, 0};           // L2: in how many later blocks the minimal P was seen again ...
-    int bestt2[2] = {0, 0};         // ... and the last of them
-    int whalf[2] = {half, half};    // L2: which lane half's rows of the winning block hold the minimum (2 = either)
+    Val bestv[kNQ], bestd[kNQ];   // L2: the smallest block minimum so far / Hamming: the smallest distance part (distance - |b|) of the chunks folded so far
+    int bestt[kNQ];               // L2: the block (of 32 train rows) bestv came from, the first one that reached it; Hamming: bestd's train row
+    int ties[kNQ], bestt2[kNQ];   // L2: in how many later blocks the minimal P was seen again, and the last of them
+    int whalf[kNQ];               // L2: which lane half's rows of the winning block hold the minimum (2 = either)
+    Val mn[kNQ];                  // the running minimum (L2: of the block being folded; Hamming: of everything since the last chunk fold)
+#pragma unroll
+    for (int c = 0; c < kNQ; ++c) {
+        bestv[c] = bestd[c] = mn[c] = kBig;
+        bestt[c] = ties[c] = bestt2[c] = 0;
+        whalf[c] = half;
+    }
 
     const uint4* __restrict__ trB = rows + (size_t)f.offB * (kRowBytes / 16);
     const uint32_t* __restrict__ nrmB = norms + f.offB;
     const int n_tiles = (f.nB + kTileRows - 1) / kTileRows;
-    // stage step st (kSub tiles = 256 rows x 128 B = 2048 16-byte pieces, eight per thread) into buffer st & 1; rows beyond nB repeat
+    // stage step st (kSub tiles = 128 rows x 128 B = 1024 16-byte pieces, four per thread) into buffer st & 1; rows beyond nB repeat
     // the last row with a norm that never wins
     const int n_steps = (n_tiles + kSub - 1) / kSub;
-    static_assert(kStepRows * (kRowBytes / 16) == 8 * 256, "eight named staging registers");
-    struct Stage { uint4 v0, v1, v2, v3, v4, v5, v6, v7; uint32_t nv; };  // (named members, returned by value: stays in registers)
+    static_assert(kStepRows * (kRowBytes / 16) == 4 * 256, "four named staging registers");
+    struct Stage { uint4 v0, v1, v2, v3; uint32_t nv; };  // (named members, returned by value: stays in registers)
     auto stage_load = [&](int st) -> Stage {
         Stage sg;
         auto piece = [&](int i) -> uint4 {
@@ -331,10 +336,9 @@ bf_mfma_kernel(const uint4* __restrict__ rows, const uint32_t* __restrict__ norm
             return trB[(size_t)min(st * kStepRows + (pc >> 3), f.nB - 1) * 8 + (pc & 7)];
         };
         sg.v0 = piece(0); sg.v1 = piece(1); sg.v2 = piece(2); sg.v3 = piece(3);
-        sg.v4 = piece(4); sg.v5 = piece(5); sg.v6 = piece(6); sg.v7 = piece(7);
-        // (the norm stays raw here: turning it into the accumulator's start value would wait for it -- and with it for the eight
-        //  row loads just issued -- a whole memory latency before the step's products; stage_store does that a step later)
-        sg.nv = nrmB[min(st * kStepRows + tid, f.nB - 1)];
+        // (the norm stays raw here: turning it into the accumulator's start value would wait for it -- and with it for the row loads
+        //  just issued -- a whole memory latency before the step's products; stage_store does that a step later)
+        sg.nv = nrmB[min(st * kStepRows + (tid & (kStepRows - 1)), f.nB - 1)];
         return sg;
     };
     auto stage_store = [&](int st, const Stage& sg) {
@@ -344,23 +348,26 @@ bf_mfma_kernel(const uint4* __restrict__ rows, const uint32_t* __restrict__ norm
             *reinterpret_cast<uint4*>(base + (uint32_t)(pc >> 3) * kRowPitch + (uint32_t)(pc & 7) * 16u) = v;
         };
         put(0, sg.v0); put(1, sg.v1); put(2, sg.v2); put(3, sg.v3);
-        put(4, sg.v4); put(5, sg.v5); put(6, sg.v6); put(7, sg.v7);
-        const int r = st * kStepRows + tid;
-        Val nv = kBig;
-        if (r < f.nB) {
-            if constexpr (HAM) nv = __uint_as_float(sg.nv) + (float)(r & (kHamChunk - 1)) * (1.0f / (float)kHamChunk);   // popcount + row / 32768
-            else nv = (int32_t)sg.nv >> 1;                                                                            // floor(w / 2)
+        if (tid < kStepRows) {
+            const int r = st * kStepRows + tid;
+            Val nv = kBig;
+            if (r < f.nB) {
+                if constexpr (HAM) nv = __uint_as_float(sg.nv) + (float)(r & (kHamChunk - 1)) * (1.0f / (float)kHamChunk);   // popcount + row / 32768
+                else nv = (int32_t)sg.nv >> 1;                                                                            // floor(w / 2)
+            }
+            reinterpret_cast<Val*>(lds + kNormOff)[(st & 1) * kStepRows + tid] = nv;
         }
-        reinterpret_cast<Val*>(lds + kNormOff)[(st & 1) * kStepRows + tid] = nv;
     };
     // ---- the main loop, scheduled by hand in the source (scheduling barriers keep the compiler from re-ordering it).
-    // A BLOCK = 32 train rows x the wave's 64 query columns = two accumulators (c0: columns 0..31, c1: 32..63), eight MFMAs in four
-    // k-steps. C-in = the norm of the accumulator's row (rows (reg & 3) + 8 (reg >> 2) + 4 half of the block), so after the K loop the
-    // accumulator holds |a| - 2 a.b (Hamming) / h + a'.~b' (L2). The matrix pipe takes an MFMA every 32 cycles and leaves the
-    // vector ALU free for 24 of them, so every k-step's pair of MFMAs is followed by a share of the work on the block BEFORE (`done`):
-    // its minimum per query column (v_min3) and then the comparison with the best so far. The LDS reads of the next k-step /
-    // next block are issued a k-step ahead. Every step runs all four tiles: rows past the end carry norms that never win.
-    struct Block { Acc c0, c1; };
+    // A BLOCK = 32 train rows x the wave's 128 query columns = four accumulators in two PAIRS (A: columns 0..63, B: 64..127), sixteen
+    // MFMAs: the four A pieces of the block feed pair A's four k-steps, then pair B's -- every staged row and every LDS read serves
+    // twice the products of the two-accumulator kernel of round 2 (the kernel runs at the chip's power limit: fewer bytes moved per
+    // product is what buys throughput). C-in = the norm of the accumulator's row (rows (reg & 3) + 8 (reg >> 2)
+    // + 4 half of the block), so after the K loop an accumulator holds |a| - 2 a.b + row / 32768 (Hamming) / h + a'.~b' (L2). The
+    // matrix pipe takes an MFMA every 32 cycles and leaves the vector ALU free for most of them: while one pair's MFMAs run, the
+    // OTHER pair's finished accumulators are folded into the minima (v_min3), so all four accumulators are live and none is copied.
+    // The LDS reads of the next block's A pieces go out under pair A's k-steps, its norms under pair B's (after B's first k-step
+    // has consumed this block's). Every step runs both tiles: rows past the end carry norms that never win.
     const uint32_t a_lane = (uint32_t)col * kRowPitch + 16u * (uint32_t)half;   // this lane's A row inside a block + its 16 bytes of a k-step
     auto lds_a = [&](int st, int blk, int s) -> uint4 {   // blk = 2 * tile + row block
         return *reinterpret_cast<const uint4*>(lds + (uint32_t)(st & 1) * kStepBytes + (uint32_t)blk * (32u * kRowPitch) + a_lane + 32u * (uint32_t)s);
@@ -384,18 +391,18 @@ bf_mfma_kernel(const uint4* __restrict__ rows, const uint32_t* __restrict__ norm
             return __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_bit_cast(i32x4, a), __builtin_bit_cast(i32x4, b), c, 0, 0, 0);
         }
     };
-    Val mn[2] = {kBig, kBig};   // the minimum of `done`
-    auto min_regs = [&](const Block& bl, int from, int to) {
+    Acc acc[kNQ];   // pair A = acc[0], acc[1]; pair B = acc[2], acc[3]
+    auto min_regs = [&](int pair, int from, int to) {   // fold registers [from, to) of the pair's two accumulators
 #pragma unroll
         for (int reg = from; reg < to; ++reg) {
-            mn[0] = min(mn[0], bl.c0[reg]);
-            mn[1] = min(mn[1], bl.c1[reg]);
+            mn[2 * pair] = min(mn[2 * pair], acc[2 * pair][reg]);
+            mn[2 * pair + 1] = min(mn[2 * pair + 1], acc[2 * pair + 1][reg]);
         }
     };
-    auto block_compare = [&](int blk) {   // L2: the first block that reached the minimum stays (Hamming: mn simply keeps running)
+    auto block_compare = [&](int pair, int blk) {   // L2: the first block that reached the minimum stays (Hamming: mn simply keeps running)
         if constexpr (!HAM) {
 #pragma unroll
-            for (int c = 0; c < 2; ++c) {
+            for (int c = 2 * pair; c < 2 * pair + 2; ++c) {
                 const bool lt = mn[c] < bestv[c], eq = mn[c] == bestv[c];
                 ties[c] = lt ? 0 : ties[c] + (eq ? 1 : 0);
                 bestt2[c] = eq ? blk : bestt2[c];
@@ -407,7 +414,7 @@ bf_mfma_kernel(const uint4* __restrict__ rows, const uint32_t* __restrict__ norm
     };
     auto ham_fold = [&](int chunk) {   // Hamming: the running minimum of a chunk of kHamChunk rows into (distance part, row)
 #pragma unroll
-        for (int c = 0; c < 2; ++c) {
+        for (int c = 0; c < kNQ; ++c) {
             const float d = floorf((float)mn[c]);   // equal distances: the earlier chunk holds the lower rows
             const bool lt = d < (float)bestd[c];
             bestt[c] = lt ? chunk * kHamChunk + (int)(((float)mn[c] - d) * (float)kHamChunk) : bestt[c];
@@ -415,75 +422,85 @@ bf_mfma_kernel(const uint4* __restrict__ rows, const uint32_t* __restrict__ norm
             mn[c] = kBig;
         }
     };
-    // staging runs two steps ahead: step st + 2 is requested from memory while step st + 1, requested a step ago, goes into the other
-    // LDS buffer (last read before the barrier that ended step st - 1) -- all of it BEFORE the step's products, which then form one
-    // straight piece of code up to the barrier
+    auto set_big = [&](int pair) {
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) acc[2 * pair][reg] = acc[2 * pair + 1][reg] = kBig;
+    };
+    // staging runs a step ahead in memory and a step ahead in LDS: step st + 2 is requested while step st + 1, requested a step ago,
+    // goes into the other LDS buffer (last read before the barrier that ended step st - 1) -- all of it BEFORE the step's products
     Stage sv = stage_load(0);
     stage_store(0, sv);
     if (n_steps > 1) sv = stage_load(1);
     __syncthreads();
-    Block done;   // at first a dummy that beats nothing
-#pragma unroll
-    for (int reg = 0; reg < 16; ++reg) done.c0[reg] = done.c1[reg] = kBig;
+    set_big(0);   // at first dummies that beat nothing
+    set_big(1);
     for (int st = 0; st < n_steps; ++st) {
         if constexpr (HAM) {
-            if (st != 0 && (st & (kHamChunk / kStepRows - 1)) == 0) {   // a new chunk of rows (rare): settle the one before, lagging block included
-                min_regs(done, 0, 16);
+            if (st != 0 && (st & (kHamChunk / kStepRows - 1)) == 0) {   // a new chunk of rows (rare): settle the one before, the lagging pair included
+                min_regs(1, 0, 16);
                 ham_fold(st / (kHamChunk / kStepRows) - 1);
-#pragma unroll
-                for (int reg = 0; reg < 16; ++reg) done.c0[reg] = done.c1[reg] = kBig;
+                set_big(1);
             }
         }
 #if !defined(BF_DIAG) || BF_DIAG != 2
         if (st + 1 < n_steps) stage_store(st + 1, sv);
         if (st + 2 < n_steps) sv = stage_load(st + 2);
 #endif
-        // the four A pieces of a block are read a whole block ahead (LDS latency under load is several MFMAs long)
         uint4 a_cur[kKSteps], a_nxt[kKSteps];
 #pragma unroll
         for (int s = 0; s < kKSteps; ++s) a_cur[s] = lds_a(st, 0, s);
         uint4 n0 = lds_n(st, 0, 0), n1 = lds_n(st, 0, 1), n2 = lds_n(st, 0, 2), n3 = lds_n(st, 0, 3);
 #pragma unroll
         for (int blk = 0; blk < 2 * kSub; ++blk) {
-            Block cur;
-            {   // k-step 0; `done`'s last MFMAs are still in the pipe: the comparison of the block before `done` goes here
-                const Acc nrm = as_acc(n0, n1, n2, n3);
-                cur.c1 = mfma(a_cur[0], bq[1][0], nrm);
-                cur.c0 = mfma(a_cur[0], bq[0][0], nrm);
-                if (blk + 1 < 2 * kSub) a_nxt[0] = lds_a(st, blk + 1, 0);
-                block_compare(st * 2 * kSub + blk - 2);
-                __builtin_amdgcn_sched_barrier(0);
-            }
+            const int gblk = st * 2 * kSub + blk;   // the block's number in the frame
+            const bool more = blk + 1 < 2 * kSub;
+            const Acc nrm = as_acc(n0, n1, n2, n3);
+            // ---- pair A; pair B of the block before is folded meanwhile (its last MFMAs are still in the pipe during k-step 0)
+            acc[1] = mfma(a_cur[0], bq[1][0], nrm);
+            acc[0] = mfma(a_cur[0], bq[0][0], nrm);
+            if (more) a_nxt[0] = lds_a(st, blk + 1, 0);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int s = 1; s < kKSteps; ++s) {
-                cur.c0 = mfma(a_cur[s], bq[0][s], cur.c0);
-                cur.c1 = mfma(a_cur[s], bq[1][s], cur.c1);
-                if (blk + 1 < 2 * kSub) {
-                    a_nxt[s] = lds_a(st, blk + 1, s);
+                acc[0] = mfma(a_cur[s], bq[0][s], acc[0]);
+                acc[1] = mfma(a_cur[s], bq[1][s], acc[1]);
+                if (more) a_nxt[s] = lds_a(st, blk + 1, s);
+                min_regs(1, s == 1 ? 0 : (s == 2 ? 6 : 11), s == 1 ? 6 : (s == 2 ? 11 : 16));
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // ---- pair B; pair A of this block is folded meanwhile
+            acc[3] = mfma(a_cur[0], bq[3][0], nrm);
+            acc[2] = mfma(a_cur[0], bq[2][0], nrm);
+            block_compare(1, gblk - 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int s = 1; s < kKSteps; ++s) {
+                acc[2] = mfma(a_cur[s], bq[2][s], acc[2]);
+                acc[3] = mfma(a_cur[s], bq[3][s], acc[3]);
+                if (more) {
                     if (s == 1) { n0 = lds_n(st, blk + 1, 0); n1 = lds_n(st, blk + 1, 1); }
                     if (s == 2) { n2 = lds_n(st, blk + 1, 2); n3 = lds_n(st, blk + 1, 3); }
                 }
-                min_regs(done, s == 1 ? 0 : (s == 2 ? 6 : 11), s == 1 ? 6 : (s == 2 ? 11 : 16));
+                min_regs(0, s == 1 ? 0 : (s == 2 ? 6 : 11), s == 1 ? 6 : (s == 2 ? 11 : 16));
                 __builtin_amdgcn_sched_barrier(0);
             }
-            done = cur;
+            block_compare(0, gblk);
 #pragma unroll
             for (int s = 0; s < kKSteps; ++s) a_cur[s] = a_nxt[s];
         }
-#if !defined(BF_DIAG) || BF_DIAG != 1   // (BF_DIAG: timing-only diagnostic builds with wrong results, never the product -- DESIGN.md section 7)
+#if !defined(BF_DIAG) || BF_DIAG != 1   // (BF_DIAG: timing-only diagnostic builds with wrong results, never the product -- DESIGN.md section 4.5)
         __syncthreads();
 #endif
     }
-    block_compare(n_steps * 2 * kSub - 2);
-    min_regs(done, 0, 16);
-    block_compare(n_steps * 2 * kSub - 1);
+    min_regs(1, 0, 16);   // the last block's pair B
+    block_compare(1, n_steps * 2 * kSub - 1);
     if constexpr (HAM) ham_fold((n_steps - 1) / (kHamChunk / kStepRows));
     // ---- the two halves of the wave hold disjoint row sets of the same query
     gms_dmatch* __restrict__ out = matches + pr.match_off;
     if constexpr (HAM) {
-        int rowi[2];
+        int rowi[kNQ];
 #pragma unroll
-        for (int c = 0; c < 2; ++c) {   // lower distance, then lower row
+        for (int c = 0; c < kNQ; ++c) {   // lower distance, then lower row
             rowi[c] = bestt[c];
             const float od = __shfl_xor(bestd[c], 32);
             const int orow = __shfl_xor(rowi[c], 32);
@@ -491,18 +508,21 @@ bf_mfma_kernel(const uint4* __restrict__ rows, const uint32_t* __restrict__ norm
             bestd[c] = take ? od : bestd[c];
             rowi[c] = take ? orow : rowi[c];
         }
-        const int q = half ? qrow[1] : qrow[0];   // half 0 writes columns 0..31, half 1 columns 32..63: one record per lane
-        if (q < f.m) {
-            gms_dmatch m;
-            m.queryIdx = q;
-            m.trainIdx = half ? rowi[1] : rowi[0];
-            m.imgIdx = 0;
-            m.distance = (half ? bestd[1] : bestd[0]) + __uint_as_float(norms[f.offA + q]);
-            *reinterpret_cast<uint4*>(&out[q]) = *reinterpret_cast<const uint4*>(&m);
+#pragma unroll
+        for (int pp = 0; pp < kNQ / 2; ++pp) {   // half 0 writes column set 2 pp, half 1 set 2 pp + 1: two records per lane
+            const int q = half ? qrow[2 * pp + 1] : qrow[2 * pp];
+            if (q < f.m) {
+                gms_dmatch m;
+                m.queryIdx = q;
+                m.trainIdx = half ? rowi[2 * pp + 1] : rowi[2 * pp];
+                m.imgIdx = 0;
+                m.distance = (half ? bestd[2 * pp + 1] : bestd[2 * pp]) + __uint_as_float(norms[f.offA + q]);
+                *reinterpret_cast<uint4*>(&out[q]) = *reinterpret_cast<const uint4*>(&m);
+            }
         }
     } else {
 #pragma unroll
-        for (int c = 0; c < 2; ++c) {   // lower value, then earlier block
+        for (int c = 0; c < kNQ; ++c) {   // lower value, then earlier block
             const Val ov = __builtin_bit_cast(Val, __shfl_xor(__builtin_bit_cast(int, bestv[c]), 32));
             const int ot = __shfl_xor(bestt[c], 32);
             const int oties = __shfl_xor(ties[c], 32), ot2 = __shfl_xor(bestt2[c], 32);
@@ -523,13 +543,15 @@ bf_mfma_kernel(const uint4* __restrict__ rows, const uint32_t* __restrict__ norm
         const int n_blocks = (f.nB + 31) / 32;
         const int piece = lane & 7, grp = lane >> 3;
         const uint4 ones = make_uint4(0x01010101u, 0x01010101u, 0x01010101u, 0x01010101u);
-        for (int i0 = 0; i0 < 64; i0 += 8) {
-            if (q0 + wave * 64 + i0 >= f.m) break;                                        // wave-uniform
-            const int i = i0 + grp, q = q0 + wave * 64 + i;                               // this group's query: column i of the wave
-            int blk = __shfl(i0 < 32 ? bestt[0] : bestt[1], i & 31);
-            const int nt = __shfl(i0 < 32 ? ties[0] : ties[1], i & 31);
-            const int blk2 = __shfl(i0 < 32 ? bestt2[0] : bestt2[1], i & 31);
-            const int hsel = __shfl(i0 < 32 ? whalf[0] : whalf[1], i & 31);
+        auto pick = [&](const int (&v)[kNQ], int c) { return c == 0 ? v[0] : c == 1 ? v[1] : c == 2 ? v[2] : v[3]; };   // (c is wave-uniform)
+        for (int i0 = 0; i0 < 32 * kNQ; i0 += 8) {
+            if (q0 + wave * (32 * kNQ) + i0 >= f.m) break;                                // wave-uniform
+            const int i = i0 + grp, q = q0 + wave * (32 * kNQ) + i;                       // this group's query: column i of the wave
+            const int cs = i0 >> 5;                                                       // its column set
+            int blk = __shfl(pick(bestt, cs), i & 31);
+            const int nt = __shfl(pick(ties, cs), i & 31);
+            const int blk2 = __shfl(pick(bestt2, cs), i & 31);
+            const int hsel = __shfl(pick(whalf, cs), i & 31);
             const uint4 x = rows[(size_t)(f.offA + min(q, f.m - 1)) * 8 + piece];
             const uint4 nb = make_uint4(~x.x, ~x.y, ~x.z, ~x.w);
             const int query_part = dot16(nb, nb) + 2 * dot16(nb, ones);                   // this lane's 16 elements of the bracket
@@ -695,9 +717,10 @@ hipError_t launch_bf_match(int kind, const void* d_desc, const void* d_prep, int
         const uint32_t* bad = reinterpret_cast<const uint32_t*>(base + (size_t)total * 132);
         hipLaunchKernelGGL(bf_mfma_kernel<false>, dim3(n), dim3(256), 0, stream, reinterpret_cast<const uint4*>(base), norms, bad,
                            d_frame_off, n_frames, d_pairs, tiles, n, d_matches);
-        // pairs with a frame that is not SIFT-like (every block of the other pairs returns at once)
-        hipLaunchKernelGGL(bf_l2_loop_kernel<kL2Dim>, dim3(n), dim3(256), 0, stream, reinterpret_cast<const float*>(d_desc), bad, d_frame_off,
-                           n_frames, d_pairs, tiles, d_matches);
+        // pairs with a frame that is not SIFT-like (every block of the other pairs returns at once); one query per lane, 256 per workgroup
+        const int tiles_loop = (max_query + 255) / 256;
+        hipLaunchKernelGGL(bf_l2_loop_kernel<kL2Dim>, dim3((uint32_t)tiles_loop * (uint32_t)n_pairs), dim3(256), 0, stream, reinterpret_cast<const float*>(d_desc),
+                           bad, d_frame_off, n_frames, d_pairs, tiles_loop, d_matches);
         return hipGetLastError();
     }
     return hipErrorInvalidValue;
