@@ -35,10 +35,10 @@ def _check(oracle, descs, pairs, got, hamming):
 
 def test_hamming_small_frames_every_tail(ctx, pkg, oracle, synth):
     rng = np.random.default_rng(3)
-    counts = [1, 2, 63, 64, 65, 255, 256, 257, 700, 1025]
+    counts = [1, 2, 63, 64, 65, 255, 256, 257, 511, 513, 700, 1025]     # around the wave's 128 columns and the workgroup's 512 queries
     descs = [rng.integers(0, 256, (n, 32), dtype=np.uint8) for n in counts]
-    descs[8][100:140] = descs[8][20:60]          # duplicate train rows: the lower index wins
-    descs[9][:40] = descs[8][20:60]              # ... and queries that hit them exactly
+    descs[10][100:140] = descs[10][20:60]        # duplicate train rows: the lower index wins
+    descs[11][:40] = descs[10][20:60]            # ... and queries that hit them exactly
     batch, table, dt = _tables(ctx, pkg, synth, descs, pkg.GMS_DESC_HAMMING256)
     ab = [(a, b) for a in range(len(counts)) for b in range(len(counts)) if a != b]
     pairs = _pairs(pkg, counts, ab)
@@ -99,7 +99,7 @@ def test_hamming_frames_beyond_one_row_chunk(ctx, pkg, oracle, synth):
 
 def test_l2_sift_like_rows_on_the_matrix_cores(ctx, pkg, oracle, synth):
     rng = np.random.default_rng(4)
-    counts = [1, 31, 64, 65, 257, 1000, 3000, 777]
+    counts = [1, 31, 64, 65, 257, 1000, 3000, 777, 513]
     descs = [np.clip(np.rint(rng.gamma(1.2, 22.0, (n, 128))), 0, 255).astype(np.float32) for n in counts]
     descs[7] = rng.integers(0, 256, (777, 128)).astype(np.float32)   # every value of the int8 operands' range, both signs
     descs[5][500:520] = descs[5][100:120]        # duplicate train rows
