@@ -16,7 +16,6 @@ constexpr size_t kLdsBytes = 160 * 1024;               // gfx950 LDS per CU (and
 // inlier bit per match of the best hypothesis so far (16 x 1024 matches at most)
 constexpr uint32_t kPartialHeaderDw = 4;
 constexpr uint32_t kPartialStrideDw = kPartialHeaderDw + 16 * 1024 / 32;
-constexpr uint32_t kPartialConsumed = 0x80000000u;   // record word 0 once copyout_decided_kernel has written the pair's output
 
 // The frame table (gms_frame_table_bytes) starts with a 16-byte header -- magic, then the number of keypoints it was built
 // for -- so that the kernels find the code arrays behind the points by themselves, whatever n_frames / frame_off a filter call

@@ -267,7 +267,6 @@ __device__ __forceinline__ void hash_pair(const FilterParams& p, uint32_t* smem,
     const int lane = tid & 63;
     const int wave = tid >> 6;
 
-    if (p.partial != nullptr && p.partial[(size_t)pair_idx * kPartialStrideDw] == kPartialConsumed) return;  // (workgroup-uniform) copyout_decided_kernel's pair
     const gms_pair pr = uniform(p.pairs[pair_idx]);
     const int m = pr.m;
     const gms_dmatch* __restrict__ matches = p.matches + pr.match_off;
@@ -1983,64 +1982,6 @@ filter_kernel_dense_scales(FilterParams p)
     }
 }
 
-// Scale hypotheses, the pairs whose five scales are all decided when the byte-matrix kernel is done (its probe bounded scale 4 out:
-// almost every pair of a sequence at scale ~ 1): only the copy-out is left, and the hashed kernel -- one workgroup per CU, 147 KB of
-// LDS -- is a poor place for it (0.29 of a 1.14 ms step). Here: 256 threads and 1 KB of LDS per pair, as many workgroups per CU as
-// waves fit. The record's inlier bits (one 64-bit word per 64 consecutive matches) -> per-chunk popcounts -> exclusive scan -> the
-// survivors verbatim, in order, exactly what hash_pair's last stage writes; the record is marked consumed and the hashed kernel's
-// workgroup for the pair returns at once.
-__global__ void __launch_bounds__(256)
-copyout_decided_kernel(FilterParams p)
-{
-    __shared__ uint32_t chunk_base[256];
-    __shared__ uint32_t wave_tot[4];
-    const int pair_idx = (int)blockIdx.x, tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    uint32_t* part = p.partial + (size_t)pair_idx * kPartialStrideDw;
-    if ((part[0] & 15u) != 5u || (part[0] & kPartialConsumed) != 0u) return;   // (workgroup-uniform) not decided, or no record
-    const gms_pair pr = p.pairs[pair_idx];
-    const int m = pr.m;                       // 1 .. 16 384: the byte-matrix kernel took the pair
-    const int n_chunks = (m + 63) >> 6;       // <= 256: one per thread
-    const unsigned long long* __restrict__ bits64 = reinterpret_cast<const unsigned long long*>(part + kPartialHeaderDw);
-    const unsigned long long mine = tid < n_chunks ? bits64[tid] : 0ull;
-    const uint32_t v = (uint32_t)__popcll(mine);
-    uint32_t incl = v;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t t = (uint32_t)__shfl_up((int)incl, d);
-        if (lane >= d) incl += t;
-    }
-    if (lane == 63) wave_tot[wave] = incl;
-    __syncthreads();
-    uint32_t wave_off = 0;
-    for (int w = 0; w < wave; ++w) wave_off += wave_tot[w];
-    chunk_base[tid] = wave_off + incl - v;
-    const uint32_t total = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
-    __syncthreads();
-    const gms_dmatch* __restrict__ matches = p.matches + pr.match_off;
-    gms_dmatch* __restrict__ out = p.out + pr.match_off;
-    uint8_t* mask_out = p.mask ? p.mask + pr.match_off : nullptr;
-    for (int i = tid; i < m; i += 256) {      // (i & 63 == lane)
-        const int ch = i >> 6;
-        const unsigned long long b = bits64[ch];
-        const bool in = (b >> lane) & 1ull;
-        if (mask_out) mask_out[i] = in ? 1 : 0;
-        if (in) {
-            const uint32_t pos = chunk_base[ch] + (uint32_t)__popcll(b & ((1ull << lane) - 1ull));
-            *reinterpret_cast<uint4*>(&out[pos]) = *reinterpret_cast<const uint4*>(&matches[i]);
-        }
-    }
-    if (tid == 0) {
-        gms_pair_result r;
-        r.n_inliers = (int)total;
-        r.best_scale = (int)part[2];
-        r.best_rot = (int)part[3];
-        r.status = GMS_OK;
-        p.results[pair_idx] = r;
-    }
-    __syncthreads();                          // every read of the record is done
-    if (tid == 0) part[0] = kPartialConsumed;
-}
-
 // Test hook: the threshold comparison in device fp64 -- and, where the operands are in its range, the byte-matrix
 // path's integer form of it, which must agree (a disagreement is reported as 2).
 __global__ void threshold_kernel(const int32_t* T, const int32_t* n, const int32_t* score, double factor,
@@ -2260,9 +2201,6 @@ hipError_t launch_filter_scales(const FilterParams& p, int kpt, int n_pairs, hip
     case 16: e = rot ? launch_dense_scales_t<16, true, 1024>(p, n_pairs, stream) : launch_dense_scales_t<16, false, 1024>(p, n_pairs, stream); break;
     default: break;
     }
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(copyout_decided_kernel, dim3((unsigned)n_pairs), dim3(256), 0, stream, p);   // the pairs with nothing left but the copy-out
-    e = hipGetLastError();
     if (e != hipSuccess) return e;
     FilterParams q = p;
     q.dense = 0;
