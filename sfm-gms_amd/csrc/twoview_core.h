@@ -400,6 +400,80 @@ GMS_HD int aberth_roots(const MemC& c, int n, MemR& re, MemR& im)
     return it;
 }
 
+// The same iteration for the degree that always occurs in practice (10: the determinant's leading coefficient vanishes only on
+// degenerate samples), on plain arrays with every index a compile-time constant: on the device the coefficients and the roots then
+// live in registers instead of LDS (the generic form pays an LDS round trip per operand, and sixteen samples in lockstep run as
+// many sweeps as the slowest of them -- 48 more often than not). Statement for statement the generic loop: same operations in the
+// same order, bit-identical results.
+GMS_HD int aberth_roots_10(const double (&c)[11], double (&re)[10], double (&im)[10])
+{
+    constexpr int n = 10;
+    const double an = c[n];
+    double radius = 0.0;
+GMS_UNROLL
+    for (int k = 1; k <= n; ++k) {
+        const double q = fabs(c[n - k] / an) * (k == n ? 0.5 : 1.0);
+        if (q > 0.0) radius = fmax(radius, pow(q, 1.0 / k));
+    }
+    radius = 2.0 * radius;
+    if (!(radius > 0.0)) radius = 1.0;
+    const double centre = -c[n - 1] / (an * n);
+GMS_UNROLL
+    for (int k = 0; k < n; ++k) {
+        const double ang = 6.283185307179586 * k / n + 0.4;
+        re[k] = centre + 0.5 * radius * cos(ang);
+        im[k] = 0.5 * radius * sin(ang);
+    }
+    int it = 0;
+    for (; it < 48; ++it) {
+        double worst = 0.0;
+GMS_UNROLL
+        for (int i = 0; i < n; ++i) {
+            const double zr = re[i], zi = im[i];
+            double pr = an, pi = 0.0, dr = 0.0, di = 0.0;
+GMS_UNROLL
+            for (int k = n - 1; k >= 0; --k) {
+                const double ndr = dr * zr - di * zi + pr, ndi = dr * zi + di * zr + pi;
+                dr = ndr;
+                di = ndi;
+                const double npr = pr * zr - pi * zi + c[k], npi = pr * zi + pi * zr;
+                pr = npr;
+                pi = npi;
+            }
+            const double dd = dr * dr + di * di;
+            if (dd == 0.0) {  // on a critical point: nudge
+                re[i] = zr + 1e-8 * (1.0 + fabs(zr));
+                worst = 1.0;
+                continue;
+            }
+            const double wr = (pr * dr + pi * di) / dd, wi = (pi * dr - pr * di) / dd;
+            double sr = 0.0, si = 0.0;
+GMS_UNROLL
+            for (int j = 0; j < n; ++j) {
+                if (j == i) continue;
+                const double er = zr - re[j], ei = zi - im[j];
+                const double ee = er * er + ei * ei;
+                if (ee == 0.0) continue;
+                sr += er / ee;
+                si -= ei / ee;
+            }
+            const double qr = 1.0 - (wr * sr - wi * si), qi = -(wr * si + wi * sr);
+            const double qq = qr * qr + qi * qi;
+            double stepr = wr, stepi = wi;
+            if (qq > 0.0) {
+                stepr = (wr * qr + wi * qi) / qq;
+                stepi = (wi * qr - wr * qi) / qq;
+            }
+            re[i] = zr - stepr;
+            im[i] = zi - stepi;
+            const double rel = sqrt(stepr * stepr + stepi * stepi) / fmax(1.0, sqrt(zr * zr + zi * zi));
+            worst = fmax(worst, rel);
+        }
+        if (worst < 1e-12) break;
+    }
+    return it;
+}
+
 // E with its largest-magnitude entry positive (first such entry on ties)
 GMS_HD void canonical_sign(double* E)
 {
@@ -512,8 +586,17 @@ template <class Mem, class MemOut>
 GMS_HD int five_point(const double x1[5], const double y1[5], const double x2[5], const double y2[5], FivePointMem<Mem>& m, MemOut& models)
 {
     if (!null_space_5x9(x1, y1, x2, y2, m.basis, m.work)) return 0;
+#if defined(TV_DIAG) && TV_DIAG == 4
+    return 0;
+#endif
     constraint_matrix(m.basis, m.A, m.work);
+#if defined(TV_DIAG) && TV_DIAG == 5
+    return 0;
+#endif
     if (!eliminate_10x20(m.A)) return 0;
+#if defined(TV_DIAG) && TV_DIAG == 6
+    return 0;
+#endif
     reduced_system(m.A, m.work);  // B = work[0..38]
     // the constraint matrix has done its work: its storage now holds the run-time indexed arrays of the root finder
     struct Sub {
@@ -536,7 +619,19 @@ GMS_HD int five_point(const double x1[5], const double y1[5], const double x2[5]
 #if defined(TV_DIAG) && TV_DIAG == 2
     return 0;
 #endif
-    aberth_roots(c, n, re, im);
+    if (n == 10) {
+        double cl[11], rl[10], il[10];
+GMS_UNROLL
+        for (int k = 0; k <= 10; ++k) cl[k] = c(k);
+        aberth_roots_10(cl, rl, il);
+GMS_UNROLL
+        for (int k = 0; k < 10; ++k) {
+            re(k) = rl[k];
+            im(k) = il[k];
+        }
+    } else {
+        aberth_roots(c, n, re, im);
+    }
 #if defined(TV_DIAG) && TV_DIAG == 3
     return 0;
 #endif
