@@ -831,14 +831,17 @@ GMS_HD void undistort_point(const Camera& c, double u, double v, double& xo, dou
 GMS_HD void dlt_point(const double* Pa, const double* Pb, double x1, double y1, double x2, double y2, double X[4])
 {
     double A[4][4];
+GMS_UNROLL
     for (int k = 0; k < 4; ++k) {
         A[0][k] = x1 * Pa[8 + k] - Pa[k];
         A[1][k] = y1 * Pa[8 + k] - Pa[4 + k];
         A[2][k] = x2 * Pb[8 + k] - Pb[k];
         A[3][k] = y2 * Pb[8 + k] - Pb[4 + k];
     }
-    double S[4][4], V[4][4];
+    double S[4][4], V[4][4];   // (every index below is a compile-time constant once the loops are unrolled: registers on the device)
+GMS_UNROLL
     for (int a = 0; a < 4; ++a)
+GMS_UNROLL
         for (int b = 0; b < 4; ++b) {
             S[a][b] = A[0][a] * A[0][b] + A[1][a] * A[1][b] + A[2][a] * A[2][b] + A[3][a] * A[3][b];
             V[a][b] = a == b ? 1.0 : 0.0;
@@ -847,25 +850,32 @@ GMS_HD void dlt_point(const double* Pa, const double* Pb, double x1, double y1, 
     const double tr0 = S[0][0] + S[1][1] + S[2][2] + S[3][3];
     for (int sweep = 0; sweep < 12; ++sweep) {
         double off = 0.0;
+GMS_UNROLL
         for (int a = 0; a < 4; ++a)
+GMS_UNROLL
             for (int b = a + 1; b < 4; ++b) off += S[a][b] * S[a][b];
         if (off <= 1e-36 * tr0 * tr0) break;
+GMS_UNROLL
         for (int p = 0; p < 3; ++p)
+GMS_UNROLL
             for (int q = p + 1; q < 4; ++q) {
                 if (S[p][q] == 0.0) continue;
                 const double theta = (S[q][q] - S[p][p]) / (2.0 * S[p][q]);
                 const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
                 const double cs = 1.0 / sqrt(t * t + 1.0), sn = t * cs;
+GMS_UNROLL
                 for (int k = 0; k < 4; ++k) {
                     const double skp = S[k][p], skq = S[k][q];
                     S[k][p] = cs * skp - sn * skq;
                     S[k][q] = sn * skp + cs * skq;
                 }
+GMS_UNROLL
                 for (int k = 0; k < 4; ++k) {
                     const double spk = S[p][k], sqk = S[q][k];
                     S[p][k] = cs * spk - sn * sqk;
                     S[q][k] = sn * spk + cs * sqk;
                 }
+GMS_UNROLL
                 for (int k = 0; k < 4; ++k) {
                     const double vkp = V[k][p], vkq = V[k][q];
                     V[k][p] = cs * vkp - sn * vkq;
@@ -874,7 +884,14 @@ GMS_HD void dlt_point(const double* Pa, const double* Pb, double x1, double y1, 
             }
     }
     int best = 0;
-    for (int k = 1; k < 4; ++k) best = S[k][k] < S[best][best] ? k : best;
+    double dmin = S[0][0];   // (the smallest diagonal entry, the first one on ties; no run-time index into S)
+GMS_UNROLL
+    for (int k = 1; k < 4; ++k)
+        if (S[k][k] < dmin) {
+            dmin = S[k][k];
+            best = k;
+        }
+GMS_UNROLL
     for (int k = 0; k < 4; ++k) X[k] = best == 0 ? V[k][0] : best == 1 ? V[k][1] : best == 2 ? V[k][2] : V[k][3];
 }
 
