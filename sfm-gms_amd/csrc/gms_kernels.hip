@@ -1413,13 +1413,471 @@ __device__ __forceinline__ bool dense_pair(const FilterParams& p, uint32_t* smem
     return true;
 }
 
+// ------------------------------------------------------------------------------------------------
+// dense_pair_plain: the byte-matrix path WITHOUT rotation hypotheses (the reference's default flags, DisparityUtil.cpp:149,299 --
+// the headline workload), rewritten in round 3 around the instruction count: the kernel is bound by vector-instruction issue
+// (DESIGN.md section 6), and dense_pair<ROT = false> spent 20 vector instructions per match and grid type on binning, 9 on
+// marking, 140 per cell on verification. Same matrix, same phases, same results; what changed:
+//   * the code word is [entry under grid type 1 = 404 * cell + E : 18 | E : 9 | q and the two edge bits : 5]: the entry under
+//     grid type g is one and + one shift + one multiply-add away, the row header is "entry - E";
+//   * nothing is predicated: a match that is not binned under the current grid type (never, or in the last half cell of a shifted
+//     axis) swaps its code word for the lane's SINK word -- an entry in the 64 spare bytes behind the matrix -- and runs the same
+//     instructions as everybody else (no exec masks, no branches around the LDS atomics);
+//   * LDS is addressed by absolute byte offsets (the dynamic segment starts at 0 in these kernels): no "+ base" per access;
+//   * the inlier flag of a match is one bit of a wave-wide mask in scalar registers (v_cmp writes it; the copy-out wants the
+//     ballot anyway), the row header after verification is E(j*) when the cell pair passes and 0 when it does not: marking is
+//     one compare;
+//   * verification: the eight neighbour pairs of a cell are base + s * 403 * d for d in {-21, -20, -19, -1} and s = +-1 (the two
+//     lanes of a cell), their validity three compares per axis; an invalid pair reads a byte that is always zero.
+// ------------------------------------------------------------------------------------------------
+using lds_u32_t = __attribute__((address_space(3))) uint32_t;
+using lds_u16_t = __attribute__((address_space(3))) uint16_t;
+using lds_u8_t = __attribute__((address_space(3))) uint8_t;
+__device__ __forceinline__ uint32_t ldsa_add_rtn(uint32_t a, uint32_t v)
+{
+    return __hip_atomic_fetch_add(reinterpret_cast<lds_u32_t*>((uintptr_t)a), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void ldsa_add(uint32_t a, uint32_t v)
+{
+    (void)__hip_atomic_fetch_add(reinterpret_cast<lds_u32_t*>((uintptr_t)a), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void ldsa_max(uint32_t a, uint32_t v)
+{
+    (void)__hip_atomic_fetch_max(reinterpret_cast<lds_u32_t*>((uintptr_t)a), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ uint32_t ldsa_ld32(uint32_t a) { return *reinterpret_cast<lds_u32_t*>((uintptr_t)a); }
+__device__ __forceinline__ uint32_t ldsa_ld16(uint32_t a) { return *reinterpret_cast<lds_u16_t*>((uintptr_t)a); }
+__device__ __forceinline__ uint32_t ldsa_ld8(uint32_t a) { return *reinterpret_cast<lds_u8_t*>((uintptr_t)a); }
+__device__ __forceinline__ void ldsa_st32(uint32_t a, uint32_t v) { *reinterpret_cast<lds_u32_t*>((uintptr_t)a) = v; }
+__device__ __forceinline__ void ldsa_st8(uint32_t a, uint32_t v) { *reinterpret_cast<lds_u8_t*>((uintptr_t)a) = (uint8_t)v; }
+
+// a * b + c on the 24-bit multiplier, b in a scalar register (the compiler turns the builtin multiply + add into the quarter-rate
+// v_mad_u64_u32 when it cannot see that the factors are short)
+__device__ __forceinline__ uint32_t mad24_vsv(uint32_t a, uint32_t b, uint32_t c)
+{
+    uint32_t d;
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "s"(b), "v"(c));
+    return d;
+}
+// bits = 2 * bits + (a == b): a compare and an add-with-carry
+__device__ __forceinline__ uint32_t shift_in_equal(uint32_t bits, uint32_t a, uint32_t b)
+{
+    uint32_t d;
+    asm("v_cmp_eq_u32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %3, %3, vcc" : "=v"(d) : "v"(a), "v"(b), "v"(bits) : "vcc");
+    return d;
+}
+
+// plain code word
+constexpr uint32_t kPEdgeX = 1u << 1, kPEdgeY = 1u << 3;  // in the gaps of q = (hx & 1) + 20 (hy & 1) (bits 0, 2, 4)
+constexpr int kPEShift = 5;                                // bits 5..13  E(r); 0 = the sink word (binned nowhere)
+constexpr int kPAtShift = 14;                              // bits 14..31 byte offset of the entry under grid type 1: 404 * cell + E
+static_assert(kDenseLdsBytes < (1u << 18), "an entry offset is 18 bits");
+// byte 3 of a row header is zero at all times (arg-max keys end at bit 21, cellPairs words at bit 8)
+constexpr uint32_t kPZeroByte = 3u;
+
+template <int KPT, int NT, bool DEALT>
+__device__ __forceinline__ bool dense_pair_plain(const FilterParams& p, uint32_t* smem, const int pair_idx, const int tid)
+{
+    constexpr int kMcap = KPT * NT;
+    constexpr int kChunk = (KPT % 5 == 0) ? 5 : 4;
+    static_assert(KPT % kChunk == 0, "KPT must be a multiple of the chunk");
+    static_assert(NT >= 2 * kLeftN, "verification: two lanes per left cell in one sweep");
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    constexpr int kUnitsPerBlock = KPT * (NT / 64);   // (lane mapping: see dense_pair)
+    constexpr bool dealt = DEALT;
+    const int m_base = dealt ? ((((lane >> 3) * kUnitsPerBlock + wave) << 3) | (lane & 7)) : tid;
+    const int m_stride = dealt ? (NT / 64) * 8 : NT;
+    auto match_of = [&](int k) -> int { return m_base + k * m_stride; };
+
+    // the absolute LDS offsets below assume the dynamic segment starts at 0 (no static LDS in the kernels that call this)
+    if ((uint32_t)(uintptr_t)((lds_u32_t*)smem) != 0u) return false;
+
+    const gms_pair pr = uniform(p.pairs[pair_idx]);
+    const int m = pr.m;
+    if (p.with_scale || p.with_rotation || p.right_w[0] != kDenseRightW || p.right_h[0] != kDenseRightW || m <= 0 || m > kMcap ||
+        pr.frame_a < 0 || pr.frame_a >= p.n_frames || pr.frame_b < 0 || pr.frame_b >= p.n_frames)
+        return false;
+    const int64_t offA = uniform(p.frame_off[pr.frame_a]), offB = uniform(p.frame_off[pr.frame_b]);
+    const int nA = (int)(uniform(p.frame_off[pr.frame_a + 1]) - offA), nB = (int)(uniform(p.frame_off[pr.frame_b + 1]) - offB);
+    if (nA <= 0 || nB <= 0) return false;
+    const gms_dmatch* __restrict__ matches = p.matches + pr.match_off;
+    const int64_t total_kp = table_total_kp(p);
+    if (total_kp < 0 || offA + nA > total_kp || offB + nB > total_kp) return false;  // (workgroup-uniform) no header, or frames beyond the table
+    const uint16_t* __restrict__ lcodeA = reinterpret_cast<const uint16_t*>(p.pts + total_kp) + offA;
+    const uint16_t* __restrict__ rcodeB = reinterpret_cast<const uint16_t*>(p.pts + total_kp) + total_kp + offB;
+
+    uint32_t* nfine32 = smem + kDenseFineOff / 4;   // half-cell histogram: one dword per cell of grid type 1, a byte per half cell
+    const uint8_t* nfine8 = reinterpret_cast<const uint8_t*>(nfine32);
+    uint32_t* misc = smem + kDenseMiscOff / 4;
+    uint32_t* trash = smem + kDenseTrashOff / 4;
+
+    GMS_STAMP_DECL
+#ifdef GMS_PHASE_TIMING
+    ph_[14] = wall_clock64();
+#endif
+    if (tid < 32) misc[tid] = 0;
+    if (tid < 16) trash[tid] = 0;
+    if (tid < kFineN / 4) nfine32[tid] = 0;
+
+    // ---- staging: both frames' code words into the still unused matrix area, then the pair's DMatch records (see dense_pair)
+    const uint32_t phA = (uint32_t)(reinterpret_cast<uintptr_t>(lcodeA) >> 1) & 7u, phB = (uint32_t)(reinterpret_cast<uintptr_t>(rcodeB) >> 1) & 7u;
+    const uint32_t qA = (phA + (uint32_t)nA + 7u) >> 3, qB = (phB + (uint32_t)nB + 7u) >> 3;
+    const bool staged = (qA + qB) * 16u <= kDenseBytes;
+    const uint4* __restrict__ srcA = reinterpret_cast<const uint4*>(lcodeA - phA);
+    const uint4* __restrict__ srcB = reinterpret_cast<const uint4*>(rcodeB - phB);
+    constexpr int kStageRegs = 3;
+    uint4 tb[kStageRegs];
+#pragma unroll
+    for (int i = 0; i < kStageRegs; ++i) {
+        const uint32_t j = min((uint32_t)(i * NT + tid), qA + qB - 1u);
+        const uint4* src = j < qA ? srcA + j : srcB + (j - qA);
+        tb[i] = *src;
+    }
+    constexpr bool kKeepRec = KPT <= 10;
+    uint4 rec[kKeepRec ? KPT : 1];
+    uint2 qt[kKeepRec ? 1 : KPT];
+#pragma unroll
+    for (int k = 0; k < KPT; ++k) {
+        if (kKeepRec) rec[k] = *reinterpret_cast<const uint4*>(&matches[min(match_of(k), m - 1)]);
+        else qt[k] = *reinterpret_cast<const uint2*>(&matches[min(match_of(k), m - 1)]);
+    }
+    auto query_of = [&](int k) -> uint32_t { return kKeepRec ? rec[k].x : qt[k].x; };
+    auto train_of = [&](int k) -> uint32_t { return kKeepRec ? rec[k].y : qt[k].y; };
+    const uint32_t staged16 = staged ? qA + qB : 0u;
+    {
+        const uint4 z4 = make_uint4(0, 0, 0, 0);
+        uint4* d4 = reinterpret_cast<uint4*>(smem);
+        for (uint32_t i = staged16 + tid; i < kDenseBytes / 16; i += NT) d4[i] = z4;
+    }
+    if (staged) {
+        uint4* d4 = reinterpret_cast<uint4*>(smem);
+#pragma unroll
+        for (int i = 0; i < kStageRegs; ++i)
+            if ((uint32_t)(i * NT + tid) < qA + qB) d4[i * NT + tid] = tb[i];
+        for (uint32_t j = kStageRegs * NT + tid; j < qA + qB; j += NT) d4[j] = *(j < qA ? srcA + j : srcB + (j - qA));
+    }
+    const uint32_t ldsA = 2u * phA, ldsB = 16u * qA + 2u * phB;  // byte offsets: left code of frame A's keypoint q at ldsA + 2 q
+    __syncthreads();
+#ifdef GMS_PHASE_TIMING
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    GMS_STAMP(4);
+    ph_[15] = wall_clock64();
+#endif
+
+    // ---- code words + half-cell histogram
+    uint32_t code[KPT];
+    const uint32_t cw_sink = (kDenseTrashOff + 4u * (uint32_t)(lane & 15)) << kPAtShift;  // E = 0, q = 0, no edge bit
+    {
+        uint32_t ca[KPT], cb[KPT];
+        if (staged) {
+#pragma unroll
+            for (int k = 0; k < KPT; ++k) ca[k] = ldsa_ld16(ldsA + 2u * min(query_of(k), (uint32_t)(nA - 1)));
+#pragma unroll
+            for (int k = 0; k < KPT; ++k) cb[k] = ldsa_ld16(ldsB + 2u * min(train_of(k), (uint32_t)(nB - 1)));
+        } else {
+#pragma unroll
+            for (int k = 0; k < KPT; ++k) ca[k] = lcodeA[min(query_of(k), (uint32_t)(nA - 1))];
+#pragma unroll
+            for (int k = 0; k < KPT; ++k) cb[k] = rcodeB[min(train_of(k), (uint32_t)(nB - 1))];
+        }
+#ifdef GMS_PHASE_TIMING
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        GMS_STAMP(12);
+#endif
+        bool any_bad = false, spill = false;
+#pragma unroll
+        for (int k = 0; k < KPT; ++k) {
+            const bool live = match_of(k) < m;
+            const uint32_t e0 = cb[k] & kDEMask;
+            const uint32_t cell = ca[k] >> kLCellShift;
+            const bool ok = ((int)(query_of(k) < (uint32_t)nA) & (int)(train_of(k) < (uint32_t)nB) & (int)(cell != kLCellBad) & (int)((cb[k] & kRCodeBad) == 0u) & (int)(e0 != 0u)) != 0;
+            const bool binned = live & ok & (cell < kLCellNever);
+            const uint32_t sh = ((ca[k] & 1u) << 3) | ((ca[k] & 4u) << 2);
+            const uint32_t old = ldsa_add_rtn(binned ? kDenseFineOff + 4u * cell : kDenseTrashOff + 4u * (uint32_t)(lane & 7), 1u << sh);
+            spill |= binned & (((old >> sh) & 255u) == 255u);
+            any_bad |= live & !ok;
+            const uint32_t qe = (ca[k] & 21u) | ((ca[k] >> 4) & kPEdgeX) | ((ca[k] >> 3) & kPEdgeY);
+            const uint32_t at1 = __umul24(cell, kDenseRow) + e0;
+            code[k] = binned ? ((at1 << kPAtShift) | (e0 << kPEShift) | qe) : cw_sink;
+        }
+        if (any_bad) misc[8] = 1;
+        if (spill) misc[13] = 1;
+    }
+    GMS_STAMP(13);
+    __syncthreads();
+    GMS_STAMP(0);
+
+    // ---- motion.setTo(0), once (see dense_pair)
+    {
+        const uint4 z4 = make_uint4(0, 0, 0, 0);
+        uint4* d4 = reinterpret_cast<uint4*>(smem);
+        for (uint32_t i = tid; i < staged16; i += NT) d4[i] = z4;
+        // the sink dwords from here on: bit 31 set, and nothing below ever clears it (increments land in byte 0, arg-max keys end at
+        // bit 21, the undo stores a zero into byte 0) -- a sink is never equal to an E, so a sink word is nobody's inlier
+        if (tid < 16) trash[tid] = 0x80000000u;
+    }
+    __syncthreads();
+    GMS_STAMP(2);
+    if (misc[8] != 0) {
+        __syncthreads();
+        return false;
+    }
+    const bool spilled = misc[13] != 0;
+
+    const bool thr_fast = threshold_fast_ok(p.threshold_factor);
+    const uint32_t f2i = dense_factor_sq(p.threshold_factor);
+    uint32_t acc = 0;  // bit k: match k of this thread is an inlier under some grid type
+
+    // verification: lane pair of cell i = tid >> 1; the even lane takes the neighbour pairs at d = -21, -20, -19, -1 (positions 0..3 of
+    // the 3 x 3 block), the odd lane the mirrored ones (positions 8..5): s = +-1
+    const uint32_t vi = (uint32_t)tid >> 1;
+    const uint32_t viy = (vi * 3277u) >> 16, vix = vi - 20u * viy;  // vi / 20, vi % 20 for vi < 400 (and harmless above)
+    const bool vodd = (tid & 1) != 0;
+
+    auto run_types = [&](auto crowded_c) -> int {
+    constexpr bool CROWDED = decltype(crowded_c)::value;
+    for (int g = 0; g < 4; ++g) {
+        const int gx = g & 1, gy = g >> 1;
+        const uint32_t q_mask = (uint32_t)(gx + 20 * gy);                               // entry = entry1 + 404 * (q & q_mask)
+        const uint32_t x_mask = (gx ? kPEdgeX : 0u) | (gy ? kPEdgeY : 0u);              // x >= 20 || y >= 20 -> -1 (DLL@0x180047d3d)
+        const uint32_t key_tag = (uint32_t)g << kDTagShift;
+        const uint32_t nl_cur = kDenseFineOff + (uint32_t)(g & 1) * (kLeftN * 2u);      // crowded: 16-bit nLeft counters, two buffers
+        if (!CROWDED && tid < kLeftN) {
+            const uint32_t n = dense_nleft_cm(nfine8, tid % kLeftW, tid / kLeftW, gx, gy);
+            if (n > 255u) misc[11] = 1;
+            ldsa_st8(kDenseNleftOff + (uint32_t)tid, n);
+        }
+
+        // ---- assignMatchPairs
+        uint32_t ae[KPT];  // [E : 9 | entry : 18] of every match under this grid type (a sink's own for the matches it does not bin)
+#pragma unroll
+        for (int k0 = 0; k0 < KPT; k0 += kChunk) {
+            uint32_t old[kChunk], at[kChunk], cg[kChunk], sh[kChunk];
+#pragma unroll
+            for (int c = 0; c < kChunk; ++c) {
+                const uint32_t cw = code[k0 + c];
+                cg[c] = (cw & x_mask) ? cw_sink : cw;
+                at[c] = mad24_vsv(cg[c] & q_mask, kDenseRow, cg[c] >> kPAtShift);
+                sh[c] = at[c] << 3;  // (shifts and bit-field extracts read its low five bits: 8 * (entry & 3))
+                asm("" : "+v"(sh[c]));
+                old[c] = ldsa_add_rtn(at[c] & ~3u, 1u << (sh[c] & 31u));
+                if (CROWDED) {
+                    const uint32_t l = (((at[c] - ((cg[c] >> kPEShift) & kDEMask)) >> 2) * 649u) >> 16;  // row / 404 (the sink: 405)
+                    ldsa_add(nl_cur + 4u * (l >> 1), 1u << ((l & 1u) << 4));
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);  // all of the chunk's atomics are issued before any result is read
+#pragma unroll
+            for (int c = 0; c < kChunk; ++c) {
+                const uint32_t e = (cg[c] >> kPEShift) & kDEMask;
+                const uint32_t before = __builtin_amdgcn_ubfe(old[c], sh[c], 8);  // <= 254, or ...
+                if (CROWDED && e != 0u && before == 255u) misc[12] = 1;                // ... the entry's byte has just wrapped
+                ldsa_max(at[c] - e, key_tag | (before << 11) | e);
+                asm("v_lshl_or_b32 %0, %1, 18, %2" : "=v"(ae[k0 + c]) : "v"(e), "v"(at[c]));  // (opaque: the compiler cannot know that an entry is 18 bits)
+            }
+        }
+        GMS_STAMP(3);
+        __syncthreads();
+        GMS_STAMP(11);
+        if (!CROWDED && misc[11] != 0) return 1;
+        if (CROWDED && misc[12] != 0) return 2;
+
+        // ---- verifyCellPairs
+        if (tid < 2 * kLeftN) {
+            const uint32_t ni = CROWDED ? ldsa_ld16(nl_cur + 2u * vi) : ldsa_ld8(kDenseNleftOff + vi);
+            if (__ballot(ni != 0) != 0ull) {
+                const uint32_t hdr = vi * kDenseRow;
+                const uint32_t best = ldsa_ld32(hdr) & ((1u << kDTagShift) - 1u);  // ((max count - 1) << 11) | E(j*), lowest j* among maxima
+                const uint32_t ej = ni ? (best & kDEMask) : (uint32_t)(kDenseRightN + 3);
+                const uint32_t j = (uint32_t)(kDenseRightN + 3) - ej;
+                const uint32_t jy = (j * 3277u) >> 16, jx = j - 20u * jy;
+                const uint32_t lo = vodd ? 19u : 0u, hi = 19u - lo;
+                const bool okA = (vix != lo) & (jx != lo);   // one step against s along x stays inside both grids
+                const bool okB = (vix != hi) & (jx != hi);   // one step with s along x
+                const bool okC = (viy != lo) & (jy != lo);   // one step against s along y
+                const int s403 = vodd ? -403 : 403, s1 = vodd ? -1 : 1;
+                const uint32_t base = hdr + ej;
+                const uint32_t nlb = (CROWDED ? nl_cur + 2u * vi : kDenseNleftOff + vi);
+                uint32_t score = 0, tn = 0;  // tn = (sum of nLeft << 4) | numpair
+                auto side = [&](int d, bool valid) {
+                    const uint32_t a = valid ? base + (uint32_t)(s403 * d) : kPZeroByte;
+                    const uint32_t na = nlb + (uint32_t)((CROWDED ? 2 : 1) * s1 * d);
+                    const uint32_t cnt = ldsa_ld8(a);
+                    const uint32_t nll = CROWDED ? ldsa_ld16(na) : ldsa_ld8(na);
+                    score += cnt;
+                    tn += valid ? ((nll << 4) | 1u) : 0u;
+                };
+                side(-21, okA & okC);
+                side(-20, okC);
+                side(-19, okB & okC);
+                side(-1, okA);
+                score += dpp_xor1(score);
+                tn += dpp_xor1(tn);
+                score += (best >> 11) + 1u;  // centre pair: ll = i, rr = j*, the arg-max count itself
+                tn += (ni << 4) | 1u;
+                if (ni != 0 && !vodd) {
+                    const bool rej = CROWDED ? threshold_rejects(tn >> 4, tn & 15u, score, p.threshold_factor, thr_fast)
+                                             : dense_threshold_rejects(tn >> 4, tn & 15u, score, p.threshold_factor, thr_fast, f2i);
+                    ldsa_st32(hdr, rej ? 0u : ej);  // cellPairs[i] as E(j*), 0 = none
+                }
+            }
+        }
+        __syncthreads();
+        GMS_STAMP(5);
+
+        // ---- mark inliers (cellPairs[l] == r) and take this grid type's increments back (plain zero bytes: see dense_pair)
+        uint32_t cur = 0;
+#pragma unroll
+        for (int k = 0; k < KPT; ++k) {
+            const uint32_t at = ae[k] & 0x3FFFFu, e = ae[k] >> 18;
+            const uint32_t cr = ldsa_ld32(at - e);  // (a sink's own dword: never equal to its E = 0)
+            ldsa_st8(at, 0u);                       // (after the last grid type as well: the area is free then)
+            cur = shift_in_equal(cur, cr, e);       // match k ends up in bit KPT - 1 - k
+        }
+        acc |= cur;
+        if (CROWDED && tid < kLeftN / 2) ldsa_st32(kDenseFineOff + (uint32_t)((g + 1) & 1) * (kLeftN * 2u) + 4u * (uint32_t)tid, 0u);
+        __syncthreads();
+        GMS_STAMP(6);
+    }
+    return 0;
+    };
+
+    int status = 1;
+    if (!spilled) status = run_types(std::false_type{});
+    if (status == 1) {
+        // crowded: start over on a clean matrix (the abandoned grid type's bytes may have wrapped), no inlier bits yet
+        __syncthreads();
+        {
+            const uint4 z4 = make_uint4(0, 0, 0, 0);
+            uint4* d4 = reinterpret_cast<uint4*>(smem);
+            for (uint32_t i = tid; i < kDenseBytes / 16; i += NT) d4[i] = z4;
+            if (tid < kLeftN) nfine32[tid] = 0;
+            if (tid == 0) misc[11] = 0;
+        }
+        acc = 0;
+        if (tid < 16) trash[tid] = 0x80000000u;
+        __syncthreads();
+        status = run_types(std::true_type{});
+    }
+    if (status != 0) {
+        __syncthreads();
+        return false;
+    }
+    GMS_STAMP(7);
+
+    // ---- copy-out: surviving DMatch verbatim, in input order (DLL@0x180048340), from the registers (see dense_pair)
+    constexpr int kWaves = NT / 64;
+    uint32_t* cnt_tab = smem;
+    unsigned long long keep[KPT];
+#pragma unroll
+    for (int k = 0; k < KPT; ++k) keep[k] = __ballot((acc >> (KPT - 1 - k)) & 1u);
+    gms_dmatch* __restrict__ out = p.out + pr.match_off;
+    uint8_t* mask_out = p.mask ? p.mask + pr.match_off : nullptr;
+    uint32_t total = 0;
+    if (!dealt) {
+        constexpr int kScanRegs = (KPT * kWaves + 63) / 64;
+#pragma unroll
+        for (int k = 0; k < KPT; ++k)
+            if (lane == 0) cnt_tab[k * kWaves + wave] = (uint32_t)__popcll(keep[k]);
+        __syncthreads();
+        uint32_t excl[kScanRegs];
+#pragma unroll
+        for (int v = 0; v < kScanRegs; ++v) {
+            const int idx = v * 64 + lane;
+            const uint32_t c = idx < KPT * kWaves ? cnt_tab[idx] : 0u;
+            uint32_t incl = c;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t t = __shfl_up(incl, d);
+                if (lane >= d) incl += t;
+            }
+            excl[v] = total + incl - c;
+            total += __shfl(incl, 63);
+        }
+        GMS_STAMP(8);
+#pragma unroll
+        for (int k = 0; k < KPT; ++k) {
+            const int i = k * NT + tid;
+            const int ch = k * kWaves + wave;
+            static_assert(64 % kWaves == 0, "a wave's chunk never straddles two scan registers");
+            const uint32_t base = __shfl(excl[(k * kWaves) >> 6], ch & 63);
+            if (i < m) {
+                const bool in = (keep[k] >> lane) & 1ull;
+                if (mask_out) mask_out[i] = in ? 1 : 0;
+                if (in) {
+                    const uint32_t pos = base + (uint32_t)__popcll(keep[k] & ((1ull << lane) - 1ull));
+                    *reinterpret_cast<uint4*>(&out[pos]) = kKeepRec ? rec[k] : *reinterpret_cast<const uint4*>(&matches[i]);
+                }
+            }
+        }
+    } else {
+        constexpr int kUnits = KPT * NT / 8;
+        static_assert(kUnits <= 2 * NT, "two scan entries per thread");
+        uint32_t* wave_tot = misc + 16;
+#pragma unroll
+        for (int k = 0; k < KPT; ++k)
+            if ((lane & 7) == 0) cnt_tab[match_of(k) >> 3] = (uint32_t)__popc((uint32_t)(keep[k] >> (lane & 56)) & 0xFFu);
+        __syncthreads();
+        {
+            const uint32_t c0 = 2 * tid < kUnits ? cnt_tab[2 * tid] : 0u, c1 = 2 * tid + 1 < kUnits ? cnt_tab[2 * tid + 1] : 0u;
+            uint32_t incl = c0 + c1;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t t = __shfl_up(incl, d);
+                if (lane >= d) incl += t;
+            }
+            if (lane == 63) wave_tot[wave] = incl;
+            __syncthreads();
+            uint32_t off = 0;
+#pragma unroll
+            for (int w = 0; w < kWaves; ++w) {
+                const uint32_t tw = wave_tot[w];
+                off += w < wave ? tw : 0u;
+                total += tw;
+            }
+            if (2 * tid < kUnits) cnt_tab[2 * tid] = off + incl - c0 - c1;
+            if (2 * tid + 1 < kUnits) cnt_tab[2 * tid + 1] = off + incl - c1;
+        }
+        __syncthreads();
+        GMS_STAMP(8);
+#pragma unroll
+        for (int k = 0; k < KPT; ++k) {
+            const int i = match_of(k);
+            if (i < m) {
+                const uint32_t byte = (uint32_t)(keep[k] >> (lane & 56)) & 0xFFu;
+                const bool in = (byte >> (lane & 7)) & 1u;
+                if (mask_out) mask_out[i] = in ? 1 : 0;
+                if (in) {
+                    const uint32_t pos = cnt_tab[i >> 3] + (uint32_t)__popc(byte & ((1u << (lane & 7)) - 1u));
+                    *reinterpret_cast<uint4*>(&out[pos]) = kKeepRec ? rec[k] : *reinterpret_cast<const uint4*>(&matches[i]);
+                }
+            }
+        }
+    }
+    GMS_STAMP(9);
+    GMS_STAMP_FLUSH;
+    if (tid == 0) {
+        gms_pair_result r;
+        r.n_inliers = (int)total;
+        r.best_scale = total ? 0 : -1;
+        r.best_rot = total ? 1 : -1;
+        r.status = GMS_OK;
+        p.results[pair_idx] = r;
+    }
+    return true;
+}
+
 template <int KPT, bool ROT, int NT, bool DEALT>
 __global__ void __launch_bounds__(NT)
 filter_kernel_dense(FilterParams p)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     first_round_stagger(p);
-    if (!dense_pair<KPT, ROT, NT, DEALT>(p, smem, (int)blockIdx.x, (int)threadIdx.x)) hash_pair<KPT, ROT, NT>(p, smem, (int)blockIdx.x, (int)threadIdx.x);
+    bool done;
+    if constexpr (ROT) done = dense_pair<KPT, true, NT, DEALT>(p, smem, (int)blockIdx.x, (int)threadIdx.x);
+    else done = dense_pair_plain<KPT, NT, DEALT>(p, smem, (int)blockIdx.x, (int)threadIdx.x);
+    if (!done) hash_pair<KPT, ROT, NT>(p, smem, (int)blockIdx.x, (int)threadIdx.x);
 }
 
 // Are a batch's matches in spatial order? One small workgroup, launched now and then behind a byte-matrix launch (gms_capi.cpp):
