@@ -57,9 +57,12 @@ namespace {
 //   GMS_DEAL=0|1         never / always deal the matches to the lanes of the byte-matrix kernel (default: what the probe saw)
 //   GMS_SCALE_PROBE=0|1  never / always bound the finer scale hypotheses' inlier counts first (default: while it pays, see below)
 //   GMS_CHECK_PAIRS=0|1  never / always validate the pair table behind a launch (default: the first launch and every sixteenth)
+//   GMS_PREFETCH=t[,a]   byte-matrix kernel: before grid type t (0..3, default 3; -1 = never) a workgroup touches the match records of
+//                        the pair a places ahead (default: the number of CUs = the pair its CU's next workgroup takes)
 struct Knobs {
     bool dense_on = true, band_on = true, stream_on = true;
     int stagger_us = -1, deal = -1, scale_probe = -1, check_pairs = -1;
+    int prefetch_type = 3, prefetch_ahead = 0;
     size_t band_ws_budget = (size_t)4 << 30;
 };
 const Knobs& knobs()
@@ -73,6 +76,10 @@ const Knobs& knobs()
         if (const char* e = std::getenv("GMS_DEAL")) v.deal = std::atoi(e) != 0 ? 1 : 0;
         if (const char* e = std::getenv("GMS_SCALE_PROBE")) v.scale_probe = std::atoi(e) != 0 ? 1 : 0;
         if (const char* e = std::getenv("GMS_CHECK_PAIRS")) v.check_pairs = std::atoi(e) != 0 ? 1 : 0;
+        if (const char* e = std::getenv("GMS_PREFETCH")) {
+            v.prefetch_type = std::atoi(e);
+            if (const char* comma = std::strchr(e, ',')) v.prefetch_ahead = std::atoi(comma + 1);
+        }
         if (const char* e = std::getenv("GMS_BAND_WS_BYTES")) {
             const long long b = std::atoll(e);
             if (b > 0) v.band_ws_budget = (size_t)b;
@@ -296,6 +303,8 @@ int filter_launch(gms_ctx* c, hipStream_t st, const float* d_pts, const int64_t*
     p.pairs = d_pairs;
     p.n_pairs = n_pairs;
     p.stagger_blocks = c->n_cus;
+    p.prefetch_type = knobs().prefetch_type;
+    p.prefetch_ahead = knobs().prefetch_ahead > 0 ? knobs().prefetch_ahead : c->n_cus;
     p.matches = d_matches;
     p.out = d_out;
     p.results = d_results;

@@ -44,6 +44,7 @@ struct FilterParams {
     int probe_scales;           // scale hypotheses: bit s set = bound scale s's inlier count first and skip the scale when it cannot win
     uint32_t* probe_stats;      // optional device counters: [0] scales probed, [1] scales the probe let skip
     uint32_t* overflow_events;  // streamed byte-matrix kernels: a word (pinned host memory) that counts the pairs they had to hand on because an entry left its byte
+    int prefetch_type, prefetch_ahead;  // byte-matrix kernel: before grid type prefetch_type a workgroup touches the records of pair + prefetch_ahead (0 = off)
     int dense;                  // try the byte-matrix path first (no scale hypotheses only); the general path is the fallback
     double threshold_factor;
     int right_w[5], right_h[5]; // setScale (DLL@0x180048c10): cvRound(20 * ratio[s])

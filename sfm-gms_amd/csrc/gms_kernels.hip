@@ -1635,6 +1635,21 @@ __device__ __forceinline__ bool dense_pair_plain(const FilterParams& p, uint32_t
     const uint32_t viy = (vi * 3277u) >> 16, vix = vi - 20u * viy;  // vi / 20, vi % 20 for vi < 400 (and harmless above)
     const bool vodd = (tid & 1) != 0;
 
+    // L2 prefetch for the workgroup that follows this one on the CU: workgroups are handed out in order, one per CU, so that is
+    // pair_idx + (number of CUs) -- on the same XCD (256 = 8 x 32)
+    const uint32_t* __restrict__ pf_base = nullptr;
+    uint32_t pf_lines = 0, pf_sink = 0, pf_sink2 = 0;
+    {
+        const int nxt = pair_idx + p.prefetch_ahead;
+        if (p.prefetch_ahead > 0 && nxt < p.n_pairs) {
+            const gms_pair pn = uniform(p.pairs[nxt]);
+            if (pn.m > 0 && pn.m <= kMcap) {
+                pf_base = reinterpret_cast<const uint32_t*>(p.matches + pn.match_off);
+                pf_lines = min(((uint32_t)pn.m * 16u + 127u) >> 7, 2u * NT);   // (the array's first line may start a little earlier: close enough)
+            }
+        }
+    }
+
     auto run_types = [&](auto crowded_c) -> int {
     constexpr bool CROWDED = decltype(crowded_c)::value;
     for (int g = 0; g < 4; ++g) {
@@ -1643,6 +1658,14 @@ __device__ __forceinline__ bool dense_pair_plain(const FilterParams& p, uint32_t
         const uint32_t x_mask = (gx ? kPEdgeX : 0u) | (gy ? kPEdgeY : 0u);              // x >= 20 || y >= 20 -> -1 (DLL@0x180047d3d)
         const uint32_t key_tag = (uint32_t)g << kDTagShift;
         const uint32_t nl_cur = kDenseFineOff + (uint32_t)(g & 1) * (kLeftN * 2u);      // crowded: 16-bit nLeft counters, two buffers
+        if (!CROWDED && g == p.prefetch_type && pf_lines) {
+            // touch the match records of the pair this CU's NEXT workgroup will filter (one dword per 128-byte line): they are in the
+            // XCD's L2 when that workgroup asks for them. Late on purpose -- one grid type before the end -- so that only a few
+            // CUs' worth of lines sit in the 4 MB at any time (touched at the start of a pair they are evicted before use).
+            // (two independent loads, consumed only before the copy-out: nothing waits for them here)
+            if ((uint32_t)tid < pf_lines) pf_sink = pf_base[32u * (uint32_t)tid];
+            if ((uint32_t)tid + NT < pf_lines) pf_sink2 = pf_base[32u * ((uint32_t)tid + NT)];
+        }
         if (!CROWDED && tid < kLeftN) {
             const uint32_t n = dense_nleft_cm(nfine8, tid % kLeftW, tid / kLeftW, gx, gy);
             if (n > 255u) misc[11] = 1;
@@ -1765,6 +1788,11 @@ __device__ __forceinline__ bool dense_pair_plain(const FilterParams& p, uint32_t
         return false;
     }
     GMS_STAMP(7);
+    if (p.prefetch_type == 4 && pf_lines) {  // (diagnostic setting: as late as possible)
+        if ((uint32_t)tid < pf_lines) pf_sink = pf_base[32u * (uint32_t)tid];
+        if ((uint32_t)tid + NT < pf_lines) pf_sink2 = pf_base[32u * ((uint32_t)tid + NT)];
+    }
+    if ((pf_sink ^ pf_sink2) == 0x9E3779B9u && p.n_pairs < 0) trash[0] = pf_sink;  // (never true: keeps the prefetch loads alive; they landed long ago)
 
     // ---- copy-out: surviving DMatch verbatim, in input order (DLL@0x180048340), from the registers (see dense_pair)
     constexpr int kWaves = NT / 64;
