@@ -1708,10 +1708,23 @@ __device__ __forceinline__ bool dense_pair_plain(const FilterParams& p, uint32_t
 
         // ---- verifyCellPairs
         if (tid < 2 * kLeftN) {
-            const uint32_t ni = CROWDED ? ldsa_ld16(nl_cur + 2u * vi) : ldsa_ld8(kDenseNleftOff + vi);
+            // (everything that does not depend on j* is read at once: the cell's nLeft, its header, the four neighbours' nLeft)
+            const int s1 = vodd ? -1 : 1;
+            const uint32_t nlb = (CROWDED ? nl_cur + 2u * vi : kDenseNleftOff + vi);
+            const uint32_t hdr = vi * kDenseRow;
+            const uint32_t ni = CROWDED ? ldsa_ld16(nlb) : ldsa_ld8(nlb);
+            const uint32_t hdr_word = ldsa_ld32(hdr);
+            uint32_t nl4[4];
+            {
+                constexpr int kD[4] = {-21, -20, -19, -1};
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const uint32_t na = nlb + (uint32_t)((CROWDED ? 2 : 1) * s1 * kD[c]);
+                    nl4[c] = CROWDED ? ldsa_ld16(na) : ldsa_ld8(na);
+                }
+            }
             if (__ballot(ni != 0) != 0ull) {
-                const uint32_t hdr = vi * kDenseRow;
-                const uint32_t best = ldsa_ld32(hdr) & ((1u << kDTagShift) - 1u);  // ((max count - 1) << 11) | E(j*), lowest j* among maxima
+                const uint32_t best = hdr_word & ((1u << kDTagShift) - 1u);  // ((max count - 1) << 11) | E(j*), lowest j* among maxima
                 const uint32_t ej = ni ? (best & kDEMask) : (uint32_t)(kDenseRightN + 3);
                 const uint32_t j = (uint32_t)(kDenseRightN + 3) - ej;
                 const uint32_t jy = (j * 3277u) >> 16, jx = j - 20u * jy;
@@ -1719,22 +1732,18 @@ __device__ __forceinline__ bool dense_pair_plain(const FilterParams& p, uint32_t
                 const bool okA = (vix != lo) & (jx != lo);   // one step against s along x stays inside both grids
                 const bool okB = (vix != hi) & (jx != hi);   // one step with s along x
                 const bool okC = (viy != lo) & (jy != lo);   // one step against s along y
-                const int s403 = vodd ? -403 : 403, s1 = vodd ? -1 : 1;
+                const int s403 = vodd ? -403 : 403;
                 const uint32_t base = hdr + ej;
-                const uint32_t nlb = (CROWDED ? nl_cur + 2u * vi : kDenseNleftOff + vi);
                 uint32_t score = 0, tn = 0;  // tn = (sum of nLeft << 4) | numpair
-                auto side = [&](int d, bool valid) {
+                auto side = [&](int c, int d, bool valid) {
                     const uint32_t a = valid ? base + (uint32_t)(s403 * d) : kPZeroByte;
-                    const uint32_t na = nlb + (uint32_t)((CROWDED ? 2 : 1) * s1 * d);
-                    const uint32_t cnt = ldsa_ld8(a);
-                    const uint32_t nll = CROWDED ? ldsa_ld16(na) : ldsa_ld8(na);
-                    score += cnt;
-                    tn += valid ? ((nll << 4) | 1u) : 0u;
+                    score += ldsa_ld8(a);
+                    tn += valid ? ((nl4[c] << 4) | 1u) : 0u;
                 };
-                side(-21, okA & okC);
-                side(-20, okC);
-                side(-19, okB & okC);
-                side(-1, okA);
+                side(0, -21, okA & okC);
+                side(1, -20, okC);
+                side(2, -19, okB & okC);
+                side(3, -1, okA);
                 score += dpp_xor1(score);
                 tn += dpp_xor1(tn);
                 score += (best >> 11) + 1u;  // centre pair: ll = i, rr = j*, the arg-max count itself
@@ -1792,7 +1801,8 @@ __device__ __forceinline__ bool dense_pair_plain(const FilterParams& p, uint32_t
         if ((uint32_t)tid < pf_lines) pf_sink = pf_base[32u * (uint32_t)tid];
         if ((uint32_t)tid + NT < pf_lines) pf_sink2 = pf_base[32u * ((uint32_t)tid + NT)];
     }
-    if ((pf_sink ^ pf_sink2) == 0x9E3779B9u && p.n_pairs < 0) trash[0] = pf_sink;  // (never true: keeps the prefetch loads alive; they landed long ago)
+    // (never true: keeps the prefetch loads alive; they landed long ago, and no copy-out store has been issued yet)
+    if (p.prefetch_type != 4 && (pf_sink ^ pf_sink2) == 0x9E3779B9u && p.n_pairs < 0) trash[0] = pf_sink;
 
     // ---- copy-out: surviving DMatch verbatim, in input order (DLL@0x180048340), from the registers (see dense_pair)
     constexpr int kWaves = NT / 64;
@@ -1804,7 +1814,13 @@ __device__ __forceinline__ bool dense_pair_plain(const FilterParams& p, uint32_t
     uint8_t* mask_out = p.mask ? p.mask + pr.match_off : nullptr;
     uint32_t total = 0;
     if (!dealt) {
+        uint32_t row_base[KPT];
+
+        // A chunk is 64 consecutive matches = one wave's k-th record; chunk (k, wave) sits at position k * 16 + wave of the order, so the
+        // sixteen chunks of one k are one 16-lane DPP row of the published counts: a row-wise scan on the vector ALU (four DPP adds
+        // per register, no LDS round trips), the rows' totals added up in scalar registers.
         constexpr int kScanRegs = (KPT * kWaves + 63) / 64;
+        static_assert(kWaves == 16, "one DPP row per k");
 #pragma unroll
         for (int k = 0; k < KPT; ++k)
             if (lane == 0) cnt_tab[k * kWaves + wave] = (uint32_t)__popcll(keep[k]);
@@ -1815,21 +1831,28 @@ __device__ __forceinline__ bool dense_pair_plain(const FilterParams& p, uint32_t
             const int idx = v * 64 + lane;
             const uint32_t c = idx < KPT * kWaves ? cnt_tab[idx] : 0u;
             uint32_t incl = c;
+            incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x111, 0xF, 0xF, true);  // row_shr:1, zeros shifted in
+            incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x112, 0xF, 0xF, true);
+            incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x114, 0xF, 0xF, true);
+            incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x118, 0xF, 0xF, true);
+            excl[v] = incl - c;  // within its row
+            (void)idx;
+            // totals of this register's rows, in order (scalar)
 #pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const uint32_t t = __shfl_up(incl, d);
-                if (lane >= d) incl += t;
+            for (int r = 0; r < 4; ++r) {
+                const int k = v * 4 + r;
+                if (k < KPT) {
+                    row_base[k] = total;
+                    total += (uint32_t)__builtin_amdgcn_readlane((int)incl, r * 16 + 15);
+                }
             }
-            excl[v] = total + incl - c;
-            total += __shfl(incl, 63);
         }
         GMS_STAMP(8);
+        const int wave_s = __builtin_amdgcn_readfirstlane(wave);
 #pragma unroll
         for (int k = 0; k < KPT; ++k) {
             const int i = k * NT + tid;
-            const int ch = k * kWaves + wave;
-            static_assert(64 % kWaves == 0, "a wave's chunk never straddles two scan registers");
-            const uint32_t base = __shfl(excl[(k * kWaves) >> 6], ch & 63);
+            const uint32_t base = row_base[k] + (uint32_t)__builtin_amdgcn_readlane((int)excl[k >> 2], (k & 3) * 16 + wave_s);
             if (i < m) {
                 const bool in = (keep[k] >> lane) & 1ull;
                 if (mask_out) mask_out[i] = in ? 1 : 0;
@@ -1885,6 +1908,7 @@ __device__ __forceinline__ bool dense_pair_plain(const FilterParams& p, uint32_t
     }
     GMS_STAMP(9);
     GMS_STAMP_FLUSH;
+    if (p.prefetch_type == 4 && (pf_sink ^ pf_sink2) == 0x9E3779B9u && p.n_pairs < 0) trash[0] = pf_sink;
     if (tid == 0) {
         gms_pair_result r;
         r.n_inliers = (int)total;
