@@ -1430,6 +1430,9 @@ __device__ __forceinline__ bool dense_pair(const FilterParams& p, uint32_t* smem
 //   * verification: the eight neighbour pairs of a cell are base + s * 403 * d for d in {-21, -20, -19, -1} and s = +-1 (the two
 //     lanes of a cell), their validity three compares per axis; an invalid pair reads a byte that is always zero.
 // ------------------------------------------------------------------------------------------------
+// The match records are read once and the survivors written once: non-temporal, so that what the L2 keeps is the lines a
+// workgroup touches ahead for its successor (below) -- with plain loads and stores a good part of those is evicted before use.
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 using lds_u32_t = __attribute__((address_space(3))) uint32_t;
 using lds_u16_t = __attribute__((address_space(3))) uint16_t;
 using lds_u8_t = __attribute__((address_space(3))) uint8_t;
@@ -1539,7 +1542,7 @@ __device__ __forceinline__ bool dense_pair_plain(const FilterParams& p, uint32_t
     uint2 qt[kKeepRec ? 1 : KPT];
 #pragma unroll
     for (int k = 0; k < KPT; ++k) {
-        if (kKeepRec) rec[k] = *reinterpret_cast<const uint4*>(&matches[min(match_of(k), m - 1)]);
+        if (kKeepRec) { const u32x4_t rv = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(&matches[min(match_of(k), m - 1)])); rec[k] = make_uint4(rv.x, rv.y, rv.z, rv.w); }
         else qt[k] = *reinterpret_cast<const uint2*>(&matches[min(match_of(k), m - 1)]);
     }
     auto query_of = [&](int k) -> uint32_t { return kKeepRec ? rec[k].x : qt[k].x; };
@@ -1858,7 +1861,7 @@ __device__ __forceinline__ bool dense_pair_plain(const FilterParams& p, uint32_t
                 if (mask_out) mask_out[i] = in ? 1 : 0;
                 if (in) {
                     const uint32_t pos = base + (uint32_t)__popcll(keep[k] & ((1ull << lane) - 1ull));
-                    *reinterpret_cast<uint4*>(&out[pos]) = kKeepRec ? rec[k] : *reinterpret_cast<const uint4*>(&matches[i]);
+                    { const uint4 rv = kKeepRec ? rec[k] : *reinterpret_cast<const uint4*>(&matches[i]); __builtin_nontemporal_store(u32x4_t{rv.x, rv.y, rv.z, rv.w}, reinterpret_cast<u32x4_t*>(&out[pos])); }
                 }
             }
         }
@@ -1901,7 +1904,7 @@ __device__ __forceinline__ bool dense_pair_plain(const FilterParams& p, uint32_t
                 if (mask_out) mask_out[i] = in ? 1 : 0;
                 if (in) {
                     const uint32_t pos = cnt_tab[i >> 3] + (uint32_t)__popc(byte & ((1u << (lane & 7)) - 1u));
-                    *reinterpret_cast<uint4*>(&out[pos]) = kKeepRec ? rec[k] : *reinterpret_cast<const uint4*>(&matches[i]);
+                    { const uint4 rv = kKeepRec ? rec[k] : *reinterpret_cast<const uint4*>(&matches[i]); __builtin_nontemporal_store(u32x4_t{rv.x, rv.y, rv.z, rv.w}, reinterpret_cast<u32x4_t*>(&out[pos])); }
                 }
             }
         }
