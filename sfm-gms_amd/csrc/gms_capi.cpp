@@ -326,14 +326,14 @@ int filter_launch(gms_ctx* c, hipStream_t st, const float* d_pts, const int64_t*
     }
     const int force_deal = c->opt_deal >= 0 ? c->opt_deal : knobs().deal, force_probe = c->opt_probe >= 0 ? c->opt_probe : knobs().scale_probe;
     p.dealt = (p.dense && kpt && (force_deal >= 0 ? force_deal != 0 : c->use_dealt != 0)) ? 1 : 0;
-    // First-round stagger: the spread is about one pair's duration on the path the launch will mostly take -- 26 us (byte
+    // First-round stagger: the spread is about two thirds of a pair's duration on the path the launch will mostly take -- 16 us (byte
     // matrix) / 72 us (hashed) at 10k matches, in proportion to max_m -- in ticks of the 100 MHz wall clock. Only launches of
     // at least four dispatch rounds are staggered, and none with scale hypotheses on the byte matrix: a pair takes ten times as
     // long there and its loads are a small share of it, so the spread only delays (1.12 ms against 1.18 per 2048 pairs without).
     const bool scales_on_matrix = with_scale && knobs().dense_on;
     p.stagger_ticks = 0;
     if (n_pairs >= 4 * p.stagger_blocks && kpt && max_m >= 2048) {  // (measured neutral at 4k matches, -1 % at 500: tools/measure_misc.py)
-        const double us10k = knobs().stagger_us >= 0 ? (double)knobs().stagger_us : (scales_on_matrix ? 0.0 : p.dense ? 26.0 : 72.0);
+        const double us10k = knobs().stagger_us >= 0 ? (double)knobs().stagger_us : (scales_on_matrix ? 0.0 : p.dense ? 16.0 : 72.0);
         p.stagger_ticks = (int)(us10k * 100.0 * max_m / 10000.0);
     }
 #ifdef GMS_PHASE_TIMING

@@ -44,6 +44,49 @@ __device__ __forceinline__ uint32_t* lds_at(uint32_t* base, uint32_t byte_off)
     return reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(base) + byte_off);
 }
 
+// ---- idioms of the byte-matrix kernels that count their instructions (dense_pair_plain in gms_kernels.hip, stream_plain_kernel in
+//      gms_kernel_stream.hip): LDS by absolute byte offset (the dynamic segment of these kernels starts at 0, so no "+ base" per access),
+//      non-temporal record traffic, two instructions the compiler does not pick by itself
+// The match records are read once and the survivors written once: non-temporal, so that what the L2 keeps is the lines a
+// workgroup touches ahead for its successor (below) -- with plain loads and stores a good part of those is evicted before use.
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+using lds_u32_t = __attribute__((address_space(3))) uint32_t;
+using lds_u16_t = __attribute__((address_space(3))) uint16_t;
+using lds_u8_t = __attribute__((address_space(3))) uint8_t;
+__device__ __forceinline__ uint32_t ldsa_add_rtn(uint32_t a, uint32_t v)
+{
+    return __hip_atomic_fetch_add(reinterpret_cast<lds_u32_t*>((uintptr_t)a), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void ldsa_add(uint32_t a, uint32_t v)
+{
+    (void)__hip_atomic_fetch_add(reinterpret_cast<lds_u32_t*>((uintptr_t)a), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void ldsa_max(uint32_t a, uint32_t v)
+{
+    (void)__hip_atomic_fetch_max(reinterpret_cast<lds_u32_t*>((uintptr_t)a), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ uint32_t ldsa_ld32(uint32_t a) { return *reinterpret_cast<lds_u32_t*>((uintptr_t)a); }
+__device__ __forceinline__ uint32_t ldsa_ld16(uint32_t a) { return *reinterpret_cast<lds_u16_t*>((uintptr_t)a); }
+__device__ __forceinline__ uint32_t ldsa_ld8(uint32_t a) { return *reinterpret_cast<lds_u8_t*>((uintptr_t)a); }
+__device__ __forceinline__ void ldsa_st32(uint32_t a, uint32_t v) { *reinterpret_cast<lds_u32_t*>((uintptr_t)a) = v; }
+__device__ __forceinline__ void ldsa_st8(uint32_t a, uint32_t v) { *reinterpret_cast<lds_u8_t*>((uintptr_t)a) = (uint8_t)v; }
+
+// a * b + c on the 24-bit multiplier, b in a scalar register (the compiler turns the builtin multiply + add into the quarter-rate
+// v_mad_u64_u32 when it cannot see that the factors are short)
+__device__ __forceinline__ uint32_t mad24_vsv(uint32_t a, uint32_t b, uint32_t c)
+{
+    uint32_t d;
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "s"(b), "v"(c));
+    return d;
+}
+// bits = 2 * bits + (a == b): a compare and an add-with-carry
+__device__ __forceinline__ uint32_t shift_in_equal(uint32_t bits, uint32_t a, uint32_t b)
+{
+    uint32_t d;
+    asm("v_cmp_eq_u32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %3, %3, vcc" : "=v"(d) : "v"(a), "v"(b), "v"(bits) : "vcc");
+    return d;
+}
+
 // verifyCellPairs' test "thresh = sqrt(T / n) * factor; reject iff thresh > score" (divsd, sqrtsd, mulsd, comisd at
 // DLL@0x180049171). In exact arithmetic (factor > 0) it is T * factor^2 > score^2 * n. b = score^2 * n is exact in
 // fp64 (< 2^53) and a = fl(fl(T * factor) * factor) is within 2^-51 of exact, while the reference's three roundings

@@ -25,6 +25,7 @@
 // only. Bit-exactness rules are those of gms_kernels.hip (same codes, same arg-max and tie rules, same threshold arithmetic).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include <type_traits>
 
@@ -860,6 +861,294 @@ stream_dense_kernel(FilterParams p, uint32_t* __restrict__ codes_ws, uint16_t* _
     }
 }
 
+// ================================================================================================================================
+// The same size class under the DEFAULT flags (no rotation either: DisparityUtil.cpp:149,299 -- BASELINE config 4 as the reference's
+// disparity demo calls it): stream_plain_kernel = stream_dense_kernel<false> rebuilt the way dense_pair_plain (gms_kernels.hip) rebuilt
+// the register kernel -- entry-offset code words ([404 * cell + E : 18 | E : 9 | q and edge bits : 5]) in the scratch array, a per-lane
+// sink word instead of predication, LDS by absolute offset, the two-lane verification on base + s * 403 * d -- and with what the
+// streaming allows on top: the inlier flag of a match is one bit of two registers of its thread (a thread owns matches tid + 1024 k,
+// k < 64), so the code words are written once and only read afterwards (the old kernel read-modify-wrote them in every marking pass
+// and swept them three more times for the copy-out), and the records travel non-temporally.
+// ================================================================================================================================
+namespace {
+constexpr uint32_t kSPTrashOff = kDSMiscOff + 128u;         // [16] dwords: the sinks
+constexpr uint32_t kSPLdsBytes = kSPTrashOff + 64u;         // 162 592
+static_assert(kSPLdsBytes <= kLdsBytes, "stream-plain layout exceeds the LDS");
+constexpr uint32_t kSPEdgeX = 1u << 1, kSPEdgeY = 1u << 3;  // plain code word (as in gms_kernels.hip)
+constexpr int kSPEShift = 5, kSPAtShift = 14, kSPTagShift = 20;
+}  // namespace
+
+__global__ void __launch_bounds__(1024)
+stream_plain_kernel(FilterParams p, uint32_t* __restrict__ codes_ws, uint16_t* __restrict__ nleft_ws, uint32_t* __restrict__ flags, int mcap)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    constexpr int kC = 8;  // code words a thread has in flight
+    const int pi = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const gms_pair pr = p.pairs[pi];
+    const int m = pr.m;
+    uint32_t* misc = smem + kDSMiscOff / 4;
+    const int64_t total_kp = table_total_kp(p);
+    bool general = m <= 0 || m > mcap || m > 64 * 1024 || pr.frame_a < 0 || pr.frame_a >= p.n_frames || pr.frame_b < 0 || pr.frame_b >= p.n_frames ||
+                   total_kp < 0 || (uint32_t)(uintptr_t)((lds_u32_t*)smem) != 0u;
+    int64_t offA = 0, offB = 0;
+    int nA = 0, nB = 0;
+    if (!general) {
+        offA = p.frame_off[pr.frame_a];
+        offB = p.frame_off[pr.frame_b];
+        nA = (int)(p.frame_off[pr.frame_a + 1] - offA);
+        nB = (int)(p.frame_off[pr.frame_b + 1] - offB);
+        general = nA <= 0 || nB <= 0 || offA + nA > total_kp || offB + nB > total_kp;
+    }
+    if (general) {  // (workgroup-uniform) nothing this kernel can take: the general kernel decides what the pair is
+        if (tid == 0) atomicOr(&flags[pi], kSFlagGeneral);
+        return;
+    }
+    const gms_dmatch* __restrict__ matches = p.matches + pr.match_off;
+    const uint16_t* __restrict__ lcode = reinterpret_cast<const uint16_t*>(p.pts + total_kp) + offA;
+    const uint16_t* __restrict__ rcode = reinterpret_cast<const uint16_t*>(p.pts + total_kp) + total_kp + offB;
+    uint32_t* __restrict__ codes = codes_ws + (size_t)pi * mcap;
+    uint16_t* __restrict__ nl_g = nleft_ws + (size_t)pi * 4 * kLeftN;
+    const int kpt = (m + 1023) >> 10;
+    const uint32_t cw_sink = (kSPTrashOff + 4u * (uint32_t)(lane & 15)) << kSPAtShift;  // E = 0, q = 0, no edge bit
+
+    // ---- the code words and the half-cell histogram (u32, one dword per half cell: [cell][qx + 2 qy], in the still unused matrix area)
+    uint32_t* hist = smem;
+    for (int j = tid; j < kFineN; j += 1024) hist[j] = 0;
+    if (tid < 32) misc[tid] = 0;
+    __syncthreads();
+    {
+        bool any_bad = false;
+        for (int k0 = 0; k0 < kpt; k0 += kC) {
+            uint2 qt[kC];
+#pragma unroll
+            for (int j = 0; j < kC; ++j) qt[j] = *reinterpret_cast<const uint2*>(&matches[min((k0 + j) * 1024 + tid, m - 1)]);
+            uint32_t ca[kC], cb[kC];
+#pragma unroll
+            for (int j = 0; j < kC; ++j) {
+                ca[j] = lcode[min(qt[j].x, (uint32_t)(nA - 1))];
+                cb[j] = rcode[min(qt[j].y, (uint32_t)(nB - 1))];
+            }
+#pragma unroll
+            for (int j = 0; j < kC; ++j) {
+                const int i = (k0 + j) * 1024 + tid;
+                const bool live = i < m;
+                const uint32_t cell = ca[j] >> 7, e0 = cb[j] & 0x1FFu;  // cell: 510 = binned under no grid type, 511 = outside the parity domain
+                const bool ok = qt[j].x < (uint32_t)nA && qt[j].y < (uint32_t)nB && cell != 511u && (cb[j] >> 15) == 0u && e0 != 0u;
+                const bool binned = live && ok && cell < 510u;
+                any_bad |= live && !ok;
+                const uint32_t qx = ca[j] & 1u, qy = (ca[j] >> 2) & 1u;
+                if (binned) atomicAdd(&hist[cell * 4u + qx + 2u * qy], 1u);
+                const uint32_t qe = (ca[j] & 21u) | ((ca[j] >> 4) & kSPEdgeX) | ((ca[j] >> 3) & kSPEdgeY);
+                const uint32_t cw = binned ? (((__umul24(cell, kDRow) + e0) << kSPAtShift) | (e0 << kSPEShift) | qe) : cw_sink;
+                if (live) codes[i] = cw;
+            }
+        }
+        if (any_bad) misc[8] = 1;
+    }
+    __syncthreads();
+    if (misc[8] != 0) {  // an index out of range, a point outside the parity domain or outside the right grid: the general kernel's pair
+        if (tid == 0) atomicOr(&flags[pi], kSFlagGeneral);
+        return;
+    }
+    for (int item = tid; item < 4 * kLeftN; item += 1024) {
+        const int g = item / kLeftN, cell = item - g * kLeftN;
+        const int hx0 = 2 * (cell % kLeftW) - (g & 1), hy0 = 2 * (cell / kLeftW) - (g >> 1);
+        uint32_t n = 0;
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) {
+                const int hx = hx0 + dx, hy = hy0 + dy;
+                if (hx >= 0 && hy >= 0) n += hist[(((hy >> 1) * kLeftW + (hx >> 1)) << 2) + (hx & 1) + ((hy & 1) << 1)];
+            }
+        if (n > 65535u) misc[9] = 1;
+        nl_g[item] = (uint16_t)n;
+    }
+    __syncthreads();
+    if (misc[9] != 0) {  // a cell above 65 535 matches
+        if (tid == 0) {
+            atomicOr(&flags[pi], kSFlagGeneral);
+            if (p.overflow_events) atomicAdd(p.overflow_events, 1u);
+        }
+        return;
+    }
+    {   // motion.setTo(0), once: every grid type leaves the matrix as it found it; the sinks get bit 31 (nothing below ever clears it:
+        // a sink is never equal to an E, so a sink word is nobody's inlier -- see dense_pair_plain)
+        const uint4 z4 = make_uint4(0, 0, 0, 0);
+        uint4* d4 = reinterpret_cast<uint4*>(smem);
+        for (uint32_t i = tid; i < kDSNleftOff / 16u; i += 1024) d4[i] = z4;
+        if (tid < 16) smem[kSPTrashOff / 4 + tid] = 0x80000000u;
+    }
+    const bool thr_fast = threshold_fast_ok(p.threshold_factor);
+    uint32_t acc[2] = {0u, 0u};  // match tid + 1024 k: bit (k & 24) + 7 - (k & 7) of acc[k >> 5]
+
+    for (int g = 0; g < 4; ++g) {
+        const uint32_t gx = (uint32_t)(g & 1), gy = (uint32_t)(g >> 1);
+        const uint32_t q_mask = gx + 20u * gy;                                      // entry = entry1 + 404 * (q & q_mask)
+        const uint32_t x_mask = (gx ? kSPEdgeX : 0u) | (gy ? kSPEdgeY : 0u);        // x >= 20 || y >= 20 -> -1 (DLL@0x180047d3d)
+        const uint32_t tag = (uint32_t)g << kSPTagShift;  // (bits 20, 21: byte 3 of a row header stays zero)
+        if (tid < kLeftN / 2) ldsa_st32(kDSNleftOff + 4u * (uint32_t)tid, reinterpret_cast<const uint32_t*>(nl_g + g * kLeftN)[tid]);
+        __syncthreads();  // (the matrix clear / the previous grid type's undo are complete)
+        // ---- assignMatchPairs
+        for (int k0 = 0; k0 < kpt; k0 += kC) {
+            uint32_t cw[kC];
+#pragma unroll
+            for (int j = 0; j < kC; ++j) {
+                const int i = (k0 + j) * 1024 + tid;
+                cw[j] = i < m ? codes[i] : cw_sink;
+            }
+            uint32_t old[kC], at[kC], e[kC];
+#pragma unroll
+            for (int j = 0; j < kC; ++j) {
+                const uint32_t cg = (cw[j] & x_mask) ? cw_sink : cw[j];
+                at[j] = mad24_vsv(cg & q_mask, kDRow, cg >> kSPAtShift);
+                e[j] = (cg >> kSPEShift) & 0x1FFu;
+                old[j] = ldsa_add_rtn(at[j] & ~3u, 1u << ((at[j] << 3) & 31u));
+            }
+            __builtin_amdgcn_sched_barrier(0);  // all of the chunk's atomics are issued before any result is read
+#pragma unroll
+            for (int j = 0; j < kC; ++j) {
+                const uint32_t before = __builtin_amdgcn_ubfe(old[j], at[j] << 3, 8);
+                if (e[j] != 0u && before == 255u) misc[9] = 1;  // the entry's byte has just wrapped: more than 255 matches in one (left cell, right cell) pair
+                ldsa_max(at[j] - e[j], tag | (before << kKeyCountShift) | e[j]);  // highest count, then lowest right cell
+            }
+        }
+        __syncthreads();
+        if (misc[9] != 0) {  // (workgroup-uniform) the general kernel's pair; nothing has been written out
+            if (tid == 0) {
+                atomicOr(&flags[pi], kSFlagGeneral);
+                if (p.overflow_events) atomicAdd(p.overflow_events, 1u);
+            }
+            return;
+        }
+        // ---- verifyCellPairs: two lanes per cell (see dense_pair_plain)
+        if (tid < 2 * kLeftN) {
+            const uint32_t vi = (uint32_t)tid >> 1;
+            const uint32_t viy = (vi * 3277u) >> 16, vix = vi - 20u * viy;
+            const bool vodd = (tid & 1) != 0;
+            const int s1 = vodd ? -1 : 1;
+            const uint32_t nlb = kDSNleftOff + 2u * vi, hdr = vi * kDRow;
+            const uint32_t ni = ldsa_ld16(nlb);
+            const uint32_t hdr_word = ldsa_ld32(hdr);
+            uint32_t nl4[4];
+            {
+                constexpr int kD[4] = {-21, -20, -19, -1};
+#pragma unroll
+                for (int c = 0; c < 4; ++c) nl4[c] = ldsa_ld16(nlb + (uint32_t)(2 * s1 * kD[c]));
+            }
+            if (__ballot(ni != 0) != 0ull) {
+                const uint32_t best = hdr_word & ((1u << kSPTagShift) - 1u);  // ((max count - 1) << 11) | E(j*), lowest j* among maxima
+                const uint32_t ej = ni ? (best & 0x7FFu) : 403u;
+                const uint32_t j = 403u - ej;
+                const uint32_t jy = (j * 3277u) >> 16, jx = j - 20u * jy;
+                const uint32_t lo = vodd ? 19u : 0u, hi = 19u - lo;
+                const bool okA = (vix != lo) & (jx != lo), okB = (vix != hi) & (jx != hi), okC = (viy != lo) & (jy != lo);
+                const int s403 = vodd ? -403 : 403;
+                const uint32_t base = hdr + ej;
+                uint32_t score = 0, tsum = 0, np = 0;
+                auto side = [&](int c, int d, bool valid) {
+                    score += ldsa_ld8(valid ? base + (uint32_t)(s403 * d) : 3u);  // (byte 3 of a row header is zero at all times)
+                    tsum += valid ? nl4[c] : 0u;
+                    np += valid ? 1u : 0u;
+                };
+                side(0, -21, okA & okC);
+                side(1, -20, okC);
+                side(2, -19, okB & okC);
+                side(3, -1, okA);
+                score += dpp_xor1(score);
+                tsum += dpp_xor1(tsum);
+                np += dpp_xor1(np);
+                score += (best >> kKeyCountShift) + 1u;  // centre pair: ll = i, rr = j*, the arg-max count itself
+                tsum += ni;
+                np += 1u;
+                if (ni != 0 && !vodd) ldsa_st32(hdr, threshold_rejects(tsum, np, score, p.threshold_factor, thr_fast) ? 0u : ej);  // cellPairs[i] as E(j*), 0 = none
+            }
+        }
+        __syncthreads();
+        // ---- mark inliers (cellPairs[l] == r) and take this grid type's increments back
+        for (int k0 = 0; k0 < kpt; k0 += kC) {
+            uint32_t cw[kC];
+#pragma unroll
+            for (int j = 0; j < kC; ++j) {
+                const int i = (k0 + j) * 1024 + tid;
+                cw[j] = i < m ? codes[i] : cw_sink;
+            }
+            uint32_t cur = 0;
+#pragma unroll
+            for (int j = 0; j < kC; ++j) {
+                const uint32_t cg = (cw[j] & x_mask) ? cw_sink : cw[j];
+                const uint32_t at = mad24_vsv(cg & q_mask, kDRow, cg >> kSPAtShift), e = (cg >> kSPEShift) & 0x1FFu;
+                const uint32_t cr = ldsa_ld32(at - e);  // (a sink's own dword: never equal to its E = 0)
+                ldsa_st8(at, 0u);
+                cur = shift_in_equal(cur, cr, e);       // match j of the chunk ends up in bit 7 - j
+            }
+            if (k0 < 32) acc[0] |= cur << (k0 & 31);
+            else acc[1] |= cur << (k0 & 31);
+        }
+    }
+    __syncthreads();
+
+    // ---- copy-out: survivors per chunk of 64 consecutive matches (chunk k * 16 + wave), scanned; then the records, in input order
+    const unsigned long long accq = (unsigned long long)acc[0] | ((unsigned long long)acc[1] << 32);
+    auto kept = [&](int k) -> bool { return ((accq >> ((k & 56) + 7 - (k & 7))) & 1ull) != 0ull; };
+    uint32_t* cnt_tab = smem;  // in the matrix area (every reader of the matrix is past the barrier above)
+    uint32_t* wave_tot = misc + 16;
+    for (int k = 0; k < kpt; ++k) {
+        const unsigned long long b = __ballot(k * 1024 + tid < m && kept(k));
+        if (lane == 0) cnt_tab[k * 16 + wave] = (uint32_t)__popcll(b);
+    }
+    __syncthreads();
+    uint32_t total = 0;
+    {
+        const int n_chunks = kpt * 16;  // <= 1024: one scan entry per thread
+        const uint32_t c = tid < n_chunks ? cnt_tab[tid] : 0u;
+        uint32_t incl = c;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t t = __shfl_up(incl, d);
+            if (lane >= d) incl += t;
+        }
+        if (lane == 63) wave_tot[wave] = incl;
+        __syncthreads();
+        uint32_t off = 0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) {
+            const uint32_t tw = wave_tot[w];
+            off += w < wave ? tw : 0u;
+            total += tw;
+        }
+        if (tid < n_chunks) cnt_tab[tid] = off + incl - c;
+    }
+    __syncthreads();
+    gms_dmatch* __restrict__ out = p.out + pr.match_off;
+    uint8_t* mask_out = p.mask ? p.mask + pr.match_off : nullptr;
+    for (int k = 0; k < kpt; ++k) {
+        const int i = k * 1024 + tid;
+        const bool keep = i < m && kept(k);
+        const unsigned long long b = __ballot(keep);
+        if (i < m && mask_out) mask_out[i] = keep ? 1 : 0;
+        if (keep) {
+            const uint32_t pos = cnt_tab[k * 16 + wave] + (uint32_t)__popcll(b & ((1ull << lane) - 1ull));
+            __builtin_nontemporal_store(__builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(&matches[i])), reinterpret_cast<u32x4_t*>(&out[pos]));
+        }
+    }
+    if (tid == 0) {
+        gms_pair_result r;
+        r.n_inliers = (int)total;
+        r.best_scale = total ? 0 : -1;
+        r.best_rot = total ? 1 : -1;
+        r.status = GMS_OK;
+        p.results[pi] = r;
+    }
+}
+
+// GMS_STREAM_PLAIN=0 (diagnostic, read once per process): the default-flags pairs of this size class on stream_dense_kernel<false> instead
+static bool stream_plain_on()
+{
+    static const bool on = [] { const char* e = getenv("GMS_STREAM_PLAIN"); return !(e && atoi(e) == 0); }();
+    return on;
+}
+
 size_t stream_dense_ws_bytes_per_pair(int mcap) { return (size_t)mcap * 4 + 4 * (size_t)kLeftN * 2 + 4 + 64; }
 
 // ws layout for n pairs: codes [n][mcap] u32 | nleft [n][4][400] u16 | flags [n]; *flags_out marks the pairs left to launch_filter_big (bit 1)
@@ -877,6 +1166,7 @@ hipError_t launch_filter_stream_dense(const FilterParams& p, int mcap, void* ws,
     hipError_t e = hipMemsetAsync(flags, 0, (size_t)n * 4, stream);
     if (e != hipSuccess) return e;
     if (p.with_rotation) hipLaunchKernelGGL(stream_dense_kernel<true>, dim3((unsigned)n), dim3(1024), kDSLdsBytes, stream, p, codes, nleft, flags, mcap);
+    else if (stream_plain_on()) hipLaunchKernelGGL(stream_plain_kernel, dim3((unsigned)n), dim3(1024), kSPLdsBytes, stream, p, codes, nleft, flags, mcap);
     else hipLaunchKernelGGL(stream_dense_kernel<false>, dim3((unsigned)n), dim3(1024), kDSLdsBytes, stream, p, codes, nleft, flags, mcap);
     *flags_out = flags;
     return hipGetLastError();
@@ -886,7 +1176,8 @@ hipError_t launch_filter_stream_dense(const FilterParams& p, int mcap, void* ws,
 hipError_t init_stream_kernels()  // once per context: see init_filter_kernels
 {
     const void* fns[] = {reinterpret_cast<const void*>(stream_filter_kernel<true>), reinterpret_cast<const void*>(stream_filter_kernel<false>),
-                         reinterpret_cast<const void*>(stream_dense_kernel<true>), reinterpret_cast<const void*>(stream_dense_kernel<false>)};
+                         reinterpret_cast<const void*>(stream_dense_kernel<true>), reinterpret_cast<const void*>(stream_dense_kernel<false>),
+                         reinterpret_cast<const void*>(stream_plain_kernel)};
     for (const void* fn : fns) {
         const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes);
         if (e != hipSuccess) return e;

@@ -1430,46 +1430,6 @@ __device__ __forceinline__ bool dense_pair(const FilterParams& p, uint32_t* smem
 //   * verification: the eight neighbour pairs of a cell are base + s * 403 * d for d in {-21, -20, -19, -1} and s = +-1 (the two
 //     lanes of a cell), their validity three compares per axis; an invalid pair reads a byte that is always zero.
 // ------------------------------------------------------------------------------------------------
-// The match records are read once and the survivors written once: non-temporal, so that what the L2 keeps is the lines a
-// workgroup touches ahead for its successor (below) -- with plain loads and stores a good part of those is evicted before use.
-typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
-using lds_u32_t = __attribute__((address_space(3))) uint32_t;
-using lds_u16_t = __attribute__((address_space(3))) uint16_t;
-using lds_u8_t = __attribute__((address_space(3))) uint8_t;
-__device__ __forceinline__ uint32_t ldsa_add_rtn(uint32_t a, uint32_t v)
-{
-    return __hip_atomic_fetch_add(reinterpret_cast<lds_u32_t*>((uintptr_t)a), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-__device__ __forceinline__ void ldsa_add(uint32_t a, uint32_t v)
-{
-    (void)__hip_atomic_fetch_add(reinterpret_cast<lds_u32_t*>((uintptr_t)a), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-__device__ __forceinline__ void ldsa_max(uint32_t a, uint32_t v)
-{
-    (void)__hip_atomic_fetch_max(reinterpret_cast<lds_u32_t*>((uintptr_t)a), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-__device__ __forceinline__ uint32_t ldsa_ld32(uint32_t a) { return *reinterpret_cast<lds_u32_t*>((uintptr_t)a); }
-__device__ __forceinline__ uint32_t ldsa_ld16(uint32_t a) { return *reinterpret_cast<lds_u16_t*>((uintptr_t)a); }
-__device__ __forceinline__ uint32_t ldsa_ld8(uint32_t a) { return *reinterpret_cast<lds_u8_t*>((uintptr_t)a); }
-__device__ __forceinline__ void ldsa_st32(uint32_t a, uint32_t v) { *reinterpret_cast<lds_u32_t*>((uintptr_t)a) = v; }
-__device__ __forceinline__ void ldsa_st8(uint32_t a, uint32_t v) { *reinterpret_cast<lds_u8_t*>((uintptr_t)a) = (uint8_t)v; }
-
-// a * b + c on the 24-bit multiplier, b in a scalar register (the compiler turns the builtin multiply + add into the quarter-rate
-// v_mad_u64_u32 when it cannot see that the factors are short)
-__device__ __forceinline__ uint32_t mad24_vsv(uint32_t a, uint32_t b, uint32_t c)
-{
-    uint32_t d;
-    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "s"(b), "v"(c));
-    return d;
-}
-// bits = 2 * bits + (a == b): a compare and an add-with-carry
-__device__ __forceinline__ uint32_t shift_in_equal(uint32_t bits, uint32_t a, uint32_t b)
-{
-    uint32_t d;
-    asm("v_cmp_eq_u32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %3, %3, vcc" : "=v"(d) : "v"(a), "v"(b), "v"(bits) : "vcc");
-    return d;
-}
-
 // plain code word
 constexpr uint32_t kPEdgeX = 1u << 1, kPEdgeY = 1u << 3;  // in the gaps of q = (hx & 1) + 20 (hy & 1) (bits 0, 2, 4)
 constexpr int kPEShift = 5;                                // bits 5..13  E(r); 0 = the sink word (binned nowhere)
