@@ -626,7 +626,8 @@ def main():
 
     wall, kern_ms = timed_steps(ctx, wl, stream, args.steps, args.warmup, False, False, dist)
     wall_max = distmod.max_over_ranks(wall, dist)  # whole-job time = the slowest rank
-    variant = {"dealt": bool(ctx.query(1)), "matches_per_thread": ctx.query(3)}  # which bit-identical instantiation the timed launches ran
+    variant = {"dealt": bool(ctx.query(1)), "matches_per_thread": ctx.query(3),  # which bit-identical instantiation the timed launches ran
+               "touch_ahead": {"before_grid_type": ctx.query(6), "pairs_ahead": ctx.query(7)}, "first_round_stagger_us": ctx.query(8) / 100.0}
     value = wl.n_pairs * world * args.steps / wall_max
 
     # ---- parity on every rank: the sampled pairs of every resident chunk, as the timed launches left them

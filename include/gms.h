@@ -118,6 +118,10 @@ int  gms_ctx_reserve(gms_ctx* ctx, int n_pairs, int max_m, int with_rotation, in
 #define GMS_QUERY_LAST_KPT          3 /* matches per thread of the workgroup kernel (0: the large-pair kernels ran)        */
 #define GMS_QUERY_LAUNCHES          4 /* filter launches of the context so far                                             */
 #define GMS_QUERY_CUS               5 /* compute units of the context's device                                             */
+#define GMS_QUERY_PREFETCH_TYPE     6 /* byte-matrix kernel: grid type (0..3) before which a workgroup touches the match records of
+                                         the pair its CU's next workgroup will filter, so that they wait in L2 (-1: never)        */
+#define GMS_QUERY_PREFETCH_AHEAD    7 /* ... how many pairs ahead that pair is (the number of CUs unless GMS_PREFETCH says otherwise) */
+#define GMS_QUERY_STAGGER_TICKS     8 /* first-round start spread of the most recent launch, in 10 ns ticks (0: none)             */
 int  gms_ctx_query(gms_ctx* ctx, int what, int64_t* value);
 /* Forces one of those choices for the context's later launches (value 0 / 1), or hands it back to the library (-1, the default).
  * Speed only: every variant produces the same bytes. The environment switches GMS_DEAL / GMS_SCALE_PROBE do the same process-wide. */

@@ -73,7 +73,7 @@ class GmsContext:
         _check(self._lib.gms_ctx_set_option(self._h, int(option), int(value)), self._lib, "gms_ctx_set_option")
 
     def query(self, what):
-        """gms_ctx_query: 1 = last launch dealt, 2 = its scale-probe mask, 3 = its matches per thread, 4 = launches, 5 = CUs."""
+        """gms_ctx_query: 1 = last launch dealt, 2 = its scale-probe mask, 3 = its matches per thread, 4 = launches, 5 = CUs, 6 / 7 = touch-ahead grid type / pairs ahead, 8 = last launch's first-round stagger (10 ns ticks)."""
         v = C.c_int64(0)
         _check(self._lib.gms_ctx_query(self._h, int(what), C.byref(v)), self._lib, "gms_ctx_query")
         return int(v.value)

@@ -175,7 +175,7 @@ struct gms_ctx {
     // The host never reads a pinned word that a kernel may be writing: a verdict kernel is followed by an event, and the first
     // launch (or gms_ctx_synchronize) that finds the event complete ADOPTS the words; launches run on the adopted values in between.
     // last_* = what the most recent launch ran with (gms_ctx_query).
-    int use_dealt = 0, use_probe = 1, last_dealt = 0, last_probe = 0, last_kpt = 0;
+    int use_dealt = 0, use_probe = 1, last_dealt = 0, last_probe = 0, last_kpt = 0, last_stagger_ticks = 0;
     hipEvent_t verdict_event = nullptr;
     bool verdict_pending = false;
     unsigned filter_launches = 0;  // every launch of the context (pair-table validation every sixteenth)
@@ -402,6 +402,7 @@ int filter_launch(gms_ctx* c, hipStream_t st, const float* d_pts, const int64_t*
     c->last_dealt = p.dealt;
     c->last_probe = p.probe_scales;
     c->last_kpt = kpt;
+    c->last_stagger_ticks = p.stagger_ticks;
     // pair-table validation (ranges [match_off, match_off + m) must be disjoint: include/gms.h), behind the filter: offenders'
     // status becomes GMS_ERR_BAD_ARG. The first launch of a context and every sixteenth; never inside a stream capture.
     if (n_pairs > 1 && !capturing && knobs().check_pairs != 0 && (knobs().check_pairs == 1 || (c->filter_launches & 15u) == 0u))
@@ -610,6 +611,9 @@ int gms_ctx_query(gms_ctx* c, int what, int64_t* value)
     case GMS_QUERY_LAST_KPT: *value = c->last_kpt; return GMS_OK;
     case GMS_QUERY_LAUNCHES: *value = (int64_t)c->filter_launches; return GMS_OK;
     case GMS_QUERY_CUS: *value = c->n_cus; return GMS_OK;
+    case GMS_QUERY_PREFETCH_TYPE: *value = knobs().prefetch_type; return GMS_OK;
+    case GMS_QUERY_PREFETCH_AHEAD: *value = knobs().prefetch_ahead > 0 ? knobs().prefetch_ahead : c->n_cus; return GMS_OK;
+    case GMS_QUERY_STAGGER_TICKS: *value = c->last_stagger_ticks; return GMS_OK;
     default: return GMS_ERR_BAD_ARG;
     }
 }
