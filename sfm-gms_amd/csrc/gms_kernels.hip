@@ -2063,6 +2063,10 @@ __device__ __forceinline__ bool dense_scales_pair(const FilterParams& p, uint32_
         const uint4 z4 = make_uint4(0, 0, 0, 0);
         uint4* d4 = reinterpret_cast<uint4*>(smem);
         for (uint32_t i = tid; i < staged16; i += NT) d4[i] = z4;
+        // the sink dwords (see dense_pair_plain): the binning and marking loops below run unpredicated, a match that is not binned in
+        // the current pass works on its lane's sink instead. Bit 31 is never cleared (increments land in byte 0, keys end below it).
+        if (tid < 16) trash[tid] = 0x80000000u;
+        if (tid == 0) misc[15] = 0xFFFFFFFFu;  // "no header": what a match reads in the marking pass when the grid type leaves it out (E = 2047: equal to no E -- a never-binned match carries E = 0 --, and no rotation bits)
     }
     __syncthreads();
     if (misc[8] != 0) {  // an input outside the parity domain (workgroup-uniform)
@@ -2071,6 +2075,7 @@ __device__ __forceinline__ bool dense_scales_pair(const FilterParams& p, uint32_
     }
     const bool spilled = misc[13] != 0;  // a half cell above 255 matches: crowded from the start (see dense_pair)
     uint32_t* nl32 = nfine32;            // crowded mode: nLeft as 16-bit counters, two buffers of 400
+    const uint32_t sink_at = kDenseTrashOff + 4u * (uint32_t)(lane & 15), none_at = kDenseMiscOff + 4u * 15u;
 
     const bool thr_fast = threshold_fast_ok(p.threshold_factor);
     const uint32_t f2i = dense_factor_sq(p.threshold_factor);
@@ -2158,24 +2163,34 @@ __device__ __forceinline__ bool dense_scales_pair(const FilterParams& p, uint32_
                 // ---- assignMatchPairs
 #pragma unroll
                 for (int k0 = 0; k0 < KPT; k0 += kChunk) {
-                    uint32_t old[kChunk], at[kChunk], row[kChunk];
+                    // Whole matrix in LDS (scales 0..2): unpredicated, a match the grid type leaves out works on its lane's sink (see
+                    // dense_pair_plain). Banded (scales 3, 4): most matches are outside the band -- those are skipped, not sunk.
+                    uint32_t old[kChunk], at[kChunk], row[kChunk], ee[kChunk];
                     bool in[kChunk];
 #pragma unroll
                     for (int c = 0; c < kChunk; ++c) {
                         const uint32_t cw = code[k0 + c];
                         const uint32_t l = (aux[k0 + c] & 0x1FFu) + (cw & q_mask) - cell0;
                         in[c] = (cw & out_mask) == 0 && (!BANDED || l < n_held);
-                        row[c] = __umul24(l, stride);
-                        at[c] = row[c] + ((cw >> kDEShift) & emask);
-                        old[c] = 0;
-                        if (in[c]) old[c] = atomicAdd(lds_at(smem, at[c] & ~3u), 1u << ((at[c] << 3) & 31u));
+                        if constexpr (BANDED) {
+                            row[c] = __umul24(l, stride);
+                            ee[c] = (cw >> kDEShift) & emask;
+                            at[c] = row[c] + ee[c];
+                            old[c] = 0;
+                            if (in[c]) old[c] = ldsa_add_rtn(at[c] & ~3u, 1u << ((at[c] << 3) & 31u));
+                        } else {
+                            row[c] = in[c] ? __umul24(l, stride) : sink_at;  // (not binned under this grid type: the lane's sink, E = 0)
+                            ee[c] = in[c] ? ((cw >> kDEShift) & emask) : 0u;
+                            at[c] = row[c] + ee[c];
+                            old[c] = ldsa_add_rtn(at[c] & ~3u, 1u << ((at[c] << 3) & 31u));
+                        }
                     }
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int c = 0; c < kChunk; ++c) {
-                        const uint32_t before = (old[c] >> ((at[c] << 3) & 31u)) & 255u;
+                        const uint32_t before = __builtin_amdgcn_ubfe(old[c], at[c] << 3, 8);
                         if (CROWDED && in[c] && before == 255u) misc[12] = 1;  // the entry's byte has just wrapped
-                        if (in[c]) atomicMax(lds_at(smem, row[c]), key_tag | (before << 11) | ((code[k0 + c] >> kDEShift) & emask));
+                        if (!BANDED || in[c]) ldsa_max(row[c], key_tag | (before << 11) | ee[c]);
                     }
                 }
                 GMS_STAMP(3);  // insert
@@ -2281,12 +2296,19 @@ __device__ __forceinline__ bool dense_scales_pair(const FilterParams& p, uint32_
                     for (int k = 0; k < KPT; ++k) {
                         const uint32_t cw = code[k];
                         const uint32_t l = (aux[k] & 0x1FFu) + (cw & q_mask);
-                        const uint32_t row = __umul24(l - cell0, stride);
-                        cr[k] = 0xFFFFFFFFu;
-                        if ((cw & out_mask) == 0 && (!BANDED || l - cell0 < n_held)) {
-                            if (!BANDED || l - own0 < n_own) cr[k] = smem[row >> 2];
-                            const uint32_t at = row + ((cw >> kDEShift) & emask);
-                            reinterpret_cast<uint8_t*>(smem)[at] = 0;  // (every reader of the entry is past the barrier: see dense_pair)
+                        const bool in = (cw & out_mask) == 0 && (!BANDED || l - cell0 < n_held);
+                        if constexpr (BANDED) {
+                            const uint32_t row = __umul24(l - cell0, stride);
+                            cr[k] = 0xFFFFFFFFu;  // "no header" (reads as E = 2047)
+                            if (in) {
+                                if (l - own0 < n_own) cr[k] = ldsa_ld32(row);
+                                ldsa_st8(row + ((cw >> kDEShift) & emask), 0u);  // (every reader of the entry is past the barrier: see dense_pair)
+                            }
+                        } else {
+                            const uint32_t row = in ? __umul24(l - cell0, stride) : sink_at;
+                            const uint32_t at = row + (in ? ((cw >> kDEShift) & emask) : 0u);
+                            cr[k] = ldsa_ld32(in ? row : none_at);
+                            ldsa_st8(at, 0u);
                         }
                     }
 #pragma unroll

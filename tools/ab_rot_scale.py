@@ -15,6 +15,6 @@ for rnd in range(2):
         r = subprocess.run([sys.executable, "-c", code.format(root=ROOT, n=n, lib=ROOT + "/sfm-gms_amd/csrc/" + lib)], capture_output=True, text=True)
         try:
             d = json.loads(r.stdout.strip().splitlines()[-1])
-            print(lib, {k: (round(v["ms_per_launch"], 4), v["mismatches"]) for k, v in d.items()})
+            print(lib, {k: (round(v["pairs_per_s"]), v["mismatches"]) for k, v in d.items()})
         except Exception:
             print(lib, "failed", r.stderr[-400:])
