@@ -915,18 +915,40 @@ stream_plain_kernel(FilterParams p, uint32_t* __restrict__ codes_ws, uint16_t* _
     uint32_t* hist = smem;
     for (int j = tid; j < kFineN; j += 1024) hist[j] = 0;
     if (tid < 32) misc[tid] = 0;
+    // frame A's left codes staged behind the histogram when they fit (77 600 keypoints): a gather from L2 costs the CU a cycle per
+    // lane, one from LDS a few per wave -- and there are two gathers per match. (Frame B's right codes stay where they are: both
+    // frames of a 50k-keypoint pair do not fit.)
+    constexpr uint32_t kStageOff = 4u * kFineN;                          // bytes: behind the 1600 histogram dwords
+    const uint32_t phA = (uint32_t)(reinterpret_cast<uintptr_t>(lcode) >> 1) & 7u;   // the copy keeps the source's 16-byte phase
+    const uint32_t qA = (phA + (uint32_t)nA + 7u) >> 3;                  // uint4s
+    const bool stagedA = kStageOff + 16u * qA <= kDSNleftOff;
+    if (stagedA) {
+        const uint4* __restrict__ srcA = reinterpret_cast<const uint4*>(lcode - phA);
+        uint4* d4 = reinterpret_cast<uint4*>(smem) + kStageOff / 16u;
+        for (uint32_t j = tid; j < qA; j += 1024) d4[j] = srcA[j];
+    }
+    const uint32_t ldsA = kStageOff + 2u * phA;                          // left code of keypoint q at byte ldsA + 2 q
     __syncthreads();
+    // The first kR chunks of a thread's code words (32 matches) stay in registers for the whole kernel; only the rest is written to
+    // the scratch array and streamed back in every binning and marking pass (a 20k-match pair streams nothing, a 50k-match pair a
+    // third of what it did: at 256 pairs per launch the scratch arrays do not stay in L2 and that traffic is what the launch waits for).
+    constexpr int kR = 4;
+    uint32_t creg[kR * kC];
     {
         bool any_bad = false;
-        for (int k0 = 0; k0 < kpt; k0 += kC) {
+        auto build_chunk = [&](const int k0, uint32_t* cw_out) {
             uint2 qt[kC];
 #pragma unroll
-            for (int j = 0; j < kC; ++j) qt[j] = *reinterpret_cast<const uint2*>(&matches[min((k0 + j) * 1024 + tid, m - 1)]);
+            for (int j = 0; j < kC; ++j) qt[j] = *reinterpret_cast<const uint2*>(&matches[(uint32_t)min((k0 + j) * 1024 + tid, m - 1)]);
             uint32_t ca[kC], cb[kC];
 #pragma unroll
-            for (int j = 0; j < kC; ++j) {
-                ca[j] = lcode[min(qt[j].x, (uint32_t)(nA - 1))];
-                cb[j] = rcode[min(qt[j].y, (uint32_t)(nB - 1))];
+            for (int j = 0; j < kC; ++j) cb[j] = rcode[min(qt[j].y, (uint32_t)(nB - 1))];
+            if (stagedA) {
+#pragma unroll
+                for (int j = 0; j < kC; ++j) ca[j] = ldsa_ld16(ldsA + 2u * min(qt[j].x, (uint32_t)(nA - 1)));
+            } else {
+#pragma unroll
+                for (int j = 0; j < kC; ++j) ca[j] = lcode[min(qt[j].x, (uint32_t)(nA - 1))];
             }
 #pragma unroll
             for (int j = 0; j < kC; ++j) {
@@ -939,8 +961,25 @@ stream_plain_kernel(FilterParams p, uint32_t* __restrict__ codes_ws, uint16_t* _
                 const uint32_t qx = ca[j] & 1u, qy = (ca[j] >> 2) & 1u;
                 if (binned) atomicAdd(&hist[cell * 4u + qx + 2u * qy], 1u);
                 const uint32_t qe = (ca[j] & 21u) | ((ca[j] >> 4) & kSPEdgeX) | ((ca[j] >> 3) & kSPEdgeY);
-                const uint32_t cw = binned ? (((__umul24(cell, kDRow) + e0) << kSPAtShift) | (e0 << kSPEShift) | qe) : cw_sink;
-                if (live) codes[i] = cw;
+                cw_out[j] = binned ? (((__umul24(cell, kDRow) + e0) << kSPAtShift) | (e0 << kSPEShift) | qe) : cw_sink;
+            }
+        };
+#pragma unroll
+        for (int c = 0; c < kR; ++c) {
+            if (c * kC < kpt) build_chunk(c * kC, &creg[c * kC]);
+            else {
+#pragma unroll
+                for (int j = 0; j < kC; ++j) creg[c * kC + j] = cw_sink;
+            }
+        }
+#pragma unroll 1
+        for (int k0 = kR * kC; k0 < kpt; k0 += kC) {
+            uint32_t cw[kC];
+            build_chunk(k0, cw);
+#pragma unroll
+            for (int j = 0; j < kC; ++j) {
+                const uint32_t i = (uint32_t)((k0 + j) * 1024 + tid);
+                if (i < (uint32_t)m) codes[i] = cw[j];
             }
         }
         if (any_bad) misc[8] = 1;
@@ -990,28 +1029,47 @@ stream_plain_kernel(FilterParams p, uint32_t* __restrict__ codes_ws, uint16_t* _
         if (tid < kLeftN / 2) ldsa_st32(kDSNleftOff + 4u * (uint32_t)tid, reinterpret_cast<const uint32_t*>(nl_g + g * kLeftN)[tid]);
         __syncthreads();  // (the matrix clear / the previous grid type's undo are complete)
         // ---- assignMatchPairs
-        for (int k0 = 0; k0 < kpt; k0 += kC) {
-            uint32_t cw[kC];
+        auto bin_chunk = [&](const uint32_t* cwc) {
+            uint32_t cg[kC], old[kC], at[kC];
 #pragma unroll
             for (int j = 0; j < kC; ++j) {
-                const int i = (k0 + j) * 1024 + tid;
-                cw[j] = i < m ? codes[i] : cw_sink;
-            }
-            uint32_t old[kC], at[kC], e[kC];
-#pragma unroll
-            for (int j = 0; j < kC; ++j) {
-                const uint32_t cg = (cw[j] & x_mask) ? cw_sink : cw[j];
-                at[j] = mad24_vsv(cg & q_mask, kDRow, cg >> kSPAtShift);
-                e[j] = (cg >> kSPEShift) & 0x1FFu;
+                cg[j] = (cwc[j] & x_mask) ? cw_sink : cwc[j];
+                at[j] = mad24_vsv(cg[j] & q_mask, kDRow, cg[j] >> kSPAtShift);
                 old[j] = ldsa_add_rtn(at[j] & ~3u, 1u << ((at[j] << 3) & 31u));
             }
             __builtin_amdgcn_sched_barrier(0);  // all of the chunk's atomics are issued before any result is read
 #pragma unroll
             for (int j = 0; j < kC; ++j) {
+                const uint32_t e = (cg[j] >> kSPEShift) & 0x1FFu;
                 const uint32_t before = __builtin_amdgcn_ubfe(old[j], at[j] << 3, 8);
-                if (e[j] != 0u && before == 255u) misc[9] = 1;  // the entry's byte has just wrapped: more than 255 matches in one (left cell, right cell) pair
-                ldsa_max(at[j] - e[j], tag | (before << kKeyCountShift) | e[j]);  // highest count, then lowest right cell
+                if (e != 0u && before == 255u) misc[9] = 1;  // the entry's byte has just wrapped: more than 255 matches in one (left cell, right cell) pair
+                ldsa_max(at[j] - e, tag | (before << kKeyCountShift) | e);  // highest count, then lowest right cell
             }
+        };
+        uint32_t cwn[kC];  // the streamed part: the next chunk's code words are requested a chunk ahead (an L2 round trip per chunk otherwise)
+        if (kR * kC < kpt) {
+#pragma unroll
+            for (int j = 0; j < kC; ++j) {
+                const uint32_t i = (uint32_t)((kR * kC + j) * 1024 + tid);
+                cwn[j] = i < (uint32_t)m ? codes[i] : cw_sink;
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < kR; ++c)
+            if (c * kC < kpt) bin_chunk(&creg[c * kC]);
+#pragma unroll 1
+        for (int k0 = kR * kC; k0 < kpt; k0 += kC) {
+            uint32_t cw[kC];
+#pragma unroll
+            for (int j = 0; j < kC; ++j) cw[j] = cwn[j];
+            if (k0 + kC < kpt) {
+#pragma unroll
+                for (int j = 0; j < kC; ++j) {
+                    const uint32_t i = (uint32_t)((k0 + kC + j) * 1024 + tid);
+                    cwn[j] = i < (uint32_t)m ? codes[i] : cw_sink;
+                }
+            }
+            bin_chunk(cw);
         }
         __syncthreads();
         if (misc[9] != 0) {  // (workgroup-uniform) the general kernel's pair; nothing has been written out
@@ -1066,17 +1124,11 @@ stream_plain_kernel(FilterParams p, uint32_t* __restrict__ codes_ws, uint16_t* _
         }
         __syncthreads();
         // ---- mark inliers (cellPairs[l] == r) and take this grid type's increments back
-        for (int k0 = 0; k0 < kpt; k0 += kC) {
-            uint32_t cw[kC];
-#pragma unroll
-            for (int j = 0; j < kC; ++j) {
-                const int i = (k0 + j) * 1024 + tid;
-                cw[j] = i < m ? codes[i] : cw_sink;
-            }
+        auto mark_chunk = [&](const int k0, const uint32_t* cwc) {
             uint32_t cur = 0;
 #pragma unroll
             for (int j = 0; j < kC; ++j) {
-                const uint32_t cg = (cw[j] & x_mask) ? cw_sink : cw[j];
+                const uint32_t cg = (cwc[j] & x_mask) ? cw_sink : cwc[j];
                 const uint32_t at = mad24_vsv(cg & q_mask, kDRow, cg >> kSPAtShift), e = (cg >> kSPEShift) & 0x1FFu;
                 const uint32_t cr = ldsa_ld32(at - e);  // (a sink's own dword: never equal to its E = 0)
                 ldsa_st8(at, 0u);
@@ -1084,6 +1136,30 @@ stream_plain_kernel(FilterParams p, uint32_t* __restrict__ codes_ws, uint16_t* _
             }
             if (k0 < 32) acc[0] |= cur << (k0 & 31);
             else acc[1] |= cur << (k0 & 31);
+        };
+        if (kR * kC < kpt) {
+#pragma unroll
+            for (int j = 0; j < kC; ++j) {
+                const uint32_t i = (uint32_t)((kR * kC + j) * 1024 + tid);
+                cwn[j] = i < (uint32_t)m ? codes[i] : cw_sink;
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < kR; ++c)
+            if (c * kC < kpt) mark_chunk(c * kC, &creg[c * kC]);
+#pragma unroll 1
+        for (int k0 = kR * kC; k0 < kpt; k0 += kC) {
+            uint32_t cw[kC];
+#pragma unroll
+            for (int j = 0; j < kC; ++j) cw[j] = cwn[j];
+            if (k0 + kC < kpt) {
+#pragma unroll
+                for (int j = 0; j < kC; ++j) {
+                    const uint32_t i = (uint32_t)((k0 + kC + j) * 1024 + tid);
+                    cwn[j] = i < (uint32_t)m ? codes[i] : cw_sink;
+                }
+            }
+            mark_chunk(k0, cw);
         }
     }
     __syncthreads();
@@ -1093,6 +1169,7 @@ stream_plain_kernel(FilterParams p, uint32_t* __restrict__ codes_ws, uint16_t* _
     auto kept = [&](int k) -> bool { return ((accq >> ((k & 56) + 7 - (k & 7))) & 1ull) != 0ull; };
     uint32_t* cnt_tab = smem;  // in the matrix area (every reader of the matrix is past the barrier above)
     uint32_t* wave_tot = misc + 16;
+#pragma unroll 1
     for (int k = 0; k < kpt; ++k) {
         const unsigned long long b = __ballot(k * 1024 + tid < m && kept(k));
         if (lane == 0) cnt_tab[k * 16 + wave] = (uint32_t)__popcll(b);
@@ -1122,6 +1199,7 @@ stream_plain_kernel(FilterParams p, uint32_t* __restrict__ codes_ws, uint16_t* _
     __syncthreads();
     gms_dmatch* __restrict__ out = p.out + pr.match_off;
     uint8_t* mask_out = p.mask ? p.mask + pr.match_off : nullptr;
+#pragma unroll 1
     for (int k = 0; k < kpt; ++k) {
         const int i = k * 1024 + tid;
         const bool keep = i < m && kept(k);
