@@ -310,6 +310,17 @@ def test_band_and_tile_kernels_whole_file_again():
     assert res.returncode == 0, res.stdout[-3000:]
 
 
+def test_older_streamed_default_flags_kernel_whole_file_again():
+    """GMS_STREAM_PLAIN=0 (read once per process): default-flags pairs of 16 385 .. 65 536 matches run on stream_dense_kernel<false>
+    (round 3's first streamed kernel) instead of stream_plain_kernel. Same bytes for everything in this file."""
+    import os
+    import subprocess
+    import sys
+    res = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-x", "-q", "-k", "not again"],
+                         capture_output=True, text=True, timeout=1500, env=dict(os.environ, GMS_STREAM_PLAIN="0"))
+    assert res.returncode == 0, res.stdout[-3000:]
+
+
 def test_streamed_kernels_when_an_entry_leaves_its_byte(ctx, oracle, synth):
     """40 000 matches, a third of them from one left cell to one right cell: that (left cell, right cell) entry passes 255 under every
     grid type, the streamed byte-matrix kernels flag the pair and the HBM-slab kernel produces it -- same bytes; in a batch with a pair

@@ -237,6 +237,56 @@ def test_dealt_mapping_whole_file_again():
     assert res.returncode == 0, res.stdout[-3000:]
 
 
+@pytest.mark.parametrize("setting", ["-1", "0", "2,7"])
+def test_touch_ahead_setting_whole_file_again(setting):
+    """GMS_PREFETCH (read once per process): the byte-matrix kernel touches the match records of a later pair ahead of time -- never
+    (-1), before the first grid type, or before the third one for the pair seven places on instead of one CU count on. Speed only:
+    everything in this file, the golden fixtures and the API tests (batches of more pairs than CUs, ragged sizes, slices) come out
+    the same."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = [os.path.join(root, "tests", f) for f in ("test_gpu_dense_path.py", "test_golden.py", "test_gpu_api.py")]
+    res = subprocess.run([sys.executable, "-m", "pytest", *files, "-m", "gpu", "-x", "-q", "-k", "not again"], capture_output=True,
+                         text=True, timeout=1500, env=dict(os.environ, GMS_PREFETCH=setting))
+    assert res.returncode == 0, res.stdout[-3000:]
+
+
+def test_touch_ahead_reaches_over_ragged_pairs(ctx, pkg, oracle, synth):
+    """600 pairs (more than twice the CU count) whose sizes run from 1 match to the kernel's 10 240 in no order, some empty, the last
+    one ending exactly at the end of the match array: every workgroup touches the array of the pair 256 places on (another size,
+    another offset, other frames) -- the filtered bytes, results and masks are the oracle's for every pair."""
+    import importlib
+    batch = importlib.import_module("sfm-gms_amd.batch")
+    rng = np.random.default_rng(4242)
+    size, n_frames, n_kp = (1280, 720), 12, 10240
+    frames = synth.make_sequence(4242, n_frames, size=size, n_kp=n_kp)
+    table = batch.FrameTable(ctx, frames, [size] * n_frames)
+    sizes = [int(x) for x in rng.integers(1, 10241, 600)]
+    for i in (0, 5, 299, 300, 557):
+        sizes[i] = 0
+    sizes[1], sizes[2], sizes[-1] = 10240, 1, 10240
+    pairs = np.zeros(len(sizes), dtype=pkg.PAIR_DTYPE)
+    chunks, off = [], 0
+    for i, m in enumerate(sizes):
+        a, b = int(rng.integers(0, n_frames)), int(rng.integers(0, n_frames))
+        pairs[i] = (a, b, m, 0, off)
+        if m:
+            chunks.append(synth.sequence_matches(90000 + i, n_kp, n_kp, 0.5)[rng.permutation(n_kp)[:m]])
+        off += m
+    matches = np.concatenate(chunks)
+    out, res, mask = batch.filter_pairs(ctx, table, pairs, matches)
+    wh = np.array([size] * n_frames, dtype=np.int32).reshape(-1)
+    failed, wout, wres, wmask = oracle.batch(np.concatenate(frames), table.frame_off_host, wh, pairs, matches, False, False, 6.0, 8)
+    assert failed == 0
+    assert res.tobytes() == wres.tobytes()
+    assert mask.tobytes() == wmask.tobytes()
+    for i in range(len(pairs)):
+        o, k = int(pairs["match_off"][i]), int(wres["n_inliers"][i])
+        assert out[o:o + k].tobytes() == wout[o:o + k].tobytes(), i
+
+
 def test_probe_switches_to_dealing_on_ordered_input(pkg, oracle, synth):
     """Cell-sorted keypoints: the first launch of a fresh context runs in list order and is followed by the probe; later launches deal.
     Same bytes either way."""
