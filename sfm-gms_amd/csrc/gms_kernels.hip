@@ -5,10 +5,12 @@
 // per hypothesis. One 1024-thread workgroup owns one image pair and keeps the pair's whole state in
 // registers and in the CU's 160 KB LDS, in one of two forms:
 //
-//   filter_kernel_dense / dense_pair()   no scale hypotheses (right grid 20 x 20) and no left cell above 255
+//   filter_kernel_dense / dense_pair_plain(), dense_pair()   no scale hypotheses (right grid 20 x 20) and no left cell above 255
 //               matches: the 400 x 400 matrix itself, one BYTE per entry, fills the LDS; binning is one
 //               returning atomic per match, verification reads neighbour counts directly, the DMatch records
-//               stay in registers from load to copy-out. Described in front of dense_pair() below. Pairs that
+//               stay in registers from load to copy-out. dense_pair_plain() is the default-flags body (the headline: written
+//               around its instruction count, touches the next workgroup's records ahead, non-temporal record traffic),
+//               dense_pair() the one with rotation hypotheses; both are described in front of them below. Pairs that
 //               do not qualify are handed to hash_pair() by the same workgroup before anything is written.
 //   filter_kernel_dense_scales / dense_scales_pair()   scale hypotheses on the same byte matrix with a runtime row stride:
 //               scales 0..3 evaluated (scale 1 first), every later one -- and scale 4 -- bounded first by a probe that bins
