@@ -920,6 +920,8 @@ __device__ __forceinline__ uint32_t dense_nleft_cm(const uint8_t* nfine8, int x,
 template <int KPT, bool ROT, int NT, bool DEALT>
 __device__ __forceinline__ bool dense_pair(const FilterParams& p, uint32_t* smem, const int pair_idx, const int tid)
 {
+    // (since round 3 only instantiated with rotation hypotheses: the default flags run dense_pair_plain below; the ROT = false
+    //  branches are kept because they are the description the comments in front of this function follow)
     constexpr int kMcap = KPT * NT;
     constexpr int kNRot = ROT ? 8 : 1;
     constexpr int kChunk = (KPT % 5 == 0) ? 5 : 4;
