@@ -1610,7 +1610,10 @@ __device__ __forceinline__ bool dense_pair_plain(const FilterParams& p, uint32_t
         const int nxt = pair_idx + p.prefetch_ahead;
         if (p.prefetch_ahead > 0 && nxt < p.n_pairs) {
             const gms_pair pn = uniform(p.pairs[nxt]);
-            if (pn.m > 0 && pn.m <= kMcap) {
+            // (only what that pair's own workgroup will read as well: a pair it would refuse before reading -- frames out of range,
+            //  a negative offset -- is not touched either)
+            if (pn.m > 0 && pn.m <= kMcap && pn.match_off >= 0 && pn.frame_a >= 0 && pn.frame_a < p.n_frames && pn.frame_b >= 0 &&
+                pn.frame_b < p.n_frames) {
                 pf_base = reinterpret_cast<const uint32_t*>(p.matches + pn.match_off);
                 pf_lines = min(((uint32_t)pn.m * 16u + 127u) >> 7, 2u * NT);   // (the array's first line may start a little earlier: close enough)
             }
