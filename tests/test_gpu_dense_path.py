@@ -133,6 +133,21 @@ def test_frame_too_large_to_stage(ctx, oracle):
     assert _check(ctx, oracle, c, False) > 1000
 
 
+def test_frames_beyond_the_staging_area(ctx, oracle):
+    """With 16-bit code words the matrix area stages 80 800 keypoints of the two frames together; a frame B of 90 000 keypoints
+    (6 000 matches: still the register kernel's pair) makes both gathers read global memory -- default flags (dense_pair_plain) and
+    with rotation hypotheses (dense_pair)."""
+    rng = np.random.default_rng(19)
+    n2, m = 90000, 6000
+    xy2 = np.stack([rng.uniform(0, W - 1, n2), rng.uniform(0, H - 1, n2)], axis=1).astype(np.float32)
+    train = rng.permutation(n2)[:m]
+    xy1 = np.clip(xy2[train] + rng.uniform(-2, 2, (m, 2)), 0, [W - 0.01, H - 0.01]).astype(np.float32)
+    xy1[m // 2:] = np.stack([rng.uniform(0, W - 1, m - m // 2), rng.uniform(0, H - 1, m - m // 2)], axis=1)
+    c = cases._pair(xy1, xy2, np.arange(m), train, (W, H), (W, H))
+    assert _check(ctx, oracle, c, False) > 1000
+    assert _check(ctx, oracle, c, True) > 1000
+
+
 def test_eligible_and_ineligible_pairs_share_a_launch(ctx, oracle):
     """A batch whose pairs alternate between the byte-matrix path and the general path (a 300-match cell)."""
     batch = importlib.import_module("sfm-gms_amd.batch")
