@@ -310,6 +310,21 @@ def test_band_and_tile_kernels_whole_file_again():
     assert res.returncode == 0, res.stdout[-3000:]
 
 
+def test_streamed_default_flags_frame_a_beyond_its_staging_area(ctx, oracle):
+    """stream_plain_kernel stages frame A's left codes in LDS up to 77 600 keypoints; a frame A of 90 000 keypoints with 20 000
+    matches takes the left codes from global memory instead (and 20 000 matches all stay in the kernel's registers: nothing is streamed);
+    the same frames with 60 000 matches stream the tail of every thread's code words as well."""
+    rng = np.random.default_rng(23)
+    size, n1 = (3840, 2160), 90000
+    xy1 = np.stack([rng.uniform(0, size[0] - 1, n1), rng.uniform(0, size[1] - 1, n1)], axis=1).astype(np.float32)
+    xy2 = np.clip(xy1 + rng.normal(0, 2.0, xy1.shape) + [9.0, -6.0], 0, [size[0] - 0.01, size[1] - 0.01]).astype(np.float32)
+    for m in (20000, 60000):
+        q = rng.permutation(n1)[:m]
+        t = np.where(rng.uniform(size=m) < 0.5, q, rng.integers(0, n1, m))
+        c = cases._pair(xy1, xy2, q, t, size, size)
+        assert _check(ctx, oracle, c) > m // 10
+
+
 def test_older_streamed_default_flags_kernel_whole_file_again():
     """GMS_STREAM_PLAIN=0 (read once per process): default-flags pairs of 16 385 .. 65 536 matches run on stream_dense_kernel<false>
     (round 3's first streamed kernel) instead of stream_plain_kernel. Same bytes for everything in this file."""
