@@ -22,7 +22,7 @@ def _check(ctx, oracle, c, rot=False, scale=False, thr=6.0):
     return len(got)
 
 
-@pytest.mark.parametrize("n", [16385, 16400, 32768, 32769, 50000, 100000, 262144])
+@pytest.mark.parametrize("n", [16385, 16400, 32768, 32769, 50000, 65536, 65537, 100000, 262144])
 def test_sizes_across_compaction_tiles(ctx, oracle, n):
     kept = _check(ctx, oracle, cases.random_pair(80 + n % 11, n=n, size1=(3840, 2160), inlier_frac=0.5))
     assert kept > n // 10
