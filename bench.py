@@ -84,15 +84,21 @@ class Workload:
         self.table = batch.FrameTable(ctx, self.frames, [SIZE] * args.frames, device=dev)
         # the per-frame work the filter no longer does per pair (normalizePoints + the keypoints' cell codes): once per sequence,
         # amortised over the 999 pairs every frame takes part in; timed here so that the line can say what it costs
+        # (on a stream of its own: the handle of torch's current stream is 0, which gms_ctx_set_stream reads as "the context's own
+        #  stream" -- events recorded on stream 0 would not bracket the kernel)
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        st = torch.cuda.current_stream(dev)
+        st = torch.cuda.Stream(device=dev)
+        assert st.cuda_stream != 0
         ctx.set_stream(st.cuda_stream)
         t = self.table
+        torch.cuda.synchronize()
+        ctx.normalize_device(t.d_kp.data_ptr(), t.d_frame_off.data_ptr(), t.d_wh.data_ptr(), t.n_frames, t.total, t.d_pts.data_ptr())  # warm-up
         ev0.record(st)
         ctx.normalize_device(t.d_kp.data_ptr(), t.d_frame_off.data_ptr(), t.d_wh.data_ptr(), t.n_frames, t.total, t.d_pts.data_ptr())
         ev1.record(st)
         torch.cuda.synchronize()
         self.frame_table_build_ms = float(ev0.elapsed_time(ev1))
+        self.frame_table_bytes = int(ctx.frame_table_bytes(t.total))
         n_chunks = min(args.warmup + args.steps, max(1, args.max_resident))
         self.plan = self.dist.RankPlan(args.frames, self.n_kp, args.pairs, n_chunks, rank, world)
         self.n_pairs = self.plan.chunk
@@ -654,7 +660,7 @@ def main():
             "config": {"workload": "config3: one 1080p sequence, all N(N-1)/2 pairs in lexicographic order, 10k keypoints/frame, "
                                    "M=10k putative matches/pair, matchGMS(withRotation=false, withScale=false, thresholdFactor=6.0)",
                        "image_size": list(SIZE), "frames": args.frames, "features": n_kp,
-                       "frame_table_bytes": 8 * n_kp * args.frames, "total_pairs": wl.plan.total_pairs,
+                       "frame_table_bytes": wl.frame_table_bytes, "total_pairs": wl.plan.total_pairs,
                        "pairs_per_step_per_gpu": wl.n_pairs, "resident_chunks_per_gpu": n_res,
                        "inlier_frac": args.inlier_frac, "mean_kept_per_pair": kept_per_launch / wl.n_pairs,
                        "sharding": f"contiguous blocks of the pair list x{world}, no collective; rendezvous over gloo"},
@@ -673,7 +679,13 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):  # measured in a separate rocprofv3 --pmc run (tools/pmc_collect.sh), not in this one
             try:
-                line["roofline"]["traffic_from_profiles"] = json.load(open(tpath))
+                tj = json.load(open(tpath))
+                line["roofline"]["traffic_from_profiles"] = tj
+                # the counter figure belongs to a named kernel at a named batch size: it is this launch's traffic only when both agree
+                if tj.get("kernel") == line["roofline"]["kernel"] and tj.get("pairs_per_launch") == wl.n_pairs:
+                    line["roofline"]["traffic"] = float(tj["hbm_bytes_per_launch"])
+                    line["roofline"]["traffic_source"] = ("profiles/traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over this command "
+                                                          "(tools/pmc_collect.sh), FETCH_SIZE x2 per MI355X_MICROARCH.md, bytes per launch of this kernel")
             except Exception:
                 pass
         if not args.no_cpu and world == 1:

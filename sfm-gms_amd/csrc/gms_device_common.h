@@ -70,6 +70,16 @@ __device__ __forceinline__ uint32_t ldsa_ld16(uint32_t a) { return *reinterpret_
 __device__ __forceinline__ uint32_t ldsa_ld8(uint32_t a) { return *reinterpret_cast<lds_u8_t*>((uintptr_t)a); }
 __device__ __forceinline__ void ldsa_st32(uint32_t a, uint32_t v) { *reinterpret_cast<lds_u32_t*>((uintptr_t)a) = v; }
 __device__ __forceinline__ void ldsa_st8(uint32_t a, uint32_t v) { *reinterpret_cast<lds_u8_t*>((uintptr_t)a) = (uint8_t)v; }
+typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+using lds_u32x2_t = __attribute__((address_space(3))) u32x2_t;
+__device__ __forceinline__ void ldsa_st64(uint32_t a, uint32_t lo, uint32_t hi)
+{
+    u32x2_t v;
+    v.x = lo;
+    v.y = hi;
+    *reinterpret_cast<lds_u32x2_t*>((uintptr_t)a) = v;
+}
+__device__ __forceinline__ u32x2_t ldsa_ld64(uint32_t a) { return *reinterpret_cast<lds_u32x2_t*>((uintptr_t)a); }
 
 // a * b + c on the 24-bit multiplier, b in a scalar register (the compiler turns the builtin multiply + add into the quarter-rate
 // v_mad_u64_u32 when it cannot see that the factors are short)

@@ -19,16 +19,21 @@ import bench  # noqa: E402
 PHASES = ["bin_barrier", "region_tables", "clear", "insert_first", "bin_qt_loads", "verify", "mark", "count_select", "out_scan", "copy_out", "insert_leftover", "insert_barrier", "bin_gathers", "bin_compute", "x14", "x15"]
 
 
+BY_SCALE = ["eval_s0", "eval_s1", "eval_s2", "eval_s3", "eval_s4", "probe_s0", "probe_s1", "probe_s2", "probe_s3", "probe_s4", "load", "record", "sort", "x13", "x14", "x15"]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--pairs", type=int, default=1024)
     ap.add_argument("--rot", type=int, default=0)
     ap.add_argument("--scale", type=int, default=0)
     ap.add_argument("--features", type=int, default=10000)
+    ap.add_argument("--lib", default="libgms_hip_diag.so", help="diagnostic library under sfm-gms_amd/csrc (libgms_hip_diag_byscale.so: built with -DGMS_STAMP_BY_SCALE)")
+    ap.add_argument("--by-scale", action="store_true", help="label the sums of the scale-hypothesis kernel as a -DGMS_STAMP_BY_SCALE build writes them")
     ap.add_argument("--starts", default="", help="save per-pair (start, records landed) wall-clock stamps to this .npy")
     a = ap.parse_args()
     capi = importlib.import_module("sfm-gms_amd.capi")
-    diag_path = os.path.join(ROOT, "sfm-gms_amd", "csrc", "libgms_hip_diag.so")
+    diag_path = os.path.join(ROOT, "sfm-gms_amd", "csrc", a.lib)
     capi.library_path = lambda: diag_path
     pkg = importlib.import_module("sfm-gms_amd")
     lib = pkg.load_library()
@@ -56,7 +61,8 @@ def main():
         d[:, 14:16] = 0
         mean = d.mean(axis=0)
         tot = mean.sum()
-        out[name] = {"total_cycles": tot, "phases": {n: {"cycles": float(c), "share": float(c / tot)} for n, c in zip(PHASES, mean) if c > 0}}
+        names = BY_SCALE if (a.by_scale and name == "kernel_1") else PHASES
+        out[name] = {"total_cycles": tot, "phases": {n: {"cycles": float(c), "share": float(c / tot)} for n, c in zip(names, mean) if c > 0}}
     print(json.dumps(out, indent=1))
 
 
