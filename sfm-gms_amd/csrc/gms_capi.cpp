@@ -52,7 +52,6 @@ namespace {
 //   GMS_DENSE=0          keep every pair on the hashed path
 //   GMS_BAND=0           keep large pairs on the HBM-slab kernel alone
 //   GMS_STREAM=0         pairs of 16 385 .. 65 536 matches: the 16-bit band / tile kernels instead of the streamed byte-matrix kernels
-//   GMS_SCALES_SORTED=0  scale hypotheses up to 16 384 matches: round 3's kernel pair (scales 0..3 on the byte matrix in list order, scale 4 hashed)
 //   GMS_STAGGER_US=n     spread of the first dispatch round's start times at 10k matches per pair (0 = off)
 //   GMS_BAND_WS_BYTES=n  budget of the large-pair workspace (default 4 GiB); a batch is filtered in slices that fit it
 //   GMS_DEAL=0|1         never / always deal the matches to the lanes of the byte-matrix kernel (default: what the probe saw)
@@ -61,7 +60,7 @@ namespace {
 //   GMS_PREFETCH=t[,a]   byte-matrix kernel: before grid type t (0..3, default 3; -1 = never) a workgroup touches the match records of
 //                        the pair a places ahead (default: the number of CUs = the pair its CU's next workgroup takes)
 struct Knobs {
-    bool dense_on = true, band_on = true, stream_on = true, scales_sorted = true;
+    bool dense_on = true, band_on = true, stream_on = true;
     int stagger_us = -1, deal = -1, scale_probe = -1, check_pairs = -1;
     int prefetch_type = 3, prefetch_ahead = 0;
     size_t band_ws_budget = (size_t)4 << 30;
@@ -73,7 +72,6 @@ const Knobs& knobs()
         if (const char* e = std::getenv("GMS_DENSE")) v.dense_on = std::atoi(e) != 0;
         if (const char* e = std::getenv("GMS_BAND")) v.band_on = std::atoi(e) != 0;
         if (const char* e = std::getenv("GMS_STREAM")) v.stream_on = std::atoi(e) != 0;
-        if (const char* e = std::getenv("GMS_SCALES_SORTED")) v.scales_sorted = std::atoi(e) != 0;
         if (const char* e = std::getenv("GMS_STAGGER_US")) v.stagger_us = std::atoi(e);
         if (const char* e = std::getenv("GMS_DEAL")) v.deal = std::atoi(e) != 0 ? 1 : 0;
         if (const char* e = std::getenv("GMS_SCALE_PROBE")) v.scale_probe = std::atoi(e) != 0 ? 1 : 0;
@@ -208,7 +206,7 @@ int plan_workspace(const gms_ctx* c, int n_pairs, int max_m, bool rot, bool scal
     *w = WsNeed();
     w->kpt = gms::filter_pick_kpt(max_m);  // 0: too large for the register + LDS kernel
     if (w->kpt) {
-        if (scale && knobs().dense_on) w->partial = (size_t)n_pairs * gms::partial_stride_dw(w->kpt) * 4;
+        if (scale && knobs().dense_on) w->partial = (size_t)n_pairs * gms::kPartialStrideDw * 4;
         return GMS_OK;
     }
     if (max_m > gms::kBigMaxMatches) return GMS_ERR_CAPACITY;
@@ -357,8 +355,6 @@ int filter_launch(gms_ctx* c, hipStream_t st, const float* d_pts, const int64_t*
     if (kpt && with_scale && knobs().dense_on) {
         // scale hypotheses: scales 0..3 on the byte matrix, the last on the hashed path (two launches, one record per pair)
         p.partial = (uint32_t*)c->partial_ws.p;
-        p.partial_stride = gms::partial_stride_dw(kpt);
-        p.sorted_scales = knobs().scales_sorted ? 1 : 0;
         GMS_HIP(gms::launch_filter_scales(p, kpt, n_pairs, st));
         if (p.probe_stats != nullptr) {
             void* dflag = nullptr;

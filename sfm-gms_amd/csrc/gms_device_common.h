@@ -70,16 +70,6 @@ __device__ __forceinline__ uint32_t ldsa_ld16(uint32_t a) { return *reinterpret_
 __device__ __forceinline__ uint32_t ldsa_ld8(uint32_t a) { return *reinterpret_cast<lds_u8_t*>((uintptr_t)a); }
 __device__ __forceinline__ void ldsa_st32(uint32_t a, uint32_t v) { *reinterpret_cast<lds_u32_t*>((uintptr_t)a) = v; }
 __device__ __forceinline__ void ldsa_st8(uint32_t a, uint32_t v) { *reinterpret_cast<lds_u8_t*>((uintptr_t)a) = (uint8_t)v; }
-typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
-using lds_u32x2_t = __attribute__((address_space(3))) u32x2_t;
-__device__ __forceinline__ void ldsa_st64(uint32_t a, uint32_t lo, uint32_t hi)
-{
-    u32x2_t v;
-    v.x = lo;
-    v.y = hi;
-    *reinterpret_cast<lds_u32x2_t*>((uintptr_t)a) = v;
-}
-__device__ __forceinline__ u32x2_t ldsa_ld64(uint32_t a) { return *reinterpret_cast<lds_u32x2_t*>((uintptr_t)a); }
 
 // a * b + c on the 24-bit multiplier, b in a scalar register (the compiler turns the builtin multiply + add into the quarter-rate
 // v_mad_u64_u32 when it cannot see that the factors are short)
@@ -177,6 +167,18 @@ __device__ __forceinline__ gms_pair uniform(const gms_pair& pr)
 __device__ __forceinline__ uint32_t dpp_xor1(uint32_t x)
 {
     return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1, 0xF, 0xF, false);
+}
+
+// sum of v over the wave's 64 lanes, in a scalar register: inclusive row scans on the DPP path (row_shr 1, 2, 4, 8 with zeros
+// shifted in: lane 15 of every row of sixteen ends with the row's sum), then the four row sums by v_readlane
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v)
+{
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, true);
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 15) + (uint32_t)__builtin_amdgcn_readlane((int)v, 31) +
+           (uint32_t)__builtin_amdgcn_readlane((int)v, 47) + (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
 
 }  // namespace gms

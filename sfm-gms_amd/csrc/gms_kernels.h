@@ -16,8 +16,6 @@ constexpr size_t kLdsBytes = 160 * 1024;               // gfx950 LDS per CU (and
 // inlier bit per match of the best hypothesis so far (16 x 1024 matches at most)
 constexpr uint32_t kPartialHeaderDw = 4;
 constexpr uint32_t kPartialStrideDw = kPartialHeaderDw + 16 * 1024 / 32;
-// the sorted byte-matrix kernel parks, behind the record, where every match went in its row-sorted order: 16 bits per match
-inline uint32_t partial_stride_dw(int kpt) { return kPartialStrideDw + (uint32_t)kpt * 1024u / 2u; }
 
 // The frame table (gms_frame_table_bytes) starts with a 16-byte header -- magic, then the number of keypoints it was built
 // for -- so that the kernels find the code arrays behind the points by themselves, whatever n_frames / frame_off a filter call
@@ -40,9 +38,7 @@ struct FilterParams {
     uint32_t table_slots;       // multiple of 4: data + header buckets of all 400 regions
     int region_shift;           // region slots per match = 1 + 2^-shift
     int with_rotation, with_scale;
-    uint32_t* partial;          // scale hypotheses: per-pair records of the byte-matrix kernel, or null
-    uint32_t partial_stride;    // dwords per record (partial_stride_dw)
-    int sorted_scales;          // scale hypotheses: the row-sorted byte-matrix kernel (all five scales) instead of round 3's (scales 0..3 + hashed scale 4)
+    uint32_t* partial;          // scale hypotheses: per-pair records of the byte-matrix kernel (scales 0..3), or null
     const uint32_t* pair_flags; // large-pair kernel only: when set, it filters just the pairs whose flag word has bit 1 set
     int dealt;                  // byte-matrix kernel: deal the matches to the lanes (inputs in spatial order; see dense_pair)
     int probe_scales;           // scale hypotheses: bit s set = bound scale s's inlier count first and skip the scale when it cannot win

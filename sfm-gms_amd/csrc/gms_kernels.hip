@@ -305,7 +305,7 @@ __device__ __forceinline__ void hash_pair(const FilterParams& p, uint32_t* smem,
     if (tid >= 128 && tid < 132) trash[tid] = kEmpty;
     // with scale hypotheses the byte-matrix kernel may have evaluated scales 0..2 already (see dense_scales_pair): its
     // record holds the best hypothesis so far, and this kernel continues with scale 3
-    const uint32_t* __restrict__ part = p.partial ? p.partial + (size_t)pair_idx * p.partial_stride : nullptr;
+    const uint32_t* __restrict__ part = p.partial ? p.partial + (size_t)pair_idx * kPartialStrideDw : nullptr;
     const uint32_t part0 = part != nullptr ? part[0] : 0u;       // workgroup-uniform: 0, or what the first kernel decided:
     const int scales_done = (int)(part0 & 15u);                  //   scales 0..3 (4) or all five (5: its probe bounded scale 4 out)
     const bool probed4 = (part0 >> 4) != 0;                      //   "scale 4 was probed and cannot be bounded out"
@@ -2368,20 +2368,30 @@ __device__ __forceinline__ bool dense_scales_pair(const FilterParams& p, uint32_
             return can_win ? 0 : 3;
         }
         // ---- run() return value per rotation of this scale, getInlierMask's strict '>'
-        {
-            uint32_t cnt[kNRot];
+        if constexpr (ROT) {
+            // a thread's eight counts (at most KPT each) as byte fields of two registers: the four low rotation bits of a match times
+            // 0x204081 put bit i at position 8 i (v_mul_u32_u24 + v_and instead of eight ballots per match); widened to 16-bit fields
+            // for the wave's sum (row scans on the DPP path + four v_readlane), one LDS atomic per register and wave
+            uint32_t a0 = 0, a1 = 0;
 #pragma unroll
-            for (int r = 0; r < kNRot; ++r) cnt[r] = 0;
-#pragma unroll
-            for (int k = 0; k < KPT; ++k)
-#pragma unroll
-                for (int r = 0; r < kNRot; ++r)
-                    cnt[r] += (uint32_t)__popcll(__ballot((code[k] >> (kSAccShift + r)) & 1u));
-            if (lane == 0) {
-#pragma unroll
-                for (int r = 0; r < kNRot; ++r)
-                    if (cnt[r]) atomicAdd(&misc[r], cnt[r]);
+            for (int k = 0; k < KPT; ++k) {
+                const uint32_t b = code[k] >> kSAccShift;
+                a0 += __umul24(b & 15u, 0x204081u) & 0x01010101u;
+                a1 += __umul24((b >> 4) & 15u, 0x204081u) & 0x01010101u;
             }
+            const uint32_t w0 = wave_sum(a0 & 0x00FF00FFu), w1 = wave_sum((a0 >> 8) & 0x00FF00FFu);    // rotations (0, 2), (1, 3)
+            const uint32_t w2 = wave_sum(a1 & 0x00FF00FFu), w3 = wave_sum((a1 >> 8) & 0x00FF00FFu);    // rotations (4, 6), (5, 7)
+            if (lane == 0) {
+                if (w0) atomicAdd(&misc[0], w0);
+                if (w1) atomicAdd(&misc[1], w1);
+                if (w2) atomicAdd(&misc[2], w2);
+                if (w3) atomicAdd(&misc[3], w3);
+            }
+        } else {
+            uint32_t c0 = 0;
+#pragma unroll
+            for (int k = 0; k < KPT; ++k) c0 += (uint32_t)__popcll(__ballot((code[k] >> kSAccShift) & 1u));
+            if (lane == 0 && c0) atomicAdd(&misc[0], c0);
         }
         __syncthreads();  // counts complete; headers zeroed
         // getInlierMask walks scale-outer, rotation-inner and keeps on strict '>': the first hypothesis with the largest count wins.
@@ -2390,7 +2400,7 @@ __device__ __forceinline__ bool dense_scales_pair(const FilterParams& p, uint32_
         int winner = -1;
 #pragma unroll
         for (int r = 0; r < kNRot; ++r) {
-            const uint32_t c = misc[r];
+            const uint32_t c = ROT ? (misc[(r >> 2) * 2 + (r & 1)] >> ((r & 2) << 3)) & 0xFFFFu : misc[0];
             if (c > best_count || (c == best_count && c != 0 && s < best_scale)) {
                 best_count = c;
                 best_scale = s;
@@ -2494,621 +2504,8 @@ filter_kernel_dense_scales(FilterParams p)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     first_round_stagger(p);
-    uint32_t* part = p.partial + (size_t)blockIdx.x * p.partial_stride;
+    uint32_t* part = p.partial + (size_t)blockIdx.x * kPartialStrideDw;
     if (!dense_scales_pair<KPT, ROT, NT>(p, smem, (int)blockIdx.x, (int)threadIdx.x, part)) {
-        if (threadIdx.x == 0) part[0] = 0u;  // the hashed kernel evaluates all five scales
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// Scale hypotheses, round 4: sorted_scales_pair() -- all five scales on the byte matrix, the matches in ROW-SORTED order.
-//
-// dense_scales_pair() above keeps a pair's matches in list order, so a banded pass (scale 3: three bands of left rows; a probe of
-// scale 4: four) walks every register of every thread although a half or a quarter of the matches take part, and scale 4 itself
-// (1604-byte rows: seven bands of three rows) was left to the hashed kernel at three times the cost of a byte-matrix scale.
-// Here the matches are counting-sorted by half-cell of their left point ONCE, at load: the half-cell histogram is built with
-// returning atomics anyway, so the returned count is the match's rank inside its half cell, a prefix scan over the 1600 half
-// cells (row-major) gives every half cell its start, and (code word, scale word) move through the still empty matrix area to the
-// thread that owns their sorted position. A band of left rows under either grid-type shift is then ONE contiguous range of
-// positions (half rows [2 lo - gy, 2 hi - gy)): a banded pass costs what its band holds, and scale 4 runs here as seven bands.
-// Position p lives in register slot p / 1024 of thread T^-1(p % 1024) with T(tid) = 256 (wave / 4) + 4 lane + wave % 4: a wave
-// instruction holds 64 positions spread over 256 consecutive ones (a half row: ~40 half cells), so its lanes hit different
-// matrix entries even on clustered input (the dealt mapping of dense_pair(), built in), and a band's range leaves whole waves idle
-// (they skip on an empty exec mask). The order of equal keys is whatever the atomics made it: no result depends on it.
-// Where a match came from is parked in the pair's workspace record (16 bits per match, written and read coalesced); at the end
-// the winner's inlier bits go through an LDS byte array indexed by position back to list order, and the record that
-// filter_kernel picks up says "all five scales decided": it only copies out.
-// A pair with a half cell above 255 matches (its rank byte wrapped) or outside the parity domain is left to the hashed kernel.
-// ------------------------------------------------------------------------------------------------
-constexpr uint32_t kSortStartOff = kDenseBytes - 3216u;  // [1608] u16: first sorted position of every half cell (row-major), in the tail of the matrix area
-static_assert(kSortStartOff % 16 == 0 && 16u * 1024u * 8u <= kSortStartOff, "the sort's exchange buffer (8 bytes per match) ends in front of the start table");
-
-template <int KPT, bool ROT, int NT>
-__device__ __forceinline__ bool sorted_scales_pair(const FilterParams& p, uint32_t* smem, const int pair_idx, const int tid,
-                                                   uint32_t* __restrict__ part)
-{
-    static_assert(NT == 1024, "the position mapping below is written for sixteen waves");
-    constexpr int kMcap = KPT * NT;
-    constexpr int kNRot = ROT ? 8 : 1;
-    constexpr int kChunk = (KPT % 5 == 0) ? 5 : 4;
-    static_assert(KPT % kChunk == 0, "KPT must be a multiple of the chunk");
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-#ifndef GMS_SORT_MAP
-#define GMS_SORT_MAP 0
-#endif
-#if GMS_SORT_MAP == 0
-    const uint32_t tpos = (uint32_t)(((wave >> 2) << 8) + (lane << 2) + (wave & 3));  // T(tid): slot k of this thread holds sorted position k * NT + tpos
-#elif GMS_SORT_MAP == 1
-    const uint32_t tpos = (uint32_t)((lane << 4) + wave);
-#else
-    const uint32_t tpos = (uint32_t)tid;
-#endif
-
-    const gms_pair pr = uniform(p.pairs[pair_idx]);
-    const int m = pr.m;
-    if (!p.with_scale || m <= 0 || m > kMcap || pr.frame_a < 0 || pr.frame_a >= p.n_frames || pr.frame_b < 0 ||
-        pr.frame_b >= p.n_frames)
-        return false;
-    if (p.right_w[0] != 20 || p.right_h[0] != 20 || p.right_w[1] != 10 || p.right_h[1] != 10 || p.right_w[2] != 14 ||
-        p.right_h[2] != 14 || p.right_w[3] != 28 || p.right_h[3] != 28 || p.right_w[4] != 40 || p.right_h[4] != 40)
-        return false;
-    constexpr uint32_t kSEMask = 0x7FFu;   // E(r) = nr + 3 - r needs 11 bits at 40 x 40 right cells (bits 8..18 of the code word)
-    constexpr int kSAccShift = 19;         // rotation bits 19..26
-    constexpr int kSProbeBit = 27;         // PROBE: "sits in its row's arg-max entry under some grid type"
-    const int64_t offA = p.frame_off[pr.frame_a], offB = p.frame_off[pr.frame_b];
-    const int nA = (int)(p.frame_off[pr.frame_a + 1] - offA), nB = (int)(p.frame_off[pr.frame_b + 1] - offB);
-    if (nA <= 0 || nB <= 0) return false;
-    const gms_dmatch* __restrict__ matches = p.matches + pr.match_off;
-    const int64_t total_kp = table_total_kp(p);
-    if (total_kp < 0 || offA + nA > total_kp || offB + nB > total_kp) return false;  // (workgroup-uniform) no header, or frames beyond the table
-    const uint16_t* __restrict__ lcodeA = reinterpret_cast<const uint16_t*>(p.pts + total_kp) + offA;
-    const uint32_t* __restrict__ scodeB = reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint16_t*>(p.pts + total_kp) + 2 * total_kp) + offB;
-    uint16_t* __restrict__ park = reinterpret_cast<uint16_t*>(part + kPartialStrideDw);  // [kMcap]: sorted position of match i (0xFFFF: binned nowhere)
-
-    const uint8_t* dense8 = reinterpret_cast<const uint8_t*>(smem);
-    uint32_t* nfine32 = smem + kDenseFineOff / 4;   // half-cell histogram: one dword per cell of grid type 1, a byte per half cell (as in dense_pair)
-    const uint8_t* nfine8 = reinterpret_cast<const uint8_t*>(nfine32);
-    uint8_t* nleft8 = reinterpret_cast<uint8_t*>(smem) + kDenseNleftOff;
-    uint32_t* misc = smem + kDenseMiscOff / 4;
-    uint32_t* trash = smem + kDenseTrashOff / 4;
-
-    GMS_STAMP_DECL
-    if (tid < 32) misc[tid] = 0;
-    if (tid < 16) trash[tid] = 0;
-    if (tid < kFineN / 4) nfine32[tid] = 0;
-
-    // ---- both frames' codes staged in the still unused matrix area, then the pair's (queryIdx, trainIdx) (see dense_pair)
-    const uint32_t phA = (uint32_t)(reinterpret_cast<uintptr_t>(lcodeA) >> 1) & 7u, phB = (uint32_t)(reinterpret_cast<uintptr_t>(scodeB) >> 2) & 3u;
-    const uint32_t qA = (phA + (uint32_t)nA + 7u) >> 3, qB = (phB + (uint32_t)nB + 3u) >> 2;  // uint4s of either copy
-    const bool staged = (qA + qB) * 16u <= kDenseBytes;  // workgroup-uniform
-    const uint4* __restrict__ srcA = reinterpret_cast<const uint4*>(lcodeA - phA);
-    const uint4* __restrict__ srcB = reinterpret_cast<const uint4*>(scodeB - phB);
-    constexpr int kStageRegs = 4;
-    uint4 tb[kStageRegs];
-#pragma unroll
-    for (int i = 0; i < kStageRegs; ++i) {
-        const uint32_t j = min((uint32_t)(i * NT + tid), qA + qB - 1u);
-        const uint4* src = j < qA ? srcA + j : srcB + (j - qA);
-        tb[i] = *src;
-    }
-    uint2 qt[KPT];
-#pragma unroll
-    for (int k = 0; k < KPT; ++k) qt[k] = *reinterpret_cast<const uint2*>(&matches[min(k * NT + tid, m - 1)]);
-    if (staged) {
-        uint4* d4 = reinterpret_cast<uint4*>(smem);
-#pragma unroll
-        for (int i = 0; i < kStageRegs; ++i)
-            if ((uint32_t)(i * NT + tid) < qA + qB) d4[i * NT + tid] = tb[i];
-        for (uint32_t j = kStageRegs * NT + tid; j < qA + qB; j += NT) d4[j] = *(j < qA ? srcA + j : srcB + (j - qA));
-    }
-    const uint16_t* ldsA = reinterpret_cast<const uint16_t*>(smem) + phA;  // left code of frame A's keypoint q at ldsA[q]
-    const uint32_t* ldsB = smem + 4u * qA + phB;                           // scale code of frame B's keypoint t at ldsB[t]
-    __syncthreads();
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-
-    GMS_STAMP_OUT(4, 10);  // indices landed, codes staged
-    // code word as in dense_pair (E = E(r) of the current scale, 11 bits); aux = left cell under grid type 1 : 9 | right cell on the
-    // 20 x 20 grid : 9 | on the 28 x 28 grid : 10 | low bit of the 40 x 40 cell's x, y : 2 (the scale code as it stands, 9 bits up)
-    uint32_t code[KPT], aux[KPT];
-    {
-        uint32_t ca[KPT], cb[KPT];
-        if (staged) {
-#pragma unroll
-            for (int k = 0; k < KPT; ++k) ca[k] = ldsA[min(qt[k].x, (uint32_t)(nA - 1))];
-#pragma unroll
-            for (int k = 0; k < KPT; ++k) cb[k] = ldsB[min(qt[k].y, (uint32_t)(nB - 1))];
-        } else {
-#pragma unroll
-            for (int k = 0; k < KPT; ++k) ca[k] = lcodeA[min(qt[k].x, (uint32_t)(nA - 1))];
-#pragma unroll
-            for (int k = 0; k < KPT; ++k) cb[k] = scodeB[min(qt[k].y, (uint32_t)(nB - 1))];
-        }
-        bool any_bad = false, spill = false;
-        uint32_t fr[KPT];  // [half cell of the left point, row-major : 11 | rank inside it : 8], or ~0: binned nowhere
-#pragma unroll
-        for (int k = 0; k < KPT; ++k) {
-            const bool live = k * NT + tid < m;
-            const uint32_t cell = ca[k] >> kLCellShift;  // under grid type 1; kLCellNever / kLCellBad above the grid
-            const bool ok = ((int)(qt[k].x < (uint32_t)nA) & (int)(qt[k].y < (uint32_t)nB) & (int)(cell != kLCellBad) & (int)((cb[k] & kSCodeBad) == 0u)) != 0;
-            const bool binned = live & ok & (cell < kLCellNever);
-            const uint32_t sh = ((ca[k] & 1u) << 3) | ((ca[k] & 4u) << 2);  // byte (hx & 1) + 2 (hy & 1) of the cell's dword
-            const uint32_t old = atomicAdd(binned ? &nfine32[cell] : &trash[lane & 7], 1u << sh);
-            const uint32_t rank = (old >> sh) & 255u;
-            spill |= binned & (rank == 255u);
-            any_bad |= live & !ok;
-            const uint32_t r0 = cb[k] & 0x1FFu;
-            code[k] = binned ? ((ca[k] & 31u) | ((ca[k] & 0x60u) << 1) | ((403u - r0) << kDEShift)) : kDNever;
-            aux[k] = binned ? (cell | ((cb[k] & 0x1FFFFFu) << 9)) : 0u;
-            // half cell hy * 40 + hx with hx = 2 cx + (hx & 1), hy = 2 cy + (hy & 1): 2 cell + 40 cy + 40 (hy & 1) + (hx & 1)
-            const uint32_t cy = (cell * 3277u) >> 16;
-            const uint32_t f = 2u * cell + 40u * cy + ((ca[k] & 4u) ? 40u : 0u) + (ca[k] & 1u);
-            fr[k] = binned ? (f | (rank << 11)) : 0xFFFFFFFFu;
-        }
-        if (any_bad) misc[8] = 1;
-        if (spill) misc[13] = 1;
-        __syncthreads();  // histogram complete; every read of the staged codes is done
-        if ((misc[8] | misc[13]) != 0) {  // outside the parity domain, or a half cell above 255 matches (workgroup-uniform; nothing written yet)
-            __syncthreads();
-            return false;
-        }
-        // ---- exclusive scan over the 1600 half cells in row-major order: thread t < 800 takes half cells 2 t, 2 t + 1 (one cell's
-        //      two bytes of one half row), wave scan, wave totals through misc[16..31]
-        uint32_t c0 = 0, c1 = 0;
-        if (tid < 800) {
-            const int hy = tid / 20, cx = tid - hy * 20;
-            const uint32_t w = nfine32[(hy >> 1) * kLeftW + cx] >> ((hy & 1) << 4);
-            c0 = w & 255u;
-            c1 = (w >> 8) & 255u;
-        }
-        uint32_t incl = c0 + c1;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t t = __shfl_up(incl, d);
-            if (lane >= d) incl += t;
-        }
-        if (lane == 63) misc[16 + wave] = incl;
-        __syncthreads();
-        uint32_t wave_off = 0, nb_v = 0;
-#pragma unroll
-        for (int w = 0; w < NT / 64; ++w) {
-            const uint32_t x = misc[16 + w];
-            nb_v += x;
-            wave_off += w < wave ? x : 0u;
-        }
-        const uint32_t excl = wave_off + incl - (c0 + c1);
-        if (tid < 800) ldsa_st32(kSortStartOff + 4u * (uint32_t)tid, excl | ((excl + c0) << 16));
-        __syncthreads();
-        // ---- to the sorted order: (code, aux) through the matrix area, the match's position parked in the pair's record
-        const uint32_t nb_u = (uint32_t)uniform((int)nb_v);  // matches binned at all
-#pragma unroll
-        for (int k = 0; k < KPT; ++k) {
-            const bool binned = fr[k] != 0xFFFFFFFFu;
-            const uint32_t f = binned ? (fr[k] & 0x7FFu) : 0u;
-            const uint32_t pos = ldsa_ld16(kSortStartOff + 2u * f) + ((fr[k] >> 11) & 255u);
-            if (binned) ldsa_st64(8u * pos, code[k], aux[k]);
-            if (k * NT + tid < m) park[k * NT + tid] = (uint16_t)(binned ? pos : 0xFFFFu);
-        }
-        // first position of every half ROW (lane h: row h; lanes from 40 on: the number of binned matches) -- band borders, read with v_readlane
-        const uint32_t srow_v = lane < 40 ? ldsa_ld16(kSortStartOff + 80u * (uint32_t)lane) : nb_u;
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < KPT; ++k) {
-            const uint32_t pos = (uint32_t)(k * NT) + tpos;
-            const u32x2_t v = ldsa_ld64(8u * min(pos, (uint32_t)(kMcap - 1)));
-            code[k] = pos < nb_u ? v.x : kDNever;
-            aux[k] = pos < nb_u ? v.y : 0u;
-        }
-        __syncthreads();
-        {
-            const uint4 z4 = make_uint4(0, 0, 0, 0);
-            uint4* d4 = reinterpret_cast<uint4*>(smem);
-            for (uint32_t i = tid; i < kDenseBytes / 16; i += NT) d4[i] = z4;
-            // the sink dwords (see dense_pair_plain): the whole-matrix binning and marking loops run unpredicated, a match that is not
-            // binned in the current pass works on its lane's sink instead. Bit 31 is never cleared.
-            if (tid < 16) trash[tid] = 0x80000000u;
-            if (tid == 0) misc[15] = 0xFFFFFFFFu;  // "no header": what a match reads in the marking pass when the grid type leaves it out
-            if (tid >= 16 && tid < 32) misc[tid] = 0;
-        }
-        __syncthreads();
-        // (srow_v and nb_u stay live below)
-        const uint32_t sink_at = kDenseTrashOff + 4u * (uint32_t)(lane & 15), none_at = kDenseMiscOff + 4u * 15u;
-        uint32_t* nl32 = nfine32;            // crowded mode: nLeft as 16-bit counters, two buffers of 400
-        // first sorted position of half row h (h <= 0: 0, h >= 40: all binned matches)
-        auto spos = [&](int h) -> uint32_t { return (uint32_t)__builtin_amdgcn_readlane((int)srow_v, min(max(h, 0), 40)); };
-
-        const bool thr_fast = threshold_fast_ok(p.threshold_factor);
-        const uint32_t f2i = dense_factor_sq(p.threshold_factor);
-        uint32_t best_count = 0, bestbits = 0;
-        int best_scale = -1, best_rot = -1;
-        GMS_STAMP(12);  // sorted
-
-        // One scale hypothesis (see dense_scales_pair for the phases; PROBE, CROWDED and the return values are the same).
-        // BANDED: scale 3 (788-byte rows) in bands of 8 own rows, scale 4 (1604-byte rows) in bands of 3, a halo row on either side;
-        // probes band without halo (10 and 5 rows). A band's matches are the positions [spos(2 blo - gy), spos(2 bhi - gy)).
-        auto run_scale = [&](auto banded_c, auto crowded_c, auto probe_c, const int s) -> int {
-            constexpr bool BANDED = decltype(banded_c)::value;
-            constexpr bool CROWDED = decltype(crowded_c)::value;
-            constexpr bool PROBE = decltype(probe_c)::value;
-            const uint32_t wr = (uint32_t)p.right_w[s], nr = wr * wr;
-            const uint32_t stride = 4u + nr;                 // header dword + one byte per right cell
-            const uint32_t wr_magic = 65535u / wr + 1u;      // j / wr == (j * magic) >> 16 for j * wr < 65536
-            {   // the code words' E(r) for this scale
-#pragma unroll
-                for (int k = 0; k < KPT; ++k) {
-                    uint32_t r;
-                    if (s == 0) {
-                        r = (aux[k] >> 9) & 0x1FFu;
-                    } else if (s == 3) {
-                        r = (aux[k] >> 18) & 0x3FFu;
-                    } else if (s == 4) {  // double the 20 x 20 cell's coordinates and add the stored low bits: fl(40 n) = 2 fl(20 n) + bit
-                        const uint32_t c20 = (aux[k] >> 9) & 0x1FFu, cy = (c20 * 3277u) >> 16, cx = c20 - cy * 20u;
-                        r = (2u * cy + ((aux[k] >> 29) & 1u)) * 40u + 2u * cx + ((aux[k] >> 28) & 1u);
-                    } else {  // halve the finer grid's cell coordinates: 20 -> 10 (s == 1), 28 -> 14 (s == 2)
-                        const uint32_t fine = s == 1 ? (aux[k] >> 9) & 0x1FFu : (aux[k] >> 18) & 0x3FFu, wf = s == 1 ? 20u : 28u;
-                        const uint32_t fy = (fine * (s == 1 ? 3277u : 2341u)) >> 16, fx = fine - fy * wf;  // fine / wf for fine < 784
-                        r = (fy >> 1) * (wf >> 1) + (fx >> 1);
-                    }
-                    if (!(code[k] & kDNever)) code[k] = (code[k] & ~(kSEMask << kDEShift)) | ((nr + 3u - r) << kDEShift);
-                }
-            }
-            int status = 0;
-            const int band_rows = PROBE ? (s == 4 ? 5 : 10) : (s == 4 ? 3 : 8), halo = PROBE ? 0 : 1;
-            const int n_bands = BANDED ? (kLeftH + band_rows - 1) / band_rows : 1;
-            for (int g = 0; g < 4; ++g) {
-                const int gx = g & 1, gy = g >> 1;
-                const uint32_t q_mask = (uint32_t)(gx + 20 * gy);
-                const uint32_t out_mask = kDNever | (gx ? kDEdgeX : 0u) | (gy ? kDEdgeY : 0u);
-                uint32_t* nl32cur = nl32 + (g & 1) * (kLeftN / 2);
-                const uint16_t* nl16cur = reinterpret_cast<const uint16_t*>(nl32cur);
-                if (!CROWDED && tid < kLeftN) {
-                    const uint32_t n = dense_nleft_cm(nfine8, tid % kLeftW, tid / kLeftW, gx, gy);
-                    if (n > 255u) misc[11] = 1;
-                    nleft8[tid] = (uint8_t)n;
-                }
-                if (CROWDED && !PROBE) {  // nLeft of this grid type by counting (read by verify, behind the first barrier below)
-#pragma unroll
-                    for (int k = 0; k < KPT; ++k) {
-                        const uint32_t cw = code[k];
-                        const uint32_t l = (aux[k] & 0x1FFu) + (cw & q_mask);
-                        if ((cw & out_mask) == 0) atomicAdd(&nl32cur[l >> 1], 1u << ((l & 1u) << 4));
-                    }
-                }
-                for (int band = 0; band < n_bands; ++band) {
-                    const int lo = BANDED ? band * band_rows : 0, hi = BANDED ? min(lo + band_rows, kLeftH) : kLeftH;      // own rows
-                    const int blo = BANDED ? max(lo - halo, 0) : 0, bhi = BANDED ? min(hi + halo, kLeftH) : kLeftH;        // rows held
-                    const uint32_t cell0 = (uint32_t)(blo * kLeftW);
-                    const uint32_t own0 = (uint32_t)(lo * kLeftW), n_own = (uint32_t)((hi - lo) * kLeftW);
-                    // the band's matches as a range of sorted positions (held rows; own rows)
-                    const uint32_t held_lo = BANDED ? spos(2 * blo - gy) : 0u, held_n = BANDED ? spos(2 * bhi - gy) - held_lo : 0u;
-                    const uint32_t own_lo = BANDED ? spos(2 * lo - gy) : 0u, own_n = BANDED ? spos(2 * hi - gy) - own_lo : 0u;
-                    // arg-max keys carry (grid type, band) in their top bits: every binning pass outranks what the previous one
-                    // left in the headers (a cellPairs word, below 2^20), so headers are never reset inside a scale
-                    const uint32_t key_tag = (uint32_t)(BANDED ? g * n_bands + band + 1 : g) << kDTagShift;
-                    const uint32_t edge_x = gx ? kDEdgeX : 0u;
-
-                    // ---- assignMatchPairs
-#pragma unroll
-                    for (int k0 = 0; k0 < KPT; k0 += kChunk) {
-                        if constexpr (BANDED) {  // (uniform) none of the chunk's slots reaches into the band
-                            if ((uint32_t)(k0 * NT) >= held_lo + held_n || (uint32_t)((k0 + kChunk) * NT) <= held_lo) continue;
-                        }
-                        uint32_t old[kChunk], at[kChunk], row[kChunk], ee[kChunk];
-                        bool in[kChunk];
-#pragma unroll
-                        for (int c = 0; c < kChunk; ++c) {
-                            const uint32_t cw = code[k0 + c];
-                            const uint32_t l = (aux[k0 + c] & 0x1FFu) + (cw & q_mask) - cell0;
-                            if constexpr (BANDED) {
-                                in[c] = (uint32_t)((k0 + c) * NT) + tpos - held_lo < held_n && (cw & edge_x) == 0u;
-                                row[c] = __umul24(l, stride);
-                                ee[c] = (cw >> kDEShift) & kSEMask;
-                                at[c] = row[c] + ee[c];
-                                old[c] = 0;
-                                if (in[c]) old[c] = ldsa_add_rtn(at[c] & ~3u, 1u << ((at[c] << 3) & 31u));
-                            } else {
-                                in[c] = (cw & out_mask) == 0;
-                                row[c] = in[c] ? __umul24(l, stride) : sink_at;  // (not binned under this grid type: the lane's sink, E = 0)
-                                ee[c] = in[c] ? ((cw >> kDEShift) & kSEMask) : 0u;
-                                at[c] = row[c] + ee[c];
-                                old[c] = ldsa_add_rtn(at[c] & ~3u, 1u << ((at[c] << 3) & 31u));
-                            }
-                        }
-                        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                        for (int c = 0; c < kChunk; ++c) {
-                            const uint32_t before = __builtin_amdgcn_ubfe(old[c], at[c] << 3, 8);
-                            if (CROWDED && in[c] && before == 255u) misc[12] = 1;  // the entry's byte has just wrapped
-                            if (!BANDED || in[c]) ldsa_max(row[c], key_tag | (before << 11) | ee[c]);
-                        }
-                    }
-                    GMS_STAMP_IN(3);  // insert
-                    __syncthreads();
-                    GMS_STAMP_IN(11);  // insert: wait for the other waves
-                    if (!CROWDED && misc[11] != 0) {  // a cell above 255 matches (workgroup-uniform; nothing has been written out)
-                        status = 1;
-                        break;
-                    }
-                    if (CROWDED && misc[12] != 0) {  // a (left cell, right cell) pair above 255 matches
-                        status = 2;
-                        break;
-                    }
-
-                    // ---- verifyCellPairs for the cells of the own rows (see dense_scales_pair)
-                    if constexpr (!PROBE) {
-                        constexpr int kNR = ROT ? 2 : 1;             // rotations per lane
-                        constexpr int kLanesPerCell = ROT ? 4 : 2, kCellShift = ROT ? 2 : 1;
-                        const int n_items = (int)n_own * kLanesPerCell;
-                        for (int item = tid; item < ((n_items + 63) & ~63); item += NT) {
-                            const bool live = item < n_items;
-                            const int i = (int)own0 + (live ? (item >> kCellShift) : 0);
-                            const int sub = item & (kLanesPerCell - 1);
-                            const int half = item & 1;  // !ROT only
-                            const int ix = i % kLeftW, iy = i / kLeftW;
-                            const uint32_t ni = live ? (CROWDED ? (uint32_t)nl16cur[i] : (uint32_t)nleft8[i]) : 0u;
-                            if (__ballot(ni != 0) == 0ull) continue;  // none of this wave's cells has a match under this grid type
-                            const uint32_t hdr = ((uint32_t)i - cell0) * (stride >> 2);
-                            const uint32_t best = smem[hdr] & ((1u << kDTagShift) - 1u);
-                            const uint32_t ej = ni ? (best & 0x7FFu) : nr + 3u;
-                            const uint32_t j = nr + 3u - ej;
-                            const int jy = (int)((j * wr_magic) >> 16), jx = (int)j - jy * (int)wr;
-                            uint32_t score[kNR], tn[kNR];  // tn = (sum of nLeft << 4) | numpair
-                            uint32_t rpack[kNR];           // where the lane's rotations send the eight outer neighbours (rotation_pack)
-#pragma unroll
-                            for (int jr = 0; jr < kNR; ++jr) {
-                                score[jr] = tn[jr] = 0;
-                                rpack[jr] = sub == 0 ? rotation_pack(jr) : sub == 1 ? rotation_pack(2 + jr) : sub == 2 ? rotation_pack(4 + jr) : rotation_pack(6 + jr);
-                            }
-#pragma unroll
-                            for (int c = 0; c < (ROT ? 8 : 4); ++c) {
-                                int ldx, ldy;
-                                if (ROT) {
-                                    const int k = c < 4 ? c : c + 1;
-                                    ldx = (k % 3) - 1; ldy = (k / 3) - 1;
-                                } else {
-                                    ldx = half ? ((c + 5) % 3) - 1 : (c % 3) - 1;
-                                    ldy = half ? ((c + 5) / 3) - 1 : (c / 3) - 1;
-                                }
-                                const int lx = ix + ldx, ly = iy + ldy;
-                                const bool okl = ni != 0 && (uint32_t)lx < (uint32_t)kLeftW && (uint32_t)ly < (uint32_t)kLeftH;
-                                const uint32_t ll = okl ? (uint32_t)(lx + ly * kLeftW) : (uint32_t)i;  // within one row of an own row: held
-                                const uint32_t nll = CROWDED ? (uint32_t)nl16cur[ll] : (uint32_t)nleft8[ll];
-                                const uint32_t rowb = (ll - cell0) * stride;
-#pragma unroll
-                                for (int jr = 0; jr < kNR; ++jr) {
-                                    int rdx = ldx, rdy = ldy;
-                                    if (ROT) {
-                                        rdx = (int)((rpack[jr] >> (4 * c)) & 3u) - 1;
-                                        rdy = (int)((rpack[jr] >> (4 * c + 2)) & 3u) - 1;
-                                    }
-                                    const int rx = jx + rdx, ry = jy + rdy;
-                                    const bool okp = okl && (uint32_t)rx < wr && (uint32_t)ry < wr;
-                                    const uint32_t cnt = dense8[rowb + (okp ? nr + 3u - (uint32_t)(rx + ry * (int)wr) : 4u)];
-                                    score[jr] += okp ? cnt : 0u;
-                                    tn[jr] += okp ? ((nll << 4) | 1u) : 0u;
-                                }
-                            }
-                            uint32_t bits = 0;
-                            if (!ROT) {
-                                score[0] += dpp_xor1(score[0]);
-                                tn[0] += dpp_xor1(tn[0]);
-                            }
-#pragma unroll
-                            for (int jr = 0; jr < kNR; ++jr) {
-                                const uint32_t sc = score[jr] + (best >> 11) + 1u, t = tn[jr] + ((ni << 4) | 1u);
-                                uint32_t pass = 0;
-                                if (ni != 0 && (ROT || half == 0))
-                                    pass = (CROWDED ? threshold_rejects(t >> 4, t & 15u, sc, p.threshold_factor, thr_fast)
-                                                    : dense_threshold_rejects(t >> 4, t & 15u, sc, p.threshold_factor, thr_fast, f2i)) ? 0u : 1u;
-                                bits |= pass << jr;
-                            }
-                            if (ROT) {  // the cell's four lanes hold rotations (0,1) (2,3) (4,5) (6,7): gather the quad's bit pairs (DPP quad_perm broadcasts)
-                                const uint32_t b0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)bits, 0x00, 0xF, 0xF, false);
-                                const uint32_t b1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)bits, 0x55, 0xF, 0xF, false);
-                                const uint32_t b2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)bits, 0xAA, 0xF, 0xF, false);
-                                const uint32_t b3 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)bits, 0xFF, 0xF, 0xF, false);
-                                bits = b0 | (b1 << 2) | (b2 << 4) | (b3 << 6);
-                            }
-                            if (ni != 0 && sub == 0) smem[hdr] = (ej << 8) | bits;
-                        }
-                        __syncthreads();
-                    }
-                    GMS_STAMP_IN(5);  // verify
-
-                    // ---- mark the matches of the own rows; every increment of the rows held is taken back
-                    {
-                        if (CROWDED && !PROBE && tid < kLeftN / 2) nl32[((g + 1) & 1) * (kLeftN / 2) + tid] = 0;  // the next grid type's counters (idle now; a barrier follows)
-#pragma unroll
-                        for (int k0 = 0; k0 < KPT; k0 += kChunk) {
-                            if constexpr (BANDED) {
-                                if ((uint32_t)(k0 * NT) >= held_lo + held_n || (uint32_t)((k0 + kChunk) * NT) <= held_lo) continue;
-                            }
-                            uint32_t cr[kChunk];
-#pragma unroll
-                            for (int c = 0; c < kChunk; ++c) {
-                                const int k = k0 + c;
-                                const uint32_t cw = code[k];
-                                const uint32_t l = (aux[k] & 0x1FFu) + (cw & q_mask) - cell0;
-                                if constexpr (BANDED) {
-                                    const uint32_t pos = (uint32_t)(k * NT) + tpos;
-                                    const bool in = pos - held_lo < held_n && (cw & edge_x) == 0u;
-                                    const uint32_t row = __umul24(l, stride);
-                                    cr[c] = 0xFFFFFFFFu;  // "no header" (reads as E = 2047)
-                                    if (in) {
-                                        if (pos - own_lo < own_n) cr[c] = ldsa_ld32(row);
-                                        ldsa_st8(row + ((cw >> kDEShift) & kSEMask), 0u);  // (every reader of the entry is past the barrier: see dense_pair)
-                                    }
-                                } else {
-                                    const bool in = (cw & out_mask) == 0;
-                                    const uint32_t row = in ? __umul24(l, stride) : sink_at;
-                                    const uint32_t at = row + (in ? ((cw >> kDEShift) & kSEMask) : 0u);
-                                    cr[c] = ldsa_ld32(in ? row : none_at);
-                                    ldsa_st8(at, 0u);
-                                }
-                            }
-#pragma unroll
-                            for (int c = 0; c < kChunk; ++c) {
-                                const int k = k0 + c;
-                                if constexpr (PROBE) {  // the header still holds the arg-max key: [tag | count - 1 | E(j*)]; (a row not owned reads as E = 2047)
-                                    if ((cr[c] & 0x7FFu) == ((code[k] >> kDEShift) & kSEMask)) code[k] |= 1u << kSProbeBit;
-                                } else {
-                                    const uint32_t x = cr[c] ^ (code[k] & (kSEMask << kDEShift));
-                                    if (x < 256u) code[k] |= x << kSAccShift;
-                                }
-                            }
-                        }
-                    }
-                    __syncthreads();
-                    GMS_STAMP_IN(6);  // mark
-                }
-                if (status != 0) break;
-            }
-            if (status != 0) return status;
-            // the next scale lays its rows out differently: no header of this one may survive as a count byte
-            for (uint32_t c = tid; c < (uint32_t)kLeftN; c += NT)
-                if (!BANDED || c < (uint32_t)((s == 4 ? 5 : 10) * kLeftW)) smem[c * (stride >> 2)] = 0;
-
-            if constexpr (PROBE) {  // ---- how many matches could be inliers at this scale at all
-                uint32_t c0 = 0;
-#pragma unroll
-                for (int k = 0; k < KPT; ++k) c0 += (uint32_t)__popcll(__ballot((code[k] >> kSProbeBit) & 1u));
-                if (lane == 0 && c0) atomicAdd(&misc[0], c0);
-                __syncthreads();  // count complete; headers zeroed
-                const uint32_t bound = misc[0];
-#pragma unroll
-                for (int k = 0; k < KPT; ++k) code[k] &= ~(1u << kSProbeBit);
-                __syncthreads();
-                if (tid < 8) misc[tid] = 0;
-                // (a scale that comes BEFORE the best one in the reference's order would also win a tie)
-                const bool can_win = bound > best_count || (bound == best_count && s < best_scale);
-                if (tid == 0 && p.probe_stats != nullptr) atomicAdd(&p.probe_stats[can_win ? 0 : 1], 1u);
-                GMS_STAMP_IN(7);
-                return can_win ? 0 : 3;
-            }
-            // ---- run() return value per rotation of this scale, getInlierMask's strict '>'
-            {
-                uint32_t cnt[kNRot];
-#pragma unroll
-                for (int r = 0; r < kNRot; ++r) cnt[r] = 0;
-#pragma unroll
-                for (int k = 0; k < KPT; ++k)
-#pragma unroll
-                    for (int r = 0; r < kNRot; ++r)
-                        cnt[r] += (uint32_t)__popcll(__ballot((code[k] >> (kSAccShift + r)) & 1u));
-                if (lane == 0) {
-#pragma unroll
-                    for (int r = 0; r < kNRot; ++r)
-                        if (cnt[r]) atomicAdd(&misc[r], cnt[r]);
-                }
-            }
-            __syncthreads();  // counts complete; headers zeroed
-            // getInlierMask walks scale-outer, rotation-inner and keeps on strict '>': the first hypothesis with the largest count wins.
-            // Scale 1 is evaluated before scale 0 here, so a count that TIES the best replaces it when this scale comes before the best one's.
-            int winner = -1;
-#pragma unroll
-            for (int r = 0; r < kNRot; ++r) {
-                const uint32_t c = misc[r];
-                if (c > best_count || (c == best_count && c != 0 && s < best_scale)) {
-                    best_count = c;
-                    best_scale = s;
-                    best_rot = r + 1;
-                    winner = r;
-                }
-            }
-            if (winner >= 0) {  // the best hypothesis' inliers: one bit per slot of the thread
-                bestbits = 0;
-#pragma unroll
-                for (int k = 0; k < KPT; ++k) bestbits |= ((code[k] >> (kSAccShift + winner)) & 1u) << k;
-            }
-#pragma unroll
-            for (int k = 0; k < KPT; ++k) code[k] &= ~(0xFFu << kSAccShift);
-            __syncthreads();
-            if (tid < 8) misc[tid] = 0;
-            GMS_STAMP_IN(7);  // count + select
-            return 0;
-        };
-
-        // one scale: the probe first where the launch asks for it and there is a best count to beat
-        auto eval_scale = [&](auto banded_c, auto crowded_c, const int s) -> int {
-            if (((p.probe_scales >> s) & 1) != 0 && best_count > 0) {
-                const int prb = run_scale(banded_c, crowded_c, std::true_type{}, s);
-                GMS_STAMP_SCALE(5 + s);
-                if (prb != 0) return prb == 3 ? 0 : prb;
-            }
-            const int ev = run_scale(banded_c, crowded_c, std::false_type{}, s);
-            GMS_STAMP_SCALE(s);
-            return ev;
-        };
-        // Order: scale 1 first (see dense_scales_pair), then 0, 2, 3, 4.
-        int status = 0;
-        for (int i = 0; i < 3 && status == 0; ++i) status = eval_scale(std::false_type{}, std::false_type{}, i == 0 ? 1 : (i == 1 ? 0 : 2));
-        for (int s = 3; s < 5 && status == 0; ++s) status = eval_scale(std::true_type{}, std::false_type{}, s);
-        if (status == 1) {
-            // crowded (a left cell above 255 matches): everything again on a clean matrix, nLeft counted into 16-bit counters and every
-            // returned entry count checked; the cell populations do not depend on the scale, so this shows at the first scale
-            __syncthreads();
-            {
-                const uint4 z4 = make_uint4(0, 0, 0, 0);
-                uint4* d4 = reinterpret_cast<uint4*>(smem);
-                for (uint32_t i = tid; i < kDenseBytes / 16; i += NT) d4[i] = z4;
-                if (tid < kLeftN) nl32[tid] = 0;
-                if (tid < 8) misc[tid] = 0;
-            }
-#pragma unroll
-            for (int k = 0; k < KPT; ++k) code[k] &= ~(0xFFu << kSAccShift);
-            best_count = bestbits = 0;
-            best_scale = best_rot = -1;
-            __syncthreads();
-            status = 0;
-            for (int i = 0; i < 3 && status == 0; ++i) status = eval_scale(std::false_type{}, std::true_type{}, i == 0 ? 1 : (i == 1 ? 0 : 2));
-            for (int s = 3; s < 5 && status == 0; ++s) status = eval_scale(std::true_type{}, std::true_type{}, s);
-        }
-        if (status != 0) {
-            __syncthreads();
-            return false;
-        }
-        __syncthreads();
-        // ---- the winner's inlier bits back to list order: a byte per sorted position in the (idle) matrix area, read through the parked positions
-        uint16_t pk[KPT];
-#pragma unroll
-        for (int k = 0; k < KPT; ++k) pk[k] = park[min(k * NT + tid, m - 1)];
-#pragma unroll
-        for (int k = 0; k < KPT; ++k) {
-            const uint32_t pos = (uint32_t)(k * NT) + tpos;
-            if (pos < nb_u) ldsa_st8(pos, (bestbits >> k) & 1u);
-        }
-        __syncthreads();
-        if (tid == 0) {
-            part[0] = 5u;  // all five scales decided: filter_kernel copies out
-            part[1] = best_count;
-            part[2] = (uint32_t)best_scale;
-            part[3] = (uint32_t)best_rot;
-        }
-#pragma unroll
-        for (int k = 0; k < KPT; ++k) {  // the inlier bit of match k * NT + tid: chunk of 64 consecutive matches = one ballot
-            const bool have = k * NT + tid < m && pk[k] != 0xFFFFu;
-            const uint32_t bit = have ? ldsa_ld8((uint32_t)pk[k]) : 0u;
-            const unsigned long long bsel = __ballot(bit != 0u);
-            if (lane == 0) {
-                const int ch = k * (NT / 64) + wave;
-                part[kPartialHeaderDw + 2 * ch] = (uint32_t)bsel;
-                part[kPartialHeaderDw + 2 * ch + 1] = (uint32_t)(bsel >> 32);
-            }
-        }
-    }
-    GMS_STAMP_OUT(9, 11);  // record written
-    GMS_STAMP_FLUSH;
-    return true;
-}
-
-template <int KPT, bool ROT, int NT>
-__global__ void __launch_bounds__(NT)
-filter_kernel_scales_sorted(FilterParams p)
-{
-    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-    first_round_stagger(p);
-    uint32_t* part = p.partial + (size_t)blockIdx.x * p.partial_stride;
-    if (!sorted_scales_pair<KPT, ROT, NT>(p, smem, (int)blockIdx.x, (int)threadIdx.x, part)) {
         if (threadIdx.x == 0) part[0] = 0u;  // the hashed kernel evaluates all five scales
     }
 }
@@ -3275,8 +2672,7 @@ static hipError_t allow_full_lds_t()
     const void* fns[] = {reinterpret_cast<const void*>(filter_kernel<KPT, ROT, NT>),
                          reinterpret_cast<const void*>(filter_kernel_dense<KPT, ROT, NT, false>),
                          reinterpret_cast<const void*>(filter_kernel_dense<KPT, ROT, NT, true>),
-                         reinterpret_cast<const void*>(filter_kernel_dense_scales<KPT, ROT, NT>),
-                         reinterpret_cast<const void*>(filter_kernel_scales_sorted<KPT, ROT, NT>)};
+                         reinterpret_cast<const void*>(filter_kernel_dense_scales<KPT, ROT, NT>)};
     for (const void* fn : fns) {
         const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes);
         if (e != hipSuccess) return e;
@@ -3316,10 +2712,6 @@ hipError_t launch_filter(const FilterParams& p, int kpt, int n_pairs, hipStream_
 template <int KPT, bool ROT, int NT>
 static hipError_t launch_dense_scales_t(const FilterParams& p, int n_pairs, hipStream_t stream)
 {
-    if (p.sorted_scales) {
-        hipLaunchKernelGGL((filter_kernel_scales_sorted<KPT, ROT, NT>), dim3((unsigned)n_pairs), dim3(NT), kDenseLdsBytes, stream, p);
-        return hipGetLastError();
-    }
     hipLaunchKernelGGL((filter_kernel_dense_scales<KPT, ROT, NT>), dim3((unsigned)n_pairs), dim3(NT), kDenseLdsBytes, stream, p);
     return hipGetLastError();
 }
