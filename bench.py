@@ -604,6 +604,92 @@ def pixels_leg(ctx, pkg, stream, dev, n_images=32, max_kp=10000, threshold=20, s
                        "rule": "keypoint records, their order and the descriptor bits vs oracle/detect_ref.c (the definition; not cv::ORB)"}}
 
 
+def real_pixels_leg(ctx, pkg, stream, dev, copies=2048, steps=6):
+    """The reference's own main() scenario (main.cpp:19-47 -> SIFT_matchGMS, FeatureMatchUtil.cpp:52-84) from real pixels: the 1920 x 1080
+    pair Disparity_L / Disparity_R as it is, with the right image turned by 180 degrees, and with the right image resized to 1000 x 1000
+    (tests/golden/image_main_scenario_1080p.npz). Pixels -> gms_detect_batch_device (10 000 keypoints) -> gms_bfmatch_device -> the
+    filter's rate on those matches: `copies` copies of the pair per launch (every copy its own match array), at the wrapper's flags
+    (true, true) and at the defaults. What the headline's uniformly random keypoints do not show: a detector's raster order and clustering."""
+    import torch
+    batch = importlib.import_module(PKG + ".batch")
+    path = os.path.join(ROOT, "tests", "golden", "image_main_scenario_1080p.npz")
+    if not os.path.exists(path):
+        return {"skipped": "tests/golden/image_main_scenario_1080p.npz not found"}
+    z = np.load(path)
+    left, right = np.ascontiguousarray(z["left"]), np.ascontiguousarray(z["right"])
+    images = [left, right, np.ascontiguousarray(right[::-1, ::-1]), np.ascontiguousarray(z["right_1000"])]
+    thr, max_kp = 3, 10000
+    kps, rows = [], []
+    for img in images:
+        k, r = batch.detect_images(ctx, img[None], thr, max_kp)
+        kps.append(k[0])
+        rows.append(r[0])
+    sizes = [(im.shape[1], im.shape[0]) for im in images]
+    table = batch.FrameTable(ctx, kps, sizes, device=dev)
+    dt = batch.DescriptorTable(ctx, table, rows, pkg.GMS_DESC_HAMMING256)
+    oracle = oracle_module()
+    out = {"workload": f"main.cpp:19-47: Disparity_L / Disparity_R (1920 x 1080) from pixels, FAST threshold {thr}, at most {max_kp} keypoints per image "
+                       f"(the build's FAST/BRIEF detector, not SIFT), BFMatcher::match, then {copies} copies of the pair per launch",
+           "keypoints": [int(len(k)) for k in kps]}
+    cx = np.minimum((kps[0]["x"] / sizes[0][0] * 20).astype(np.int64), 19)
+    cy = np.minimum((kps[0]["y"] / sizes[0][1] * 20).astype(np.int64), 19)
+    cells = np.bincount(cy * 20 + cx, minlength=400)
+    out["left_image_cells"] = {"occupied": int((cells > 0).sum()), "max_keypoints_in_a_cell": int(cells.max()),
+                               "note": "keypoints come in raster order; the byte-matrix kernel goes crowded above 255 matches in a cell of any grid type"}
+    ok = True
+    for name, b in (("normal", 1), ("rotated_180", 2), ("resized_1000", 3)):
+        m = len(kps[0])
+        one = np.zeros(1, dtype=pkg.PAIR_DTYPE)
+        one[0] = (0, b, m, 0, 0)
+        matches = batch.match_pairs(ctx, dt, one)
+        pairs = np.zeros(copies, dtype=pkg.PAIR_DTYPE)
+        pairs["frame_a"], pairs["frame_b"], pairs["m"] = 0, b, m
+        pairs["match_off"] = np.arange(copies, dtype=np.int64) * m
+        d_pairs = torch.from_numpy(pairs.view(np.uint8).reshape(-1)).to(dev)
+        d_matches = torch.from_numpy(np.ascontiguousarray(matches).view(np.uint8).reshape(-1)).to(dev).repeat(copies)
+        d_out = torch.zeros(copies * m * 16, dtype=torch.uint8, device=dev)
+        d_res = torch.zeros((copies, 4), dtype=torch.int32, device=dev)
+        rec = {}
+        for tag, rot, scale in (("rot_scale", True, True), ("default_flags", False, False)):
+            ctx.reserve(copies, m, rot, scale)
+            torch.cuda.synchronize()
+            ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+            with torch.cuda.stream(stream):
+                for s in range(-3, steps):
+                    if s == -1:  # the library picks its lane mapping from what an earlier launch saw: let that verdict land before timing
+                        torch.cuda.synchronize()
+                    if s >= 0:
+                        ev[s][0].record(stream)
+                    ctx.filter_device(table.d_pts.data_ptr(), table.d_frame_off.data_ptr(), table.n_frames, d_pairs.data_ptr(), copies, m,
+                                      d_matches.data_ptr(), d_out.data_ptr(), d_res.data_ptr(), None, rot, scale, 6.0)
+                    if s >= 0:
+                        ev[s][1].record(stream)
+            torch.cuda.synchronize()
+            ms = float(np.median([a.elapsed_time(bb) for a, bb in ev]))
+            res = d_res.cpu().numpy().view(pkg.RESULT_DTYPE).reshape(-1)
+            rc, want, _, want_res = oracle.match(sizes[0], sizes[b], kps[0], kps[b], matches, rot, scale, 6.0)
+            k = len(want)
+            bad = 0
+            for i in (0, copies - 1):
+                got = d_out[i * m * 16:(i * m + k) * 16].cpu().numpy().view(pkg.DMATCH_DTYPE)
+                bad += 0 if (rc == 0 and int(res["n_inliers"][i]) == k and got.tobytes() == want.tobytes()
+                             and (int(res["best_scale"][i]), int(res["best_rot"][i])) == (int(want_res[1]), int(want_res[2]))) else 1
+            ok = ok and bad == 0
+            alg = (32.0 * m + 16.0 * k) * copies
+            rec[tag] = {"flags": [rot, scale, 6.0], "value": copies / (ms * 1e-3), "unit": "pairs/s", "ms_per_launch": ms, "kept": k,
+                        "winner": [int(want_res[1]), int(want_res[2])], "dealt_lane_mapping": bool(ctx.query(1)),
+                        "roofline": {"bound": "hbm", "achieved": alg / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                     "frac": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "traffic": None,
+                                     "kernel": "all kernels of the launch (HIP events around gms_filter_device)", "kernel_ms_per_launch": ms,
+                                     "algorithmic_bytes_per_launch": alg},
+                        "parity": {"pairs_checked": 2, "mismatches": bad, "bit_exact": bad == 0}}
+        rec["matches"] = int(m)
+        rec["image_sizes"] = [list(sizes[0]), list(sizes[b])]
+        out[name] = rec
+    out["parity_ok"] = ok
+    return out
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -737,6 +823,9 @@ def main():
             # f2: the keypoint source in front of the matcher
             line["pixels_to_keypoints"] = pixels_leg(ctx, pkg, stream, dev)
             ok = ok and line["pixels_to_keypoints"]["parity"]["bit_exact"]
+            # BASELINE configs 1 / 2 on real pixels: the reference's own main() scenario
+            line["real_pixels"] = real_pixels_leg(ctx, pkg, stream, dev)
+            ok = ok and line["real_pixels"].get("parity_ok", True)
         print(json.dumps(line))
         sys.stdout.flush()
     distmod.barrier(dist)
