@@ -161,6 +161,16 @@ def timed_steps(ctx, wl, stream, steps, warmup, rot, scale, dist, first_chunk=0,
     return wall, float(np.mean([a.elapsed_time(b) for a, b in ev]))
 
 
+def opencv_on_box():
+    """is there an OpenCV with the reference's own matchGMS on this box? (Only recorded; tests/test_gpu_opencv_probe.py uses it.)"""
+    try:
+        import cv2
+    except Exception as e:  # noqa: BLE001
+        return {"present": False, "found": f"no cv2 module ({type(e).__name__})"}
+    has = hasattr(getattr(cv2, "xfeatures2d", None), "matchGMS")
+    return {"present": bool(has), "found": f"cv2 {cv2.__version__} " + ("with" if has else "without") + " xfeatures2d.matchGMS"}
+
+
 def oracle_module():
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import gms_oracle
@@ -761,6 +771,7 @@ def main():
                                 "once per sequence, outside the timed steps: every frame serves frames - 1 pairs",
             "parity": {"pairs_checked": checked_all, "mismatches": bad_all, "bit_exact": ok,
                        "rule": f"every {distmod.PARITY_EVERY}th global pair of every resident chunk, on every rank, vs oracle/gms_ref.c"},
+            "opencv_on_box": opencv_on_box(),
         }
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):  # measured in a separate rocprofv3 --pmc run (tools/pmc_collect.sh), not in this one

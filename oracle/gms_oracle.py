@@ -54,6 +54,10 @@ def load():
     lib.gms_ref_assign_pairs.restype = i32
     lib.gms_ref_verify_cells.argtypes = [vp, vp, i32, i32, i32, dbl, vp]
     lib.gms_ref_verify_cells.restype = i32
+    lib.gms_ref_selftest_mark.argtypes = [vp, vp, i32, vp]
+    lib.gms_ref_selftest_mark.restype = i32
+    lib.gms_ref_selftest_select.argtypes = [i32, i32, i32, vp, vp, vp, vp, vp, vp]
+    lib.gms_ref_selftest_select.restype = i32
     lib.gms_ref_neighbors.argtypes = [i32, i32, vp]
     lib.gms_ref_neighbors.restype = None
     lib.gms_ref_scale_ratio.argtypes = [i32]
@@ -211,6 +215,34 @@ def verify_cells(motion, nleft, wr, hr, rotation_type, factor=6.0):
                                   float(factor), out.ctypes.data)
     assert rc == 0
     return out
+
+
+def mark_inliers(pairs, cell_pairs, mask):
+    """run()'s marking loop for one grid type on (pairs [m, 2], cell_pairs [400]); `mask` (uint8 [m]) accumulates in place.
+    Returns the count run() would return after this grid type."""
+    lib = load()
+    pairs = np.ascontiguousarray(pairs, dtype=np.int32)
+    cp = np.ascontiguousarray(cell_pairs, dtype=np.int32)
+    assert cp.size == 400 and mask.dtype == np.uint8 and mask.flags["C_CONTIGUOUS"] and len(mask) == len(pairs)
+    return int(lib.gms_ref_selftest_mark(pairs.ctypes.data, cp.ctypes.data, len(pairs), mask.ctypes.data))
+
+
+def select_hypothesis(with_rotation, with_scale, counts, masks):
+    """getInlierMask's loop nest on scripted run() results: counts [5, 8], masks uint8 [5, 8, m] ->
+    (best count, best scale, best rot, best mask uint8 [m], call log)."""
+    lib = load()
+    counts = np.ascontiguousarray(counts, dtype=np.int32).reshape(5, 8)
+    masks = np.ascontiguousarray(masks, dtype=np.uint8)
+    m = masks.shape[2]
+    assert masks.shape == (5, 8, m)
+    best_mask = np.zeros(max(m, 1), dtype=np.uint8)
+    best = np.zeros(3, dtype=np.int32)
+    log = np.zeros(96, dtype=np.int32)
+    n_log = C.c_int(0)
+    rc = lib.gms_ref_selftest_select(int(bool(with_rotation)), int(bool(with_scale)), m, counts.ctypes.data, masks.ctypes.data,
+                                     best_mask.ctypes.data, best.ctypes.data, log.ctypes.data, C.byref(n_log))
+    assert rc == 0
+    return int(best[0]), int(best[1]), int(best[2]), best_mask[:m], log[:n_log.value].copy()
 
 
 def disparity(kp1, kp2, matches, width, height, gt, disp_ratio):

@@ -6,36 +6,37 @@
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this; the product
  * path (sfm-gms_amd/csrc) never links, calls or falls back to it.
  *
- * PARITY: PINNED ONLY IN PART. The reference holds no tests, golden vectors or recorded outputs for this path
- *  and its implementation exists only as a Windows PE32+ DLL whose imports
- * (opencv_core452.dll, ...) are not vendored, so the function as a whole cannot be run here: end-to-end
- * parity is UNPINNED. What is pinned against the reference itself:
- *   - grid_index_left / grid_index_right (the float -> cell arithmetic, where bit-exactness is decided): the two
- *     corresponding leaf functions of the DLL were executed here on 6.7k points and their outputs are committed as
- *     tests/golden/refdll_grid_index.npz (generator: tests/golden/refdll_runner.c, make_refdll_vectors.py);
- *     tests/test_oracle_pins.py requires this file to reproduce every integer;
- *   - assign_match_pairs (binning: the skip rule, the right cell cached by grid type 1, motion[l][r]++ and the
- *     per-cell counts): GMSMatcher::assignMatchPairs was executed out of the DLL (its only call is
- *     getGridIndexLeft) for grid types 1..4 on three right grids; tests/golden/refdll_assign_pairs.npz holds
- *     what it wrote, and gms_ref_assign_pairs() must reproduce it;
- *   - verify_cell_pairs (arg-max, rotated 3 x 3 neighbour sums, sqrt(T / n) * factor, '>'): the body of
- *     GMSMatcher::verifyCellPairs after its cv::sum(row) test (DLL@0x180048e12) was executed out of the DLL one
- *     cell at a time for rotation types 1..8 on nine motion matrices (all five right grids, four factors);
- *     tests/golden/refdll_verify_cells.npz holds mCellPairs and gms_ref_verify_cells() must reproduce it;
- *   - init_neighbors (getNB9 / initalizeNeighbors): the DLL's own initalizeNeighbors was executed (its operator new / delete
- *     pointed at this process's allocator) for the left grid, the five right grids of setScale and three odd grids;
- *     tests/golden/refdll_nb9.npz holds the tables, gms_ref_neighbors() must reproduce them -- and the verify fragment
- *     above consumed THOSE tables, not restated ones;
- *   - the rotation-pattern table, the scale-ratio table and the 0.5 constant: compared byte for byte with the DLL
- *     by tests/test_oracle_pins.py when /root/reference exists.
- *   - normalize_points: GMSMatcher::normalizePoints executed out of the DLL on cv::KeyPoint records of eight image sizes
- *     (tests/golden/refdll_normalize.npz); set_scale's arithmetic: the head of GMSMatcher::setScale executed up to its first
- *     import, after the DLL's own static initialiser of mScaleRatios (tests/golden/refdll_setscale.npz).
- * What is left (the loops of run and getInlierMask, matchGMS's copy-out) follows the DLL's
- * disassembly address by address (cited per function, "DLL@0x..." = virtual address in that DLL, image base
- * 0x180000000) and keeps the reference's dense 400 x N_right motion matrix and
- * loop order on purpose, so that it is an obviously faithful, structurally independent checker for the sparse
- * GPU formulation; a second restatement (gms_ref_sparse.py) must agree with it bit for bit.
+ * PARITY: PINNED BY THE REFERENCE BINARY'S OWN CODE, PIECE BY PIECE AND AS A CHAIN -- not by a run of the unmodified function.
+ * The reference holds no tests, golden vectors or recorded outputs for this path and its
+ * implementation exists only as a Windows PE32+ DLL whose imports (opencv_core452.dll, ...) are not vendored, so matchGMS cannot
+ * be called as it stands. What tests/golden/refdll_runner.c does instead is map the DLL and execute its functions -- whole where
+ * they are self-contained, from behind their first import where they are not -- on inputs built here; only inputs and returned
+ * values are committed (tests/golden/refdll_*.npz, generator make_refdll_vectors.py), and tests/test_oracle_pins.py /
+ * tests/test_golden.py require this file to reproduce every one of them:
+ *   - grid_index_left / grid_index_right (the float -> cell arithmetic): the DLL's two leaf functions on 6.7k points;
+ *   - assign_match_pairs: GMSMatcher::assignMatchPairs for grid types 1..4 on three right grids;
+ *   - verify_cell_pairs: the body of GMSMatcher::verifyCellPairs behind its cv::sum(row) test, one cell at a time, rotation
+ *     types 1..8, nine motion matrices (all five right grids, four factors), on neighbour tables the DLL filled itself;
+ *   - init_neighbors: GMSMatcher::initalizeNeighbors / getNB9 (operator new / delete pointed at this process's allocator);
+ *   - normalize_points: GMSMatcher::normalizePoints on cv::KeyPoint records of eight image sizes; set_scale: the head of
+ *     GMSMatcher::setScale up to its first import, after the DLL's own static initialiser of mScaleRatios;
+ *   - mark_inliers / count_mask (run()'s marking loop, its grid-type loop exit, its return value): the tail of GMSMatcher::run
+ *     from behind its verifyCellPairs call, for grid types 1..4 in sequence (refdll_mark.npz);
+ *   - select_hypothesis (getInlierMask: loop nest and order, strict '>', the mask copy, the value returned):
+ *     GMSMatcher::getInlierMask executed WHOLE with its eight calls of setScale / run re-pointed at a script player, every flag
+ *     combination, eleven scripts -- ties, all zero, maximum first / last (refdll_select.npz);
+ *   - the rotation-pattern table, the scale-ratio table and the 0.5 constant, byte for byte (when /root/reference exists);
+ *   - END TO END (refdll_chain.npz): getInlierMask executed whole with those calls re-pointed at drivers that run the DLL's own
+ *     pieces (setScale's head + initalizeNeighbors; per grid type assignMatchPairs, the verifyCellPairs body per cell, run's
+ *     marking / counting tail), behind the DLL's normalizePoints -- on the inputs of all fourteen golden cases (BASELINE configs 1
+ *     and 2 among them), all four flag combinations: the masks and counts equal this file's, bit for bit.
+ * What the runner supplies between the DLL's pieces, and what therefore stays pinned by reading (DLL addresses cited per
+ * function below): storage and Mat::zeros' allocations, the zero fills of run() (Mat::setTo(0), the three vector::assign calls),
+ * the "row sum == 0" test in front of a cell's verification (cv::sum), convertMatches' copy of (queryIdx, trainIdx), and
+ * matchGMS's copy-out (clear + push_back of every masked match). No arithmetic of the algorithm is among them.
+ * The dense 400 x N_right motion matrix and the reference's loop order are kept on purpose, so that this file is an obviously
+ * faithful, structurally independent checker for the sparse GPU formulation; a second restatement (gms_ref_sparse.py) must
+ * agree with it bit for bit.
  *
  * Build: gcc -O2 -ffp-contract=off -fno-fast-math (x86-64 SSE2: float ops are true fp32, no x87).
  */
@@ -252,6 +253,22 @@ static void verify_cell_pairs(gms_ref_state* st, int rotation_type)
     }
 }
 
+/* The tail of one grid type in GMSMatcher::run, DLL@0x180048ae0-0x180048b26: a match whose left cell is on the grid and whose
+ * right cell is that cell's verified partner becomes an inlier (bts: OR-accumulated over the grid types). */
+static void mark_inliers(const int* pair_first, const int* pair_second, const int* cell_pairs, int m, unsigned char* mask)
+{
+    for (int i = 0; i < m; i++)
+        if (pair_first[i] >= 0 && cell_pairs[pair_first[i]] == pair_second[i]) mask[i] = 1;
+}
+
+/* run()'s return value, DLL@0x180048b46-0x180048bd4: the number of set bits of mvbInlierMask. */
+static int count_mask(const unsigned char* mask, int m)
+{
+    int c = 0;
+    for (int i = 0; i < m; i++) c += mask[i];
+    return c;
+}
+
 /* GMSMatcher::run, DLL@0x180048630-0x180048c08. */
 static int run(gms_ref_state* st, int rotation_type)
 {
@@ -265,13 +282,56 @@ static int run(gms_ref_state* st, int rotation_type)
         }
         assign_match_pairs(st, grid_type);
         verify_cell_pairs(st, rotation_type);
-        for (int i = 0; i < st->n_matches; i++)
-            if (st->pair_first[i] >= 0 && st->cell_pairs[st->pair_first[i]] == st->pair_second[i])
-                st->mask[i] = 1;
+        mark_inliers(st->pair_first, st->pair_second, st->cell_pairs, st->n_matches, st->mask);
     }
-    int c = 0;
-    for (int i = 0; i < st->n_matches; i++) c += st->mask[i];
-    return c;
+    return count_mask(st->mask, st->n_matches);
+}
+
+/* GMSMatcher::getInlierMask, DLL@0x180047dc0-0x180047fe1, on abstract setScale / run (the real ones below; scripted ones in
+ * gms_ref_selftest_select): scale outer (0..4 with withScale, else 0 alone), rotation inner (1..8 with withRotation, else 1
+ * alone); a hypothesis replaces the best one -- its mask is copied -- on a strictly larger count, starting from 0. Without either
+ * flag the DLL copies the mask of its one run unconditionally (DLL@0x180047df4-0x180047e00): with a count of 0 that mask is all
+ * false, which is what best_mask starts as. Returns 0, or the error a callback reports. */
+typedef struct {
+    void* ctx;
+    int (*set_scale)(void* ctx, int scale);                                /* 0 = ok */
+    int (*run)(void* ctx, int rotation_type, const unsigned char** mask);  /* the count, *mask = the run's mask; < 0 = error */
+} hypothesis_ops;
+
+static int select_hypothesis(const hypothesis_ops* ops, int with_rotation, int with_scale, int m, unsigned char* best_mask,
+                             int* max_inlier, int* best_scale, int* best_rot)
+{
+    *max_inlier = 0;
+    *best_scale = *best_rot = -1;
+    if (m > 0) memset(best_mask, 0, (size_t)m);
+    const int n_scales = with_scale ? 5 : 1, n_rots = with_rotation ? 8 : 1;
+    for (int scale = 0; scale < n_scales; scale++) {
+        const int rc = ops->set_scale(ops->ctx, scale);
+        if (rc) return rc;
+        for (int rot = 1; rot <= n_rots; rot++) {
+            const unsigned char* mask = NULL;
+            const int num_inlier = ops->run(ops->ctx, rot, &mask);
+            if (num_inlier < 0) return num_inlier;
+            if (num_inlier > *max_inlier) {
+                memcpy(best_mask, mask, (size_t)m);
+                *max_inlier = num_inlier;
+                *best_scale = scale;
+                *best_rot = rot;
+            } else if (!with_rotation && !with_scale && m > 0) {
+                memcpy(best_mask, mask, (size_t)m);  /* the one run's mask, whatever its count (all false when the count is 0) */
+            }
+        }
+    }
+    return 0;
+}
+
+static int real_set_scale(void* ctx, int scale) { return set_scale((gms_ref_state*)ctx, scale) ? GMS_ERR_BAD_ARG : 0; }
+static int real_run(void* ctx, int rotation_type, const unsigned char** mask)
+{
+    gms_ref_state* st = (gms_ref_state*)ctx;
+    const int c = run(st, rotation_type);
+    *mask = st->mask;
+    return st->domain_error ? GMS_ERR_DOMAIN : c;
 }
 
 /* matchGMS (DLL@0x180048280) on a caller-kept state: `st` holds nothing but storage between calls. */
@@ -335,30 +395,12 @@ static int match_with_state(gms_ref_state* st, const gms_keypoint* kp1, int n1, 
         }
     }
 
-    /* GMSMatcher::getInlierMask, DLL@0x180047dc0-0x180047fe1: scale outer (0..4), rotation inner
-     * (1..8); keep (mask, count) on strict '>' starting from 0. Without either flag: setScale(0),
-     * run(1), take the mask unconditionally. */
+    /* GMSMatcher::getInlierMask (select_hypothesis above) on this pair's setScale / run */
     int max_inlier = 0, best_scale = -1, best_rot = -1;
-    int n_scales = with_scale ? 5 : 1;
-    int n_rots = with_rotation ? 8 : 1;
-    for (int scale = 0; scale < n_scales; scale++) {
-        if (set_scale(st, scale)) {
-            rc = GMS_ERR_BAD_ARG;
-            goto done;
-        }
-        for (int rot = 1; rot <= n_rots; rot++) {
-            int num_inlier = run(st, rot);
-            if (st->domain_error) {
-                rc = GMS_ERR_DOMAIN;
-                goto done;
-            }
-            if (num_inlier > max_inlier) {
-                memcpy(best_mask, st->mask, (size_t)m);
-                max_inlier = num_inlier;
-                best_scale = scale;
-                best_rot = rot;
-            }
-        }
+    {
+        const hypothesis_ops ops = {st, real_set_scale, real_run};
+        rc = select_hypothesis(&ops, with_rotation, with_scale, m, best_mask, &max_inlier, &best_scale, &best_rot);
+        if (rc) goto done;
     }
 
     /* matchGMS copy-out, DLL@0x18004831e-0x180048371: clear, then push every masked match. */
@@ -546,4 +588,60 @@ int gms_ref_verify_cells(const int* motion, const int* nleft, int wr, int hr, in
     free(st.nb_left);
     free(st.nb_right);
     return 0;
+}
+
+/* Test hook: run()'s marking loop and its return value for one grid type (mark_inliers / count_mask above) on a hand-laid-out
+ * state, the mask accumulating over calls -- compared with the DLL's own tail of run() (tests/golden/refdll_mark.npz). */
+int gms_ref_selftest_mark(const int* pairs /* m x 2 */, const int* cell_pairs /* 400 */, int m, unsigned char* mask /* m, in/out */)
+{
+    int* first = (int*)malloc(sizeof(int) * (size_t)(m > 0 ? m : 1));
+    int* second = (int*)malloc(sizeof(int) * (size_t)(m > 0 ? m : 1));
+    if (!first || !second) {
+        free(first);
+        free(second);
+        return -1;
+    }
+    for (int i = 0; i < m; i++) {
+        first[i] = pairs[2 * i];
+        second[i] = pairs[2 * i + 1];
+    }
+    mark_inliers(first, second, cell_pairs, m, mask);
+    free(first);
+    free(second);
+    return count_mask(mask, m);
+}
+
+/* Test hook: getInlierMask's loop nest (select_hypothesis above, the one the real path runs) on SCRIPTED run() results --
+ * counts[5][8] and masks[5][8][m] -- with a log of the calls it makes (100 + s = setScale(s), r = run(r)); compared with the DLL's
+ * own getInlierMask driven by the same script (tests/golden/refdll_select.npz). */
+typedef struct {
+    const int* counts;
+    const unsigned char* masks;
+    int m, scale, n_log;
+    int* log;
+} script_ctx;
+static int script_set_scale(void* ctx, int scale)
+{
+    script_ctx* c = (script_ctx*)ctx;
+    c->scale = scale;
+    if (c->n_log < 96) c->log[c->n_log++] = 100 + scale;
+    return 0;
+}
+static int script_run(void* ctx, int rotation_type, const unsigned char** mask)
+{
+    script_ctx* c = (script_ctx*)ctx;
+    if (c->n_log < 96) c->log[c->n_log++] = rotation_type;
+    const int idx = c->scale * 8 + rotation_type - 1;
+    *mask = c->masks + (size_t)idx * (size_t)c->m;
+    return c->counts[idx];
+}
+int gms_ref_selftest_select(int with_rotation, int with_scale, int m, const int* counts, const unsigned char* masks,
+                            unsigned char* best_mask, int* best /* count, scale, rot */, int* log /* 96 */, int* n_log)
+{
+    script_ctx c = {counts, masks, m, 0, 0, log};
+    const hypothesis_ops ops = {&c, script_set_scale, script_run};
+    for (int i = 0; i < 96; i++) log[i] = -1;
+    const int rc = select_hypothesis(&ops, with_rotation, with_scale, m, best_mask, &best[0], &best[1], &best[2]);
+    *n_log = c.n_log;
+    return rc;
 }

@@ -45,6 +45,10 @@ int   gms_ref_assign_pairs(const float* p1, const float* p2, const int* matches,
                            int* pairs, int* nleft, int* motion);                 /* DLL@0x180047880 */
 int   gms_ref_verify_cells(const int* motion, const int* nleft, int wr, int hr, int rotation_type, double factor,
                            int* cell_pairs_out);                                  /* DLL@0x180048d10 */
+/* run()'s marking loop + count for one grid type (DLL@0x180048ae0-0x180048bd4); getInlierMask's loop nest on scripted run() results (DLL@0x180047dc0) */
+int   gms_ref_selftest_mark(const int* pairs, const int* cell_pairs, int m, unsigned char* mask);
+int   gms_ref_selftest_select(int with_rotation, int with_scale, int m, const int* counts, const unsigned char* masks,
+                              unsigned char* best_mask, int* best, int* log, int* n_log);
 
 /* gms_ref_mt.c: the same call over a batch of pairs, one pair per thread at a time (the algorithm
  * itself stays serial, as in the reference). Frames are (kp pointer, n, w, h) tables. Returns the

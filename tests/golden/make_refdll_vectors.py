@@ -224,6 +224,157 @@ def setscale_fixture():
     print("setscale fixture", out["ratios"].tolist(), out["left20x20"].tolist())
 
 
+def _runner(tmp):
+    exe = os.path.join(tmp, "refdll_runner")
+    subprocess.check_call(["gcc", "-O1", "-o", exe, os.path.join(HERE, "refdll_runner.c")])
+    return exe
+
+
+def mark_fixture():
+    """The tail of GMSMatcher::run (marking loop of one grid type, the count of the mask, RVA 0x48acd on) run out of the DLL for grid
+    types 1..4 in sequence on hand-laid-out mvMatchPairs / mCellPairs: the mask after every type and the count the code returns."""
+    rng = np.random.default_rng(0x5F3759DF ^ 5)
+    out = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        exe = _runner(tmp)
+        for tag, (m, nr) in {"a": (1000, 400), "b": (77, 100), "c": (4097, 1600), "d": (32, 196), "e": (1, 784), "f": (0, 400)}.items():
+            pairs, cps = [], []
+            for t in range(4):
+                cp = rng.integers(0, nr, 400).astype(np.int32)
+                cp[rng.random(400) < 0.25] = -1          # empty cells
+                cp[rng.random(400) < 0.25] = -2          # rejected cells
+                first = rng.integers(-1, 400, m).astype(np.int32)           # -1: the left point is on no cell of this grid type
+                second = rng.integers(0, nr, m).astype(np.int32)
+                hit = rng.random(m) < 0.4                                    # matches whose right cell IS their cell's partner
+                second[hit] = np.where(first[hit] >= 0, cp[np.maximum(first[hit], 0)], second[hit])
+                second[rng.random(m) < 0.02] = -1                            # a right cell of -1 equals an "empty" cell pair: the DLL's compare decides
+                second[rng.random(m) < 0.02] = -2
+                pairs.append(np.stack([first, second], axis=1).astype(np.int32))
+                cps.append(cp)
+            fin, fout = os.path.join(tmp, "in.bin"), os.path.join(tmp, "out.bin")
+            with open(fin, "wb") as f:
+                f.write(np.int32(m).tobytes())
+                for t in range(4):
+                    f.write(pairs[t].tobytes()); f.write(cps[t].tobytes())
+            subprocess.check_call([exe, DLL, fin, fout, "mark"])
+            raw = np.fromfile(fout, dtype=np.uint32)
+            words = (m + 31) // 32
+            assert len(raw) == 4 * (words + 1)
+            out[tag + "_m"] = np.int32(m)
+            for t in range(4):
+                blk = raw[t * (words + 1):(t + 1) * (words + 1)]
+                out[f"{tag}_pairs{t + 1}"], out[f"{tag}_cell_pairs{t + 1}"] = pairs[t], cps[t]
+                out[f"{tag}_mask_words{t + 1}"] = blk[:words].copy()
+                out[f"{tag}_count{t + 1}"] = np.int32(blk[words])
+            print("mark", tag, "counts", [int(out[f"{tag}_count{t + 1}"]) for t in range(4)])
+    np.savez_compressed(os.path.join(HERE, "refdll_mark.npz"), **out)
+    print("mark fixture", os.path.getsize(os.path.join(HERE, "refdll_mark.npz")), "bytes")
+
+
+def select_fixture():
+    """GMSMatcher::getInlierMask itself run out of the DLL on scripted setScale / run (refdll_runner.c "select"): for every flag
+    combination and several scripts of counts -- distinct, tied, all zero, the maximum first / last, falling, rising -- the count it
+    returns, the mask it leaves in the caller's vector and the sequence of calls it makes."""
+    rng = np.random.default_rng(0x5F3759DF ^ 6)
+    out = {}
+    scripts = {}
+    m = 70
+    base = rng.integers(1, 60, (5, 8)).astype(np.int32)
+    scripts["random"] = base
+    t = base.copy(); t[:] = 17
+    scripts["all_tied"] = t
+    scripts["all_zero"] = np.zeros((5, 8), dtype=np.int32)
+    t = base.copy(); t[0, 0] = 99
+    scripts["first_is_max"] = t
+    t = base.copy(); t[4, 7] = 99
+    scripts["last_is_max"] = t
+    t = base.copy(); t[2, 3] = 80; t[3, 1] = 80; t[1, 6] = 80
+    scripts["ties_across_scales"] = t
+    t = base.copy(); t[1, 2] = 80; t[1, 5] = 80
+    scripts["ties_inside_a_scale"] = t
+    scripts["rising"] = np.arange(40, dtype=np.int32).reshape(5, 8)
+    scripts["falling"] = (40 - np.arange(40, dtype=np.int32)).reshape(5, 8)
+    t = np.zeros((5, 8), dtype=np.int32); t[3, 4] = 1
+    scripts["one_inlier_late"] = t
+    t = np.zeros((5, 8), dtype=np.int32); t[0, 1:] = 5; t[1:, 0] = 5
+    scripts["first_run_empty"] = t
+    words = (m + 31) // 32
+    with tempfile.TemporaryDirectory() as tmp:
+        exe = _runner(tmp)
+        for name, counts in scripts.items():
+            masks = rng.integers(0, 2, (5, 8, m)).astype(np.uint8)       # a distinct mask per hypothesis (the counts are the script's, not popcounts)
+            packed = np.zeros((5, 8, words), dtype=np.uint32)
+            for i in range(m):
+                packed[:, :, i // 32] |= masks[:, :, i].astype(np.uint32) << np.uint32(i % 32)
+            out[f"{name}_counts"], out[f"{name}_masks"] = counts, masks
+            for rot in (0, 1):
+                for scale in (0, 1):
+                    fin, fout = os.path.join(tmp, "in.bin"), os.path.join(tmp, "out.bin")
+                    with open(fin, "wb") as f:
+                        f.write(np.array([m, rot, scale], dtype=np.int32).tobytes())
+                        f.write(counts.tobytes()); f.write(packed.tobytes())
+                    subprocess.check_call([exe, DLL, fin, fout, "select"])
+                    raw = open(fout, "rb").read()
+                    ret = np.frombuffer(raw[:4], dtype=np.int32)[0]
+                    bits = np.frombuffer(raw[4:12], dtype=np.int64)[0]
+                    w = np.frombuffer(raw[12:12 + 4 * words], dtype=np.uint32)
+                    n_log = np.frombuffer(raw[12 + 4 * words:16 + 4 * words], dtype=np.int32)[0]
+                    log = np.frombuffer(raw[16 + 4 * words:], dtype=np.int32)[:n_log]
+                    got = np.array([(w[i // 32] >> np.uint32(i % 32)) & 1 for i in range(m)], dtype=np.uint8)
+                    key = f"{name}_rot{rot}_scale{scale}"
+                    out[key + "_ret"], out[key + "_bits"], out[key + "_mask"], out[key + "_calls"] = np.int32(ret), np.int64(bits), got, log.copy()
+            print("select", name, {f"r{r}s{sc}": int(out[f"{name}_rot{r}_scale{sc}_ret"]) for r in (0, 1) for sc in (0, 1)})
+    np.savez_compressed(os.path.join(HERE, "refdll_select.npz"), **out)
+    print("select fixture", os.path.getsize(os.path.join(HERE, "refdll_select.npz")), "bytes")
+
+
+def chain_fixture():
+    """matchGMS's whole computation as a chain of the DLL's own pieces (refdll_runner.c "chain": normalizePoints, getInlierMask with
+    its setScale / run calls re-pointed at drivers that run the DLL's setScale head, initalizeNeighbors, assignMatchPairs, the body of
+    verifyCellPairs and the marking / counting tail of run) on the inputs of every golden case of this directory, all four flag
+    combinations: the mask the DLL's getInlierMask leaves and the count it returns."""
+    import glob
+    kp_dtype = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")])
+    out = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        exe = _runner(tmp)
+        for path in sorted(glob.glob(os.path.join(HERE, "*.npz"))):
+            name = os.path.basename(path)[:-4]
+            z = np.load(path)
+            if "xy1" not in z.files or "query" not in z.files:
+                continue
+            xy1, xy2, q, t = z["xy1"], z["xy2"], z["query"], z["train"]
+            m = len(q)
+            kps = []
+            for xy in (xy1, xy2):
+                kp = np.zeros(len(xy), dtype=kp_dtype)
+                kp["x"], kp["y"], kp["size"], kp["angle"], kp["class_id"] = xy[:, 0], xy[:, 1], 31.0, -1.0, -1
+                kps.append(kp)
+            for rot in (0, 1):
+                for scale in (0, 1):
+                    fin, fout = os.path.join(tmp, "in.bin"), os.path.join(tmp, "out.bin")
+                    with open(fin, "wb") as f:
+                        f.write(np.array([len(xy1), len(xy2), m, z["size1"][0], z["size1"][1], z["size2"][0], z["size2"][1], rot, scale], dtype=np.int32).tobytes())
+                        f.write(np.float64(6.0).tobytes())
+                        f.write(kps[0].tobytes()); f.write(kps[1].tobytes())
+                        f.write(np.stack([q, t], axis=1).astype(np.int32).tobytes())
+                    subprocess.check_call([exe, DLL, fin, fout, "chain"])
+                    raw = open(fout, "rb").read()
+                    words = (m + 31) // 32
+                    ret = int(np.frombuffer(raw[:4], dtype=np.int32)[0])
+                    bits = int(np.frombuffer(raw[4:12], dtype=np.int64)[0])
+                    w = np.frombuffer(raw[12:12 + 4 * words], dtype=np.uint32)
+                    mask = np.unpackbits(w.view(np.uint8), bitorder="little")[:m] if m else np.zeros(0, dtype=np.uint8)
+                    assert bits in (0, m) and (bits == m or not mask.any())
+                    key = f"{name}_r{rot}s{scale}"
+                    out[key + "_mask"] = np.packbits(mask, bitorder="little")
+                    out[key + "_ret"] = np.int32(ret)
+                    same = (f"mask_r{rot}s{scale}" in z.files and np.array_equal(np.unpackbits(z[f"mask_r{rot}s{scale}"], bitorder="little")[:m], mask))
+                    print("chain", key, "count", ret, "kept", int(mask.sum()), "== golden" if same else "!= GOLDEN")
+    np.savez_compressed(os.path.join(HERE, "refdll_chain.npz"), **out)
+    print("chain fixture", os.path.getsize(os.path.join(HERE, "refdll_chain.npz")), "bytes")
+
+
 def main():
     if not os.path.exists(DLL):
         sys.exit("reference DLL not present: this generator runs only where /root/reference is mounted")
@@ -245,6 +396,9 @@ def main():
     nb9_fixture()
     normalize_fixture()
     setscale_fixture()
+    mark_fixture()
+    select_fixture()
+    chain_fixture()
     print(len(pts), "points;", "left range", res[:, :4].min(), res[:, :4].max(), "; file",
           os.path.getsize(os.path.join(HERE, "refdll_grid_index.npz")), "bytes")
 

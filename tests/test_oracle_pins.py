@@ -10,6 +10,7 @@ import numpy as np
 import pytest
 
 DLL = "/root/reference/SfM-GMS/bin/opencv_xfeatures2d452.dll"
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
 @pytest.mark.skipif(not os.path.exists(DLL), reason="reference DLL not present on this box")
@@ -228,3 +229,47 @@ def test_set_scale_matches_the_reference_binary(oracle):
             lib.gms_ref_right_grid_from(lw, lh, s, C.byref(wr), C.byref(hr))
             assert [wr.value, hr.value, wr.value * hr.value, wr.value * hr.value, 9, 4] == z[key][s].tolist(), (key, s)
     assert z["left20x20"][:, 0].tolist() == [20, 10, 14, 28, 40] and z["left15x25"][1].tolist()[:2] == [8, 12]
+
+
+def test_marking_loop_matches_the_reference_binary(oracle):
+    """The tail of GMSMatcher::run executed out of the DLL (tests/golden/refdll_runner.c "mark": the marking loop of one grid type,
+    the grid-type loop's exit, the count of the mask's bits, RVA 0x48acd-0x48bd4) for grid types 1..4 in sequence: the oracle's
+    mark_inliers / count_mask -- the functions its run() is made of -- must leave the same mask and return the same count."""
+    z = np.load(os.path.join(GOLDEN, "refdll_mark.npz"))
+    tags = sorted({k.split("_")[0] for k in z.files})
+    assert tags == list("abcdef")
+    for tag in tags:
+        m = int(z[tag + "_m"])
+        mask = np.zeros(m, dtype=np.uint8)
+        for t in range(1, 5):
+            count = oracle.mark_inliers(z[f"{tag}_pairs{t}"].reshape(m, 2), z[f"{tag}_cell_pairs{t}"], mask)
+            words = z[f"{tag}_mask_words{t}"]
+            want = np.array([(int(words[i // 32]) >> (i % 32)) & 1 for i in range(m)], dtype=np.uint8)
+            assert count == int(z[f"{tag}_count{t}"]) == int(want.sum()), (tag, t)
+            assert np.array_equal(mask, want), (tag, t)
+
+
+def test_hypothesis_selection_matches_the_reference_binary(oracle):
+    """GMSMatcher::getInlierMask executed WHOLE out of the DLL with its calls of setScale / run re-pointed at a script player
+    (refdll_runner.c "select"): the sequence of calls (scale outer, rotation inner), the strict '>' (ties keep the first), the
+    mask that ends up in the caller's vector and the count returned. The oracle's select_hypothesis -- the loop its real path
+    runs -- is driven by the same scripts."""
+    z = np.load(os.path.join(GOLDEN, "refdll_select.npz"))
+    names = sorted({k[:-len("_counts")] for k in z.files if k.endswith("_counts")})
+    assert len(names) == 11
+    for name in names:
+        counts, masks = z[name + "_counts"], z[name + "_masks"]
+        for rot in (0, 1):
+            for scale in (0, 1):
+                key = f"{name}_rot{rot}_scale{scale}"
+                best, bs, br, mask, calls = oracle.select_hypothesis(rot, scale, counts, masks)
+                assert best == int(z[key + "_ret"]), key
+                assert calls.tolist() == z[key + "_calls"].tolist(), key
+                want_calls = [v for s in range(5 if scale else 1) for v in [100 + s] + list(range(1, (8 if rot else 1) + 1))]
+                assert calls.tolist() == want_calls, key
+                if int(z[key + "_bits"]) == 0:       # the DLL never assigned the caller's vector: no hypothesis had an inlier
+                    assert best == 0 and not mask.any() and (rot or scale), key
+                else:
+                    assert np.array_equal(mask, z[key + "_mask"]), key
+                    if best > 0:
+                        assert np.array_equal(mask, masks[bs, br - 1]) and counts[bs, br - 1] == best, key
