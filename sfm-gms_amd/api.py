@@ -97,25 +97,41 @@ class GmsContext:
 
     # -- host-pointer batch path: many pairs per call, pinned staging and two streams inside the library ------------
     def filter_host_batch(self, keypoints_per_frame, sizes, pairs, matches, withRotation=False, withScale=False,
-                          thresholdFactor=6.0):
+                          thresholdFactor=6.0, out=None, results=None):
         """gms_filter_host_batch: `pairs` (PAIR_DTYPE) index `matches` (DMATCH_DTYPE) by match_off. Returns
-        (out, results): pair i's survivors at out[match_off : match_off + results[i].n_inliers]."""
-        counts = np.array([len(k) for k in keypoints_per_frame], dtype=np.int64)
-        frame_off = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
-        kp = (np.concatenate([_as(k, KEYPOINT_DTYPE, "keypoints") for k in keypoints_per_frame])
-              if frame_off[-1] else np.zeros(1, dtype=KEYPOINT_DTYPE))
+        (out, results): pair i's survivors at out[match_off : match_off + results[i].n_inliers].
+        keypoints_per_frame: a list of per-frame KEYPOINT_DTYPE arrays, or (all keypoints back to back, frame offsets [n_frames + 1])
+        as the C ABI takes them (no concatenation per call). out / results: arrays of a previous call to write into -- a fresh
+        output array costs first-touch page faults inside the call (7 ms for 327 MB), a C++ caller's std::vector has been touched
+        by its constructor."""
+        if isinstance(keypoints_per_frame, tuple):
+            kp, frame_off = keypoints_per_frame
+            kp = _as(kp, KEYPOINT_DTYPE, "keypoints") if len(kp) else np.zeros(1, dtype=KEYPOINT_DTYPE)
+            frame_off = np.ascontiguousarray(frame_off, dtype=np.int64)
+            n_frames = len(frame_off) - 1
+        else:
+            counts = np.array([len(k) for k in keypoints_per_frame], dtype=np.int64)
+            frame_off = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+            kp = (np.concatenate([_as(k, KEYPOINT_DTYPE, "keypoints") for k in keypoints_per_frame])
+                  if frame_off[-1] else np.zeros(1, dtype=KEYPOINT_DTYPE))
+            n_frames = len(counts)
         wh = np.ascontiguousarray(np.asarray(sizes, dtype=np.int32).reshape(-1, 2))
-        if wh.shape[0] != len(counts):
+        if wh.shape[0] != n_frames:
             raise ValueError("one (width, height) per frame")
         pairs = _as(pairs, PAIR_DTYPE, "pairs")
         mt = _as(matches, DMATCH_DTYPE, "matches")
-        out = np.zeros(max(len(mt), 1), dtype=DMATCH_DTYPE)
-        res = np.zeros(max(len(pairs), 1), dtype=RESULT_DTYPE)
-        rc = self._lib.gms_filter_host_batch(self._h, kp.ctypes.data, frame_off.ctypes.data, wh.ctypes.data, len(counts),
+        if out is None:
+            out = np.zeros(max(len(mt), 1), dtype=DMATCH_DTYPE)
+        if results is None:
+            results = np.zeros(max(len(pairs), 1), dtype=RESULT_DTYPE)
+        if (out.dtype != DMATCH_DTYPE or results.dtype != RESULT_DTYPE or len(out) < len(mt) or len(results) < len(pairs)
+                or not out.flags["C_CONTIGUOUS"] or not results.flags["C_CONTIGUOUS"]):
+            raise ValueError("out / results: contiguous DMATCH_DTYPE / RESULT_DTYPE arrays of at least len(matches) / len(pairs)")
+        rc = self._lib.gms_filter_host_batch(self._h, kp.ctypes.data, frame_off.ctypes.data, wh.ctypes.data, n_frames,
                                              pairs.ctypes.data, len(pairs), mt.ctypes.data, int(bool(withRotation)),
-                                             int(bool(withScale)), float(thresholdFactor), out.ctypes.data, res.ctypes.data)
+                                             int(bool(withScale)), float(thresholdFactor), out.ctypes.data, results.ctypes.data)
         _check(rc, self._lib, "gms_filter_host_batch")
-        return out[: len(mt)], res[: len(pairs)]
+        return out[: len(mt)], results[: len(pairs)]
 
     # -- device-resident batch path (raw device pointers; torch tensors' data_ptr() are fine) ---------
     def reserve(self, n_pairs, max_m, withRotation=False, withScale=False):

@@ -6,7 +6,9 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
+#include <condition_variable>
 #include <cstdio>
 #include <cstddef>
 #include <cstdlib>
@@ -159,7 +161,9 @@ struct Lane {
     hipStream_t stream = nullptr;
     PinBuf hin, hout;
     DevBuf din, dout;
+    hipEvent_t ev_res = nullptr, ev_out = nullptr;  // gms_filter_host_batch: a chunk's results are on the host / its survivors are
 };
+namespace { class CopyPool; }
 
 struct gms_ctx {
     int device = 0;
@@ -194,7 +198,8 @@ struct gms_ctx {
     hipEvent_t ws_event = nullptr;
     hipStream_t ws_stream = nullptr;
     bool ws_pending = false;
-    Lane lane[2];     // one-shot calls use lane 0 (on the context's stream); gms_filter_host_batch alternates
+    Lane lane[3];     // one-shot calls use lane 0 (on the context's stream); gms_filter_host_batch rotates through all three
+    CopyPool* pool = nullptr;  // gms_filter_host_batch: the threads that stage its chunks (created with the first call)
     DevBuf tab_kp, tab_pts, tab_small;  // gms_filter_host_batch: the call's frame table
     int n_cus = 256;  // multiProcessorCount of the device
 };
@@ -268,7 +273,7 @@ int grow_pose_ws(gms_ctx* c, size_t bytes, hipStream_t st)
 int filter_launch(gms_ctx* c, hipStream_t st, const float* d_pts, const int64_t* d_frame_off, int n_frames,
                   const gms_pair* d_pairs, int n_pairs, int max_m, const gms_dmatch* d_matches,
                   int with_rotation, int with_scale, double threshold_factor,
-                  gms_dmatch* d_out, gms_pair_result* d_results, uint8_t* d_mask)
+                  gms_dmatch* d_out, gms_pair_result* d_results, uint8_t* d_mask, bool validate_pairs = true)
 {
     if (n_pairs < 0 || max_m < 0 || n_frames < 0) return GMS_ERR_BAD_ARG;
     if (n_pairs == 0) return GMS_OK;
@@ -405,7 +410,7 @@ int filter_launch(gms_ctx* c, hipStream_t st, const float* d_pts, const int64_t*
     c->last_stagger_ticks = p.stagger_ticks;
     // pair-table validation (ranges [match_off, match_off + m) must be disjoint: include/gms.h), behind the filter: offenders'
     // status becomes GMS_ERR_BAD_ARG. The first launch of a context and every sixteenth; never inside a stream capture.
-    if (n_pairs > 1 && !capturing && knobs().check_pairs != 0 && (knobs().check_pairs == 1 || (c->filter_launches & 15u) == 0u))
+    if (validate_pairs && n_pairs > 1 && !capturing && knobs().check_pairs != 0 && (knobs().check_pairs == 1 || (c->filter_launches & 15u) == 0u))
         GMS_HIP(gms::launch_check_pairs(d_pairs, n_pairs, d_results, (uint32_t*)c->probe_stats.p + 8, st));
     if (!capturing) ++c->filter_launches;
     if (uses_ws && !capturing) {
@@ -421,39 +426,16 @@ int filter_launch(gms_ctx* c, hipStream_t st, const float* d_pts, const int64_t*
 // and coming back:                                            [ results (16 B each) | out (16 B each) ]
 size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
 
-// Host-side staging is memory-bound on one core (about 7 GB/s into pinned memory, a fraction of what PCIe moves): the copies of a
-// chunk are cut into jobs and run on a few threads.
+// Host-side staging: the copies between the caller's (pageable) arrays and the pinned blocks the copy engines work from. One core
+// moves 25-35 GB/s here, four move 65-110 (tools/ubench/host_copy_rate.cpp), the copy engines 30-55 GB/s per direction: the copies of
+// a chunk are cut into parts of 1 MB that a PERSISTENT pool of threads (created with the context's first host batch, not per chunk)
+// takes from a shared counter; the calling thread works along.
 struct CopyJob {
     void* dst;
     const void* src;
-    size_t bytes;
+    size_t bytes;   // of dst
+    int pack_xy;    // 0: memcpy; 1: src = gms_keypoint records, dst = (pt.x, pt.y) float pairs, 8 bytes each (bytes % 8 == 0)
 };
-void run_copy_jobs(const std::vector<CopyJob>& jobs)
-{
-    size_t total = 0;
-    for (const CopyJob& j : jobs) total += j.bytes;
-    unsigned hw = std::thread::hardware_concurrency();
-    const unsigned n_thr = (unsigned)std::min<size_t>(std::min<size_t>(hw ? hw : 4, 16), total / ((size_t)2 << 20) + 1);  // >= 2 MB per thread
-    auto work = [&](unsigned t) {
-        // thread t takes the byte range [t, t + 1) * total / n_thr of the concatenated jobs
-        const size_t lo = total * t / n_thr, hi = total * (t + 1) / n_thr;
-        size_t pos = 0;
-        for (const CopyJob& j : jobs) {
-            const size_t a = std::max(lo, pos), b = std::min(hi, pos + j.bytes);
-            if (a < b) std::memcpy((char*)j.dst + (a - pos), (const char*)j.src + (a - pos), b - a);
-            pos += j.bytes;
-            if (pos >= hi) break;
-        }
-    };
-    if (n_thr <= 1) {
-        work(0);
-        return;
-    }
-    std::vector<std::thread> pool;
-    for (unsigned t = 1; t < n_thr; ++t) pool.emplace_back(work, t);
-    work(0);
-    for (std::thread& th : pool) th.join();
-}
 
 // (pt.x, pt.y) of n keypoints, 8 bytes each: all the filter reads of a cv::KeyPoint (DLL@0x1800485d4) and all that has to
 // cross PCIe. Pure data movement; the divide by the image size happens on the GPU (normalize_kernel).
@@ -464,6 +446,105 @@ void pack_xy(const gms_keypoint* kp, size_t n, float* dst)
         dst[2 * i + 1] = kp[i].y;
     }
 }
+
+class CopyPool {
+public:
+    ~CopyPool() { shutdown(); }
+    void shutdown()
+    {
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            stop_ = true;
+        }
+        cv_work_.notify_all();
+        for (std::thread& t : threads_) t.join();
+        threads_.clear();
+        stop_ = false;
+    }
+    // Runs the jobs (disjoint destinations) and returns when every byte has landed.
+    void run(const std::vector<CopyJob>& jobs)
+    {
+        if (jobs.empty()) return;
+        starts_.resize(jobs.size() + 1);
+        starts_[0] = 0;
+        for (size_t i = 0; i < jobs.size(); ++i) starts_[i + 1] = starts_[i] + jobs[i].bytes;
+        const size_t total = starts_.back();
+        if (total == 0) return;
+        const unsigned n_parts = (unsigned)((total + kPart - 1) / kPart);
+        if (n_parts <= 1) {
+            part(jobs, 0);
+            return;
+        }
+        if (threads_.empty()) start();
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            jobs_ = &jobs;
+            n_parts_ = n_parts;
+            next_.store(0, std::memory_order_relaxed);
+            done_ = 0;
+            ++gen_;
+        }
+        cv_work_.notify_all();
+        unsigned mine = 0;
+        for (unsigned i; (i = next_.fetch_add(1, std::memory_order_relaxed)) < n_parts; ++mine) part(jobs, i);
+        std::unique_lock<std::mutex> lk(mu_);
+        done_ += mine;
+        cv_done_.wait(lk, [&] { return done_ == n_parts_; });
+        jobs_ = nullptr;
+    }
+
+private:
+    static constexpr size_t kPart = (size_t)1 << 20;
+    void start()
+    {
+        unsigned hw = std::thread::hardware_concurrency();
+        const unsigned n = std::min(hw ? hw : 4u, 8u) - 1;   // plus the calling thread
+        for (unsigned t = 0; t < n; ++t) threads_.emplace_back([this] { worker(); });
+    }
+    void worker()
+    {
+        uint64_t seen = 0;
+        for (;;) {
+            const std::vector<CopyJob>* jobs;
+            unsigned n_parts;
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_work_.wait(lk, [&] { return stop_ || gen_ != seen; });
+                if (stop_) return;
+                seen = gen_;
+                jobs = jobs_;
+                n_parts = n_parts_;
+            }
+            if (!jobs) continue;
+            unsigned mine = 0;
+            for (unsigned i; (i = next_.fetch_add(1, std::memory_order_relaxed)) < n_parts; ++mine) part(*jobs, i);
+            std::lock_guard<std::mutex> lk(mu_);
+            done_ += mine;
+            if (done_ == n_parts_) cv_done_.notify_all();
+        }
+    }
+    // bytes [i, i + 1) * kPart of the concatenated destinations
+    void part(const std::vector<CopyJob>& jobs, unsigned i) const
+    {
+        const size_t lo = (size_t)i * kPart, hi = std::min(lo + kPart, starts_.back());
+        size_t j = (size_t)(std::upper_bound(starts_.begin(), starts_.end(), lo) - starts_.begin()) - 1;
+        for (; j < jobs.size() && starts_[j] < hi; ++j) {
+            const size_t a = std::max(lo, starts_[j]) - starts_[j], b = std::min(hi, starts_[j + 1]) - starts_[j];
+            if (a >= b) continue;
+            if (jobs[j].pack_xy) pack_xy((const gms_keypoint*)jobs[j].src + a / 8, (b - a) / 8, (float*)((char*)jobs[j].dst + a));
+            else std::memcpy((char*)jobs[j].dst + a, (const char*)jobs[j].src + a, b - a);
+        }
+    }
+    std::vector<std::thread> threads_;
+    std::vector<size_t> starts_;
+    std::mutex mu_;
+    std::condition_variable cv_work_, cv_done_;
+    const std::vector<CopyJob>* jobs_ = nullptr;
+    unsigned n_parts_ = 0, done_ = 0;
+    std::atomic<unsigned> next_{0};
+    uint64_t gen_ = 0;
+    bool stop_ = false;
+};
 
 }  // namespace
 
@@ -508,6 +589,11 @@ int gms_ctx_create(int device, gms_ctx** out_ctx)
     c->device = device;
     e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->lane[1].stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->lane[2].stream, hipStreamNonBlocking);
+    for (Lane& l : c->lane) {
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&l.ev_res, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&l.ev_out, hipEventDisableTiming);
+    }
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ws_event, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->verdict_event, hipEventDisableTiming);
     if (e == hipSuccess) e = hipHostMalloc((void**)&c->verdict, 64, hipHostMallocDefault);
@@ -526,6 +612,11 @@ int gms_ctx_create(int device, gms_ctx** out_ctx)
         t_last_hip = (int)e;
         if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
         if (c->lane[1].stream) (void)hipStreamDestroy(c->lane[1].stream);
+        if (c->lane[2].stream) (void)hipStreamDestroy(c->lane[2].stream);
+        for (Lane& l : c->lane) {
+            if (l.ev_res) (void)hipEventDestroy(l.ev_res);
+            if (l.ev_out) (void)hipEventDestroy(l.ev_out);
+        }
         if (c->ws_event) (void)hipEventDestroy(c->ws_event);
         if (c->verdict_event) (void)hipEventDestroy(c->verdict_event);
         if (c->verdict) (void)hipHostFree(c->verdict);
@@ -549,6 +640,7 @@ int gms_ctx_destroy(gms_ctx* c)
         (void)hipStreamSynchronize(c->stream);
         (void)hipStreamSynchronize(c->own_stream);
         (void)hipStreamSynchronize(c->lane[1].stream);
+        (void)hipStreamSynchronize(c->lane[2].stream);
         if (c->ws_pending) (void)hipEventSynchronize(c->ws_event);
         DevBuf* bufs[] = {&c->aux, &c->big_ws, &c->band_ws, &c->partial_ws, &c->pose_ws, &c->probe_stats, &c->tab_kp, &c->tab_pts, &c->tab_small};
         if (c->verdict) (void)hipHostFree(c->verdict);
@@ -558,8 +650,13 @@ int gms_ctx_destroy(gms_ctx* c)
             l.hout.release();
             l.din.release();
             l.dout.release();
+            (void)hipEventDestroy(l.ev_res);
+            (void)hipEventDestroy(l.ev_out);
         }
+        delete c->pool;
+        c->pool = nullptr;
         (void)hipStreamDestroy(c->lane[1].stream);
+        (void)hipStreamDestroy(c->lane[2].stream);
         (void)hipStreamDestroy(c->own_stream);
         (void)hipEventDestroy(c->ws_event);
         (void)hipEventDestroy(c->verdict_event);
@@ -801,16 +898,18 @@ int gms_filter_host_batch(gms_ctx* c, const gms_keypoint* kp, const int64_t* fra
     GMS_HIP(hipStreamSynchronize(c->stream));
     GMS_HIP(hipStreamSynchronize(c->lane[0].stream));
     GMS_HIP(hipStreamSynchronize(c->lane[1].stream));
+    GMS_HIP(hipStreamSynchronize(c->lane[2].stream));
 
     // ---- chunks: runs of consecutive pairs of at most kChunkMatches matches (a pair larger than that is a chunk of its own)
-    const size_t kChunkMatches = (size_t)2 << 20;  // 32 MB of match records per chunk and direction
+    const size_t kChunkMatches = (size_t)2 << 20;  // 32 MB of match records per chunk
     const int kChunkPairs = 8192;
-    struct Chunk { int first, count; size_t matches; };
+    struct Chunk { int first, count; size_t matches; int max_m; };
     std::vector<Chunk> chunks;
     for (int i = 0; i < n_pairs;) {
-        Chunk ch{i, 0, 0};
+        Chunk ch{i, 0, 0, 0};
         while (i < n_pairs && ch.count < kChunkPairs && (ch.count == 0 || ch.matches + (size_t)pairs[i].m <= kChunkMatches)) {
             ch.matches += (size_t)pairs[i].m;
+            ch.max_m = std::max(ch.max_m, pairs[i].m);
             ++ch.count;
             ++i;
         }
@@ -821,14 +920,17 @@ int gms_filter_host_batch(gms_ctx* c, const gms_keypoint* kp, const int64_t* fra
         cap_m = std::max(cap_m, ch.matches);
         cap_p = std::max(cap_p, (size_t)ch.count);
     }
+    // a lane's blocks, host (pinned) and device alike:   in  [ pairs (24 B each, 16-aligned) | matches (16 B each) ]
+    //                                                    out [ results (16 B each) | survivor total (16 B) | out (16 B each) ]
+    // and, once a chunk is filtered, its survivors packed back to back over the chunk's own match records in the device's in-block
     const size_t in_pairs_bytes = align16(cap_p * sizeof(gms_pair));
-    const size_t in_bytes = in_pairs_bytes + cap_m * sizeof(gms_dmatch);
-    const size_t out_res_bytes = cap_p * sizeof(gms_pair_result);
+    const size_t in_bytes = std::max(in_pairs_bytes + cap_m * sizeof(gms_dmatch), (size_t)total_kp * 8);
+    const size_t out_res_bytes = cap_p * sizeof(gms_pair_result) + 16;
     const size_t out_bytes = out_res_bytes + cap_m * sizeof(gms_dmatch);
     for (Lane& L : c->lane) {
-        GMS_HIP(L.hin.reserve(in_bytes));
+        GMS_HIP(L.hin.reserve(&L == &c->lane[0] ? in_bytes : in_pairs_bytes + cap_m * sizeof(gms_dmatch)));
         GMS_HIP(L.hout.reserve(out_bytes));
-        GMS_HIP(L.din.reserve(in_bytes));
+        GMS_HIP(L.din.reserve(in_pairs_bytes + cap_m * sizeof(gms_dmatch)));
         GMS_HIP(L.dout.reserve(out_bytes));
     }
     {   // the workspaces for the largest chunk, once, so that no launch below has to grow them mid-pipeline
@@ -839,8 +941,12 @@ int gms_filter_host_batch(gms_ctx* c, const gms_keypoint* kp, const int64_t* fra
         w.band = std::max(w.band, w2.band);
         GMS_TRY(grow_workspace(c, w, c->lane[0].stream));
     }
+    if (!c->pool) c->pool = new (std::nothrow) CopyPool;
+    if (!c->pool) return GMS_ERR_BAD_ARG;
+    CopyPool& pool = *c->pool;
+    std::vector<CopyJob> jobs;
 
-    // ---- the frame table: (pt.x, pt.y) of every keypoint through pinned memory in pieces, then normalizePoints on the GPU
+    // ---- the frame table: (pt.x, pt.y) of every keypoint packed into pinned memory by the pool, one transfer, normalizePoints on the GPU
     const size_t small_bytes = align16((size_t)(n_frames + 1) * 8) + (size_t)n_frames * 8;
     GMS_HIP(c->tab_kp.reserve((size_t)total_kp * 8));
     GMS_HIP(c->tab_pts.reserve((size_t)gms_frame_table_bytes(total_kp)));
@@ -850,70 +956,83 @@ int gms_filter_host_batch(gms_ctx* c, const gms_keypoint* kp, const int64_t* fra
         GMS_HIP(hipMemcpyAsync(c->tab_small.p, frame_off, (size_t)(n_frames + 1) * 8, hipMemcpyHostToDevice, st));
         GMS_HIP(hipMemcpyAsync((char*)c->tab_small.p + align16((size_t)(n_frames + 1) * 8), wh, (size_t)n_frames * 8,
                                hipMemcpyHostToDevice, st));
-        GMS_HIP(hipStreamSynchronize(st));  // (frame_off / wh are the caller's pageable memory)
-        const size_t piece = std::min(c->lane[0].hin.cap, c->lane[1].hin.cap) / 8;  // keypoints per piece
-        int k = 0;
-        for (size_t done = 0; done < (size_t)total_kp; done += piece, ++k) {
-            Lane& L = c->lane[k & 1];
-            const size_t n = std::min(piece, (size_t)total_kp - done);
-            GMS_HIP(hipStreamSynchronize(L.stream));  // the piece this buffer carried two rounds ago has left it
-            pack_xy(kp + done, n, (float*)L.hin.p);
-            GMS_HIP(hipMemcpyAsync((char*)c->tab_kp.p + done * 8, L.hin.p, n * 8, hipMemcpyHostToDevice, L.stream));
-        }
-        GMS_HIP(hipStreamSynchronize(c->lane[0].stream));
-        GMS_HIP(hipStreamSynchronize(c->lane[1].stream));
-        if (total_kp)
+        if (total_kp) {
+            jobs.push_back(CopyJob{c->lane[0].hin.p, kp, (size_t)total_kp * 8, 1});
+            pool.run(jobs);
+            jobs.clear();
+            GMS_HIP(hipMemcpyAsync(c->tab_kp.p, c->lane[0].hin.p, (size_t)total_kp * 8, hipMemcpyHostToDevice, st));
             GMS_HIP(gms::launch_normalize(c->tab_kp.p, 8, (const int64_t*)c->tab_small.p,
                                           (const int32_t*)((char*)c->tab_small.p + align16((size_t)(n_frames + 1) * 8)),
                                           n_frames, total_kp, (float*)c->tab_pts.p, st));
-        GMS_HIP(hipStreamSynchronize(st));
+        }
+        GMS_HIP(hipStreamSynchronize(st));  // (frame_off / wh are the caller's pageable memory; lane 0's pinned block is reused below)
     }
     const int64_t* d_foff = (const int64_t*)c->tab_small.p;
 
-    // ---- the pipeline: chunk k rides lane k & 1 (upload -> filter -> download, stream-ordered); the host stages chunk k + 1
-    //      into the other lane's pinned block meanwhile, and hands chunk k - 1's survivors to the caller's arrays
-    //      (the copies out of a lane's pinned block and the copies of the next chunk into it run as one batch of jobs)
-    std::vector<CopyJob> jobs;
-    auto drain = [&](const Chunk& ch, Lane& L) -> int {   // appends the chunk's copy-out jobs
-        GMS_HIP(hipStreamSynchronize(L.stream));
-        const gms_pair_result* res = (const gms_pair_result*)L.hout.p;
-        const gms_dmatch* o = (const gms_dmatch*)((const char*)L.hout.p + out_res_bytes);
-        size_t local = 0;
-        for (int i = 0; i < ch.count; ++i) {
-            const gms_pair& pr = pairs[ch.first + i];
-            results[ch.first + i] = res[i];
-            if (res[i].status == GMS_OK && res[i].n_inliers > 0)
-                jobs.push_back(CopyJob{out + pr.match_off, o + local, (size_t)res[i].n_inliers * sizeof(gms_dmatch)});
-            local += (size_t)pr.m;
-        }
-        return GMS_OK;
-    };
-    for (size_t k = 0; k < chunks.size(); ++k) {
-        const Chunk& ch = chunks[k];
-        Lane& L = c->lane[k & 1];
+    // ---- the pipeline, three chunks deep. Chunk k rides lane k % 3:
+    //        iteration k     the pool copies chunk k into the lane's pinned block (and chunk k - 2's survivors out of its lane's:
+    //                        one batch of jobs), then: upload, filter, pack the survivors back to back on the device
+    //                        (compact_survivors_kernel), download the result records + the survivor total
+    //        iteration k + 1 the records are on the host: download exactly the survivors (K records, not the m slots)
+    //        iteration k + 2 the survivors are on the host: copy them to the caller's array at the pairs' offsets
+    //      so that the copy engines (both directions) and the GPU work on chunks k - 1 and k while the host threads stage k + 1.
+    auto in_matches = [&](Lane& L) { return (gms_dmatch*)((char*)L.din.p + in_pairs_bytes); };
+    const size_t n_chunks = chunks.size();
+    for (size_t k = 0; k < n_chunks + 2; ++k) {
         jobs.clear();
-        if (k >= 2) GMS_TRY(drain(chunks[k - 2], L));
-        gms_pair* hp = (gms_pair*)L.hin.p;
-        gms_dmatch* hm = (gms_dmatch*)((char*)L.hin.p + in_pairs_bytes);
-        size_t local = 0;
-        int chunk_max_m = 0;
-        for (int i = 0; i < ch.count; ++i) {
-            const gms_pair& pr = pairs[ch.first + i];
-            hp[i] = gms_pair{pr.frame_a, pr.frame_b, pr.m, 0, (int64_t)local};
-            if (pr.m) jobs.push_back(CopyJob{hm + local, matches + pr.match_off, (size_t)pr.m * sizeof(gms_dmatch)});
-            local += (size_t)pr.m;
-            chunk_max_m = std::max(chunk_max_m, pr.m);
+        if (k >= 2) {  // chunk k - 2: its survivors are (about to be) in the lane's pinned block
+            const Chunk& ch = chunks[k - 2];
+            Lane& L = c->lane[(k - 2) % 3];
+            GMS_HIP(hipEventSynchronize(L.ev_out));
+            const gms_pair_result* res = (const gms_pair_result*)L.hout.p;
+            const gms_dmatch* o = (const gms_dmatch*)((const char*)L.hout.p + out_res_bytes);
+            std::memcpy(results + ch.first, res, (size_t)ch.count * sizeof(gms_pair_result));
+            size_t at = 0;
+            for (int i = 0; i < ch.count; ++i) {
+                if (res[i].status != GMS_OK || res[i].n_inliers <= 0) continue;
+                jobs.push_back(CopyJob{out + pairs[ch.first + i].match_off, o + at, (size_t)res[i].n_inliers * sizeof(gms_dmatch), 0});
+                at += (size_t)res[i].n_inliers;
+            }
         }
-        run_copy_jobs(jobs);
-        GMS_HIP(hipMemcpyAsync(L.din.p, L.hin.p, in_pairs_bytes + local * sizeof(gms_dmatch), hipMemcpyHostToDevice, L.stream));
-        GMS_TRY(filter_launch(c, L.stream, (const float*)c->tab_pts.p, d_foff, n_frames, (const gms_pair*)L.din.p, ch.count,
-                              chunk_max_m, (const gms_dmatch*)((const char*)L.din.p + in_pairs_bytes), with_rotation, with_scale,
-                              threshold_factor, (gms_dmatch*)((char*)L.dout.p + out_res_bytes), (gms_pair_result*)L.dout.p, nullptr));
-        GMS_HIP(hipMemcpyAsync(L.hout.p, L.dout.p, out_res_bytes + local * sizeof(gms_dmatch), hipMemcpyDeviceToHost, L.stream));
+        if (k < n_chunks) {  // chunk k: pair table rebased to the chunk, match records gathered
+            const Chunk& ch = chunks[k];
+            Lane& L = c->lane[k % 3];
+            gms_pair* hp = (gms_pair*)L.hin.p;
+            gms_dmatch* hm = (gms_dmatch*)((char*)L.hin.p + in_pairs_bytes);
+            size_t local = 0;
+            for (int i = 0; i < ch.count; ++i) {
+                const gms_pair& pr = pairs[ch.first + i];
+                hp[i] = gms_pair{pr.frame_a, pr.frame_b, pr.m, 0, (int64_t)local};
+                if (pr.m) jobs.push_back(CopyJob{hm + local, matches + pr.match_off, (size_t)pr.m * sizeof(gms_dmatch), 0});
+                local += (size_t)pr.m;
+            }
+        }
+        pool.run(jobs);
+        if (k < n_chunks) {
+            const Chunk& ch = chunks[k];
+            Lane& L = c->lane[k % 3];
+            gms_pair_result* d_res = (gms_pair_result*)L.dout.p;
+            int64_t* d_total = (int64_t*)((char*)L.dout.p + out_res_bytes - 16);
+            gms_dmatch* d_out = (gms_dmatch*)((char*)L.dout.p + out_res_bytes);
+            GMS_HIP(hipMemcpyAsync(L.din.p, L.hin.p, in_pairs_bytes + ch.matches * sizeof(gms_dmatch), hipMemcpyHostToDevice, L.stream));
+            GMS_TRY(filter_launch(c, L.stream, (const float*)c->tab_pts.p, d_foff, n_frames, (const gms_pair*)L.din.p, ch.count, ch.max_m,
+                                  in_matches(L), with_rotation, with_scale, threshold_factor, d_out, d_res, nullptr,
+                                  false /* the ranges were validated on the host above; the device check's scratch word is per context, not per lane */));
+            GMS_HIP(gms::launch_compact_survivors((const gms_pair*)L.din.p, d_res, ch.count, d_out, in_matches(L), d_total, L.stream));
+            GMS_HIP(hipMemcpyAsync(L.hout.p, L.dout.p, out_res_bytes, hipMemcpyDeviceToHost, L.stream));
+            GMS_HIP(hipEventRecord(L.ev_res, L.stream));
+        }
+        if (k >= 1 && k - 1 < n_chunks) {  // chunk k - 1: its records are (about to be) on the host; fetch its survivors
+            const Chunk& ch = chunks[k - 1];
+            Lane& L = c->lane[(k - 1) % 3];
+            GMS_HIP(hipEventSynchronize(L.ev_res));
+            const int64_t kept = *(const int64_t*)((const char*)L.hout.p + out_res_bytes - 16);
+            if (kept < 0 || (size_t)kept > ch.matches) return GMS_ERR_HIP;  // (cannot happen: the kernels count what they wrote)
+            if (kept)
+                GMS_HIP(hipMemcpyAsync((char*)L.hout.p + out_res_bytes, in_matches(L), (size_t)kept * sizeof(gms_dmatch), hipMemcpyDeviceToHost, L.stream));
+            GMS_HIP(hipEventRecord(L.ev_out, L.stream));
+        }
     }
-    jobs.clear();
-    for (size_t k = chunks.size() >= 2 ? chunks.size() - 2 : 0; k < chunks.size(); ++k) GMS_TRY(drain(chunks[k], c->lane[k & 1]));
-    run_copy_jobs(jobs);
     return GMS_OK;
 }
 

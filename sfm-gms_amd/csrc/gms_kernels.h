@@ -69,6 +69,9 @@ hipError_t launch_probe_verdict(uint32_t* stats, uint32_t* flag, hipStream_t str
 // pair-table validation: ranges [match_off, match_off + m) must be disjoint; offenders get GMS_ERR_BAD_ARG in d_results (d_flag: a device word)
 hipError_t launch_check_pairs(const gms_pair* d_pairs, int n_pairs, gms_pair_result* d_results, uint32_t* d_flag, hipStream_t stream);
 hipError_t launch_filter_scales(const FilterParams& p, int kpt, int n_pairs, hipStream_t stream);
+// gms_filter_host_batch: pair i's n_inliers survivors (at d_out + match_off) packed back to back into d_packed, the total into *d_total
+hipError_t launch_compact_survivors(const gms_pair* d_pairs, const gms_pair_result* d_results, int n_pairs, const gms_dmatch* d_out,
+                                    gms_dmatch* d_packed, int64_t* d_total, hipStream_t stream);
 // large pairs (gms_kernel_big.hip): code words and table in a per-workgroup HBM slab
 constexpr int kBigMaxMatches = 1 << 22;       // per pair: 4 194 304 (a 2594 x 1131 one-keypoint-per-pixel frame of DisparityUtil.cpp:299 has 2.93 M)
 constexpr int kBigLdsMaskMatches = 262144;   // up to here the slab kernel keeps the winner's bit mask in LDS

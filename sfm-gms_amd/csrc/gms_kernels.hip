@@ -2619,6 +2619,40 @@ hipError_t launch_check_pairs(const gms_pair* d_pairs, int n_pairs, gms_pair_res
     return hipGetLastError();
 }
 
+// ---- gms_filter_host_batch: the survivors of a chunk packed back to back (what travels to the host is K records, not m slots).
+// One workgroup per pair: its offset is the sum of the pairs' counts in front of it (a chunk has at most 8192 pairs: every
+// workgroup adds them up itself), its K records are copied 16 bytes per lane; the last workgroup leaves the chunk's total.
+__global__ void __launch_bounds__(256)
+compact_survivors_kernel(const gms_pair* __restrict__ pairs, const gms_pair_result* __restrict__ results, int n_pairs,
+                         const gms_dmatch* __restrict__ out, gms_dmatch* __restrict__ packed, int64_t* __restrict__ total)
+{
+    __shared__ unsigned long long s_part[4];
+    const int i = (int)blockIdx.x, tid = (int)threadIdx.x;
+    unsigned long long sum = 0;
+    for (int j = tid; j < i; j += 256) {
+        const gms_pair_result r = results[j];
+        sum += (r.status == GMS_OK && r.n_inliers > 0) ? (unsigned long long)r.n_inliers : 0ull;
+    }
+    for (int d = 32; d > 0; d >>= 1) sum += __shfl_down(sum, d);
+    if ((tid & 63) == 0) s_part[tid >> 6] = sum;
+    __syncthreads();
+    const unsigned long long off = s_part[0] + s_part[1] + s_part[2] + s_part[3];
+    const gms_pair_result r = results[i];
+    const int k = (r.status == GMS_OK && r.n_inliers > 0) ? r.n_inliers : 0;
+    const uint4* __restrict__ src = reinterpret_cast<const uint4*>(out + pairs[i].match_off);
+    uint4* __restrict__ dst = reinterpret_cast<uint4*>(packed + off);
+    for (int j = tid; j < k; j += 256) dst[j] = src[j];
+    if (i == n_pairs - 1 && tid == 0) *total = (int64_t)(off + (unsigned long long)k);
+}
+
+hipError_t launch_compact_survivors(const gms_pair* d_pairs, const gms_pair_result* d_results, int n_pairs, const gms_dmatch* d_out,
+                                    gms_dmatch* d_packed, int64_t* d_total, hipStream_t stream)
+{
+    if (n_pairs <= 0) return hipSuccess;
+    hipLaunchKernelGGL(compact_survivors_kernel, dim3((unsigned)n_pairs), dim3(256), 0, stream, d_pairs, d_results, n_pairs, d_out, d_packed, d_total);
+    return hipGetLastError();
+}
+
 // Scale probes of the launches so far: [0] probed and evaluated anyway, [1] probed and skipped. A probe costs about 45 % of a
 // scale and saves the rest when it lets the scale skip: it pays from a skip rate of one half.
 __global__ void probe_verdict_kernel(uint32_t* stats, uint32_t* flag)
