@@ -158,10 +158,13 @@ int gms_normalize_device(gms_ctx* ctx, const gms_keypoint* d_kp, const int64_t* 
  *   d_pairs            n_pairs descriptors; max_m >= every d_pairs[i].m (host-known upper bound)
  *   d_matches          putative matches, pair i at [match_off, match_off+m). The ranges of a batch's pairs must be DISJOINT
  *                      (empty pairs aside): pair i's survivors are written over the head of the same range of d_out, so
- *                      overlapping ranges would make pairs overwrite each other. Validated on the device behind the first launch
- *                      of a context and every sixteenth (every launch with GMS_CHECK_PAIRS=1): every pair whose range
- *                      overlaps another's gets status GMS_ERR_BAD_ARG in d_results (gms_filter_host_batch validates every call
- *                      on the host and returns GMS_ERR_BAD_ARG).
+ *                      overlapping ranges would make pairs overwrite each other. Validated on the device BEHIND the first launch
+ *                      of a context and every sixteenth (every launch with GMS_CHECK_PAIRS=1; never inside a stream capture or a
+ *                      graph replay): every pair whose range overlaps another's gets status GMS_ERR_BAD_ARG in d_results. The check
+ *                      reports, it does not prevent: d_out of the flagged pairs AND of whatever their ranges touch has already been
+ *                      written by then and is invalid, and a launch that is not checked returns GMS_OK on such a table. A caller
+ *                      that cannot vouch for its table validates it once itself (gms_filter_host_batch does: every call, on the
+ *                      host, GMS_ERR_BAD_ARG before anything is launched).
  *   d_out              same offsets/capacity; pair i's survivors are written at d_out[match_off ...]
  *   d_results          n_pairs result records
  *   d_mask             optional (may be NULL): per-match inlier byte (0/1) at the match's offset */

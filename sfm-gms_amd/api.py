@@ -205,7 +205,8 @@ class GmsContext:
 
     def find_essential_batch_device(self, camera, d_pairs, n_pairs, d_coords1, d_coords2, d_mask, d_tv, prob=0.999, threshold=1.0,
                                     max_iters=1000):
-        """cv::findEssentialMat(..., RANSAC, prob, threshold, mask) per pair; camera: a CAMERA_DTYPE record (types.make_camera)."""
+        """cv::findEssentialMat(..., RANSAC, prob, threshold, mask) per pair; camera: a CAMERA_DTYPE record (types.make_camera).
+        The defaults are OpenCV's (0.999, 1.0); the reference's call, SfMUtil.cpp:39, passes 0.7 -- pipeline.run_dataset defaults to that."""
         _check(self._lib.gms_find_essential_batch_device(self._h, camera.ctypes.data, float(prob), float(threshold), int(max_iters),
                                                          d_pairs, int(n_pairs), d_coords1, d_coords2, d_mask, d_tv),
                self._lib, "gms_find_essential_batch_device")
@@ -220,7 +221,8 @@ class GmsContext:
 
     def two_view_batch_device(self, camera, d_kp, d_frame_off, n_frames, d_pairs, n_pairs, max_m, d_filtered, d_results, d_coords1,
                               d_coords2, d_mask, d_points3d, d_tv, prob=0.999, threshold=1.0, max_iters=1000):
-        """SfMUtil.cpp:25-82 for every pair of the batch: gather -> findEssentialMat -> recoverPose -> undistort + triangulate."""
+        """SfMUtil.cpp:25-82 for every pair of the batch: gather -> findEssentialMat -> recoverPose -> undistort + triangulate.
+        prob defaults to OpenCV's 0.999; the reference passes 0.7 (SfMUtil.cpp:39): pass prob=0.7 to restate its flow."""
         _check(self._lib.gms_two_view_batch_device(self._h, camera.ctypes.data, float(prob), float(threshold), int(max_iters), d_kp,
                                                    d_frame_off, int(n_frames), d_pairs, int(n_pairs), int(max_m), d_filtered, d_results,
                                                    d_coords1, d_coords2, d_mask, d_points3d, d_tv), self._lib, "gms_two_view_batch_device")

@@ -176,8 +176,10 @@ struct gms_ctx {
     // verdict[1] "probing scale hypotheses pays" (probe_verdict_kernel, below)
     uint32_t* verdict = nullptr;
     unsigned dense_launches = 0;
-    // The host never reads a pinned word that a kernel may be writing: a verdict kernel is followed by an event, and the first
-    // launch (or gms_ctx_synchronize) that finds the event complete ADOPTS the words; launches run on the adopted values in between.
+    // verdict[0] and verdict[1] are never read while a kernel may be writing them: a verdict kernel is followed by an event, and the
+    // first launch (or gms_ctx_synchronize) that finds the event complete ADOPTS the words; launches run on the adopted values in
+    // between. verdict[2] (below) is different: a counter the streamed kernels add to, read without waiting -- it only steers which of
+    // two bit-identical paths the next launches of large pairs take (and with it which workspace such a launch asks for).
     // last_* = what the most recent launch ran with (gms_ctx_query).
     int use_dealt = 0, use_probe = 1, last_dealt = 0, last_probe = 0, last_kpt = 0, last_stagger_ticks = 0;
     hipEvent_t verdict_event = nullptr;
@@ -411,7 +413,7 @@ int filter_launch(gms_ctx* c, hipStream_t st, const float* d_pts, const int64_t*
     // pair-table validation (ranges [match_off, match_off + m) must be disjoint: include/gms.h), behind the filter: offenders'
     // status becomes GMS_ERR_BAD_ARG. The first launch of a context and every sixteenth; never inside a stream capture.
     if (validate_pairs && n_pairs > 1 && !capturing && knobs().check_pairs != 0 && (knobs().check_pairs == 1 || (c->filter_launches & 15u) == 0u))
-        GMS_HIP(gms::launch_check_pairs(d_pairs, n_pairs, d_results, (uint32_t*)c->probe_stats.p + 8, st));
+        GMS_HIP(gms::launch_check_pairs(d_pairs, n_pairs, d_results, (uint32_t*)c->probe_stats.p + 8 + (c->filter_launches & 7u), st));  // (a flag word of its own per launch: launches of one context may run on different streams)
     if (!capturing) ++c->filter_launches;
     if (uses_ws && !capturing) {
         GMS_HIP(hipEventRecord(c->ws_event, st));

@@ -227,7 +227,18 @@ __device__ __forceinline__ void stream_scale(const FilterParams& p, const Stream
     const gms_pair pr = p.pairs[pi];
     const int m = pr.m;
     if (m <= 0 || m > mcap) return;
-    if (w.flags[pi] & (kSFlagDomain | kSFlagGeneral)) return;  // written by the index kernels
+    // One decision for the whole workgroup: the index kernels write this word before the launch, but the pair's OTHER workgroups of this
+    // launch may OR kSFlagGeneral into it at any time (below) -- waves reading it one by one could disagree and a part of the workgroup
+    // would run the barriers alone. One thread reads it into the workgroup's scratch word [15], everybody takes that value.
+    {
+        uint32_t* flag_word = smem + kSMiscOff / 4 + 15;
+        __syncthreads();  // (the previous item of this workgroup is done with its scratch words)
+        if (tid == 0) *flag_word = __hip_atomic_load(&w.flags[pi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        const uint32_t flag = *flag_word;
+        __syncthreads();  // (the words are zeroed below)
+        if (flag & (kSFlagDomain | kSFlagGeneral)) return;
+    }
     const uint2* __restrict__ ents = w.entries + (size_t)pi * mcap;
     // the byte array of this (scale, grid type): a match is marked by the one band that owns its left row, so a byte has one writer
     uint8_t* rb = w.rotbits + (((size_t)pi * n_scales + (n_scales == 5 ? S : 0)) * 4 + (size_t)g) * mcap;

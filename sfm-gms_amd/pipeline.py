@@ -12,9 +12,11 @@ from .batch import DescriptorTable, FrameTable, _to_dev
 from .types import DMATCH_DTYPE, PAIR_DTYPE, RESULT_DTYPE, TWO_VIEW_DTYPE, make_camera
 
 
-def run_dataset(ctx, ds, withRotation=False, withScale=False, thresholdFactor=6.0, match=None, camera=None, dist=None, prob=0.999,
+def run_dataset(ctx, ds, withRotation=False, withScale=False, thresholdFactor=6.0, match=None, camera=None, dist=None, prob=0.7,
                 ransac_threshold=1.0, max_iters=1000, device="cuda:0"):
-    """ds: io.Dataset. match=None: brute-force match when the file carries descriptors and no matches. camera = (fx, fy, cx, cy)
+    """(prob, ransac_threshold: findEssentialMat's confidence and threshold as the flow this function restates passes them -- SfMUtil.cpp:39:
+    RANSAC, 0.7, 1.0 -- not OpenCV's own default of 0.999, which gms_find_essential_batch_device's Python mirror keeps.)
+    ds: io.Dataset. match=None: brute-force match when the file carries descriptors and no matches. camera = (fx, fy, cx, cy)
     switches the two-view stage on. Returns a dict of host arrays: pairs, matches (the putative ones), out, results, and with a camera
     two_view (TWO_VIEW_DTYPE per pair), coords1, coords2, mask, points3d -- all per-match arrays laid out by match_off."""
     frames = FrameTable(ctx, ds.frames, ds.sizes, device=device)
