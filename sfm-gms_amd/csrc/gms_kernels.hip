@@ -306,7 +306,7 @@ __device__ __forceinline__ void hash_pair(const FilterParams& p, uint32_t* smem,
     // with scale hypotheses the byte-matrix kernel may have evaluated scales 0..2 already (see dense_scales_pair): its
     // record holds the best hypothesis so far, and this kernel continues with scale 3
     const uint32_t* __restrict__ part = p.partial ? p.partial + (size_t)pair_idx * kPartialStrideDw : nullptr;
-    const uint32_t part0 = part != nullptr ? part[0] : 0u;       // workgroup-uniform: 0, or what the first kernel decided:
+    const uint32_t part0 = part != nullptr ? (uint32_t)uniform((int)part[0]) : 0u;  // workgroup-uniform: 0, or what the first kernel decided:
     const int scales_done = (int)(part0 & 15u);                  //   scales 0..3 (4) or all five (5: its probe bounded scale 4 out)
     const bool probed4 = (part0 >> 4) != 0;                      //   "scale 4 was probed and cannot be bounded out"
     const bool resumed = scales_done != 0;
@@ -320,19 +320,19 @@ __device__ __forceinline__ void hash_pair(const FilterParams& p, uint32_t* smem,
                           pr.frame_b < 0 || pr.frame_b >= p.n_frames;
     int64_t offA = 0, offB = 0;
     int nA = 0, nB = 0;
-    if (!bad_pair) {
-        offA = p.frame_off[pr.frame_a];
-        offB = p.frame_off[pr.frame_b];
-        nA = (int)(p.frame_off[pr.frame_a + 1] - offA);
-        nB = (int)(p.frame_off[pr.frame_b + 1] - offB);
+    if (!bad_pair) {  // (pair-uniform values into scalar registers: see uniform())
+        offA = uniform(p.frame_off[pr.frame_a]);
+        offB = uniform(p.frame_off[pr.frame_b]);
+        nA = (int)(uniform(p.frame_off[pr.frame_a + 1]) - offA);
+        nB = (int)(uniform(p.frame_off[pr.frame_b + 1]) - offB);
     }
     const float2* __restrict__ ptsA = p.pts + offA;
     const float2* __restrict__ ptsB = p.pts + offB;
     const int mm = bad_pair ? 0 : m;
     const int n_scales = p.with_scale ? 5 : 1;
     const bool thr_fast = threshold_fast_ok(p.threshold_factor);
-    uint32_t best_count = resumed ? part[1] : 0u;
-    int best_scale = resumed ? (int)part[2] : -1, best_rot = resumed ? (int)part[3] : -1;
+    uint32_t best_count = resumed ? (uint32_t)uniform((int)part[1]) : 0u;
+    int best_scale = resumed ? uniform((int)part[2]) : -1, best_rot = resumed ? uniform((int)part[3]) : -1;
     GMS_STAMP_DECL
     if (mm == 0 || nA <= 0 || nB <= 0) {  // workgroup-uniform: nothing to filter (or nothing valid to index)
         if (tid == 0) {
@@ -353,62 +353,70 @@ __device__ __forceinline__ void hash_pair(const FilterParams& p, uint32_t* smem,
     //      together); validity is applied to the values afterwards.
     uint32_t code[KPT];
     {
-        int2 qt[KPT];
-#pragma unroll
-        for (int k = 0; k < KPT; ++k) {
-            const int i = min(k * NT + tid, mm - 1);
-            qt[k] = *reinterpret_cast<const int2*>(&matches[i]);
-        }
+        // KPT <= 10: all of a thread's loads in flight together. KPT = 16: in two halves -- sixteen (queryIdx, trainIdx) pairs and
+        // sixteen points of either frame at once are 96 registers and spilled (200 bytes of scratch per lane).
+        constexpr int kLoad = KPT > 10 ? KPT / 2 : KPT;
         // The train-side gather is 8 bytes from a random line per match: the vector memory pipe takes it one
         // line at a time. When frame B's normalised points fit the (still unused) table area, copy them into LDS
         // with coalesced loads while the match loads are in flight, and gather from LDS instead.
         const bool stage_b = (uint32_t)nB * 2u <= T && nB <= 4 * mm;  // workgroup-uniform
         float2* lds_b = reinterpret_cast<float2*>(tab);
-        if (stage_b) {
-            for (int j = tid; j < nB; j += NT) lds_b[j] = ptsB[j];
-            __syncthreads();
-        }
-#ifdef GMS_PHASE_TIMING
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        GMS_STAMP(4);  // bin: (queryIdx, trainIdx) loads landed, frame B staged
-#endif
-        float2 a[KPT], b[KPT];
-#pragma unroll
-        for (int k = 0; k < KPT; ++k) a[k] = ptsA[min((uint32_t)qt[k].x, (uint32_t)(nA - 1))];
-        if (stage_b) {
-#pragma unroll
-            for (int k = 0; k < KPT; ++k) b[k] = lds_b[min((uint32_t)qt[k].y, (uint32_t)(nB - 1))];
-        } else {
-#pragma unroll
-            for (int k = 0; k < KPT; ++k) b[k] = ptsB[min((uint32_t)qt[k].y, (uint32_t)(nB - 1))];
-        }
-#ifdef GMS_PHASE_TIMING
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        GMS_STAMP(12);  // bin: gathers landed
-#endif
         const int wr = p.right_w[0];
         const uint32_t nr = (uint32_t)(wr * p.right_h[0]);
         const float fwr = (float)wr, fhr = (float)p.right_h[0];
         bool any_bad = false;
 #pragma unroll
-        for (int k = 0; k < KPT; ++k) {
-            const bool live = k * NT + tid < mm;
-            // parity domain: indices in range; coordinates finite, non-negative, < 2^20 -- one unsigned
-            // compare on the bit patterns (negative, NaN and Inf patterns are all above 0x49800000 = 2^20;
-            // -0.0 was canonicalised away by normalize_kernel)
-            const uint32_t worst = max(max(__float_as_uint(a[k].x), __float_as_uint(a[k].y)),
-                                       max(__float_as_uint(b[k].x), __float_as_uint(b[k].y)));
-            const float fx = 20.0f * a[k].x, fy = 20.0f * a[k].y;   // mulss, rounded to fp32
-            // floor == truncation for non-negative values; 2f is exact
-            const uint32_t hx = (uint32_t)(int)(fx + fx), hy = (uint32_t)(int)(fy + fy);
-            const uint32_t r = (uint32_t)((int)(fwr * b[k].x) + (int)(fhr * b[k].y) * wr);  // no bounds test in the reference
-            const bool ok = (uint32_t)qt[k].x < (uint32_t)nA && (uint32_t)qt[k].y < (uint32_t)nB &&
-                            worst < 0x49800000u && r < nr;
-            // hx >= 40 or hy >= 40: x >= 20 or y >= 20 under every grid type, never binned
-            const uint32_t f = (live && ok && hx < 40u && hy < 40u) ? hy * kFineW + hx : kFineInvalid;
-            if (f != kFineInvalid) atomicAdd(&nfine[f], 1u);
-            any_bad |= live && !ok;
-            code[k] = ((live && ok) ? r : 0u) | (f << kFShift);
+        for (int k0 = 0; k0 < KPT; k0 += kLoad) {
+            int2 qt[kLoad];
+#pragma unroll
+            for (int k = 0; k < kLoad; ++k) {
+                const int i = min((k0 + k) * NT + tid, mm - 1);
+                qt[k] = *reinterpret_cast<const int2*>(&matches[i]);
+            }
+            if (k0 == 0 && stage_b) {
+                for (int j = tid; j < nB; j += NT) lds_b[j] = ptsB[j];
+                __syncthreads();
+            }
+#ifdef GMS_PHASE_TIMING
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            GMS_STAMP(4);  // bin: (queryIdx, trainIdx) loads landed, frame B staged
+#endif
+            float2 a[kLoad], b[kLoad];
+#pragma unroll
+            for (int k = 0; k < kLoad; ++k) a[k] = ptsA[min((uint32_t)qt[k].x, (uint32_t)(nA - 1))];
+            if (stage_b) {
+#pragma unroll
+                for (int k = 0; k < kLoad; ++k) b[k] = lds_b[min((uint32_t)qt[k].y, (uint32_t)(nB - 1))];
+            } else {
+#pragma unroll
+                for (int k = 0; k < kLoad; ++k) b[k] = ptsB[min((uint32_t)qt[k].y, (uint32_t)(nB - 1))];
+            }
+#ifdef GMS_PHASE_TIMING
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            GMS_STAMP(12);  // bin: gathers landed
+#endif
+#pragma unroll
+            for (int k = 0; k < kLoad; ++k) {
+                const bool live = (k0 + k) * NT + tid < mm;
+                // parity domain: indices in range; coordinates finite, non-negative, < 2^20 -- one unsigned
+                // compare on the bit patterns (negative, NaN and Inf patterns are all above 0x49800000 = 2^20;
+                // -0.0 was canonicalised away by normalize_kernel)
+                const uint32_t worst = max(max(__float_as_uint(a[k].x), __float_as_uint(a[k].y)),
+                                           max(__float_as_uint(b[k].x), __float_as_uint(b[k].y)));
+                const float fx = 20.0f * a[k].x, fy = 20.0f * a[k].y;   // mulss, rounded to fp32
+                // floor == truncation for non-negative values; 2f is exact
+                const uint32_t hx = (uint32_t)(int)(fx + fx), hy = (uint32_t)(int)(fy + fy);
+                // no bounds test in the reference: r = x + y * wr whatever x and y are. (Clamped to 16 bits so that the product fits the
+                // 24-bit multiplier -- unclamped the compiler builds a 64-bit multiply-add; a clamped value is far beyond the grid anyway.)
+                const uint32_t r = __umul24(min((uint32_t)(int)(fhr * b[k].y), 0xFFFFu), (uint32_t)wr) + min((uint32_t)(int)(fwr * b[k].x), 0xFFFFu);
+                const bool ok = (uint32_t)qt[k].x < (uint32_t)nA && (uint32_t)qt[k].y < (uint32_t)nB &&
+                                worst < 0x49800000u && r < nr;
+                // hx >= 40 or hy >= 40: x >= 20 or y >= 20 under every grid type, never binned
+                const uint32_t f = (live && ok && hx < 40u && hy < 40u) ? hy * kFineW + hx : kFineInvalid;
+                if (f != kFineInvalid) atomicAdd(&nfine[f], 1u);
+                any_bad |= live && !ok;
+                code[k0 + k] = ((live && ok) ? r : 0u) | (f << kFShift);
+            }
         }
         if (any_bad) misc[8] = 1;  // benign race: every writer stores 1
     }
@@ -466,21 +474,25 @@ __device__ __forceinline__ void hash_pair(const FilterParams& p, uint32_t* smem,
             // ---- getGridIndexRight again for this scale's right grid ------------------------------------------
             const uint32_t nr = (uint32_t)(wr * hr);
             const float fwr = (float)wr, fhr = (float)hr;
-            int t[KPT];
-#pragma unroll
-            for (int k = 0; k < KPT; ++k) t[k] = matches[min(k * NT + tid, mm - 1)].trainIdx;
-            float2 b[KPT];
-#pragma unroll
-            for (int k = 0; k < KPT; ++k) b[k] = ptsB[min((uint32_t)t[k], (uint32_t)(nB - 1))];
+            constexpr int kLoad = KPT > 10 ? KPT / 2 : KPT;  // (KPT = 16: in two halves, see above)
             bool any_bad = false;
 #pragma unroll
-            for (int k = 0; k < KPT; ++k) {
-                const uint32_t fpart = code[k] & (kFMask << kFShift);
-                const bool had = fpart != (kFineInvalid << kFShift);  // valid at scale 0 (so indices and points are fine)
-                const uint32_t r = (uint32_t)((int)(fwr * b[k].x) + (int)(fhr * b[k].y) * wr);
-                const bool ok = r < nr;
-                any_bad |= had && !ok;
-                code[k] = (had && ok) ? (fpart | r) : (kFineInvalid << kFShift);
+            for (int k0 = 0; k0 < KPT; k0 += kLoad) {
+                int t[kLoad];
+#pragma unroll
+                for (int k = 0; k < kLoad; ++k) t[k] = matches[min((k0 + k) * NT + tid, mm - 1)].trainIdx;
+                float2 b[kLoad];
+#pragma unroll
+                for (int k = 0; k < kLoad; ++k) b[k] = ptsB[min((uint32_t)t[k], (uint32_t)(nB - 1))];
+#pragma unroll
+                for (int k = 0; k < kLoad; ++k) {
+                    const uint32_t fpart = code[k0 + k] & (kFMask << kFShift);
+                    const bool had = fpart != (kFineInvalid << kFShift);  // valid at scale 0 (so indices and points are fine)
+                    const uint32_t r = __umul24(min((uint32_t)(int)(fhr * b[k].y), 0xFFFFu), (uint32_t)wr) + min((uint32_t)(int)(fwr * b[k].x), 0xFFFFu);
+                    const bool ok = r < nr;
+                    any_bad |= had && !ok;
+                    code[k0 + k] = (had && ok) ? (fpart | r) : (kFineInvalid << kFShift);
+                }
             }
             if (any_bad) misc[8] = 1;
         }
@@ -513,9 +525,6 @@ __device__ __forceinline__ void hash_pair(const FilterParams& p, uint32_t* smem,
             //      LDS, is what divergent exec-mask handling would saturate here).
             {
                 uint32_t pending = 0;
-                uint32_t d[KPT];   // region of the match's left cell under this grid type, 0 = not binned
-#pragma unroll
-                for (int k = 0; k < KPT; ++k) d[k] = fdesc[(code[k] >> kFShift) & kFMask];
                 const uint32_t trash_add = (uint32_t)((trash - tab) + lane) << 2;        // never equals kEmpty
                 const uint32_t trash_min = (uint32_t)((trash - tab) + 64 + lane) << 2;
                 const uint32_t trash_bkt = (uint32_t)((trash - tab) + 128) << 2;          // one all-empty bucket
@@ -523,10 +532,13 @@ __device__ __forceinline__ void hash_pair(const FilterParams& p, uint32_t* smem,
                 for (int k0 = 0; k0 < KPT; k0 += kChunk) {
                     uint32_t slot[kChunk];  // byte offset of the hashed bucket, then of the match's slot
                     uint4 v[kChunk];
+                    uint32_t d[kChunk];     // region of the match's left cell under this grid type, 0 = not binned
+#pragma unroll
+                    for (int c = 0; c < kChunk; ++c) d[c] = fdesc[(code[k0 + c] >> kFShift) & kFMask];
 #pragma unroll
                     for (int c = 0; c < kChunk; ++c) {
-                        const uint32_t nb = d[k0 + c] & 0xFFFFu;
-                        const uint32_t bo = ((d[k0 + c] >> 16) + 1u + bucket_of(code[k0 + c] & kRMask, nb)) << 4;
+                        const uint32_t nb = d[c] & 0xFFFFu;
+                        const uint32_t bo = ((d[c] >> 16) + 1u + bucket_of(code[k0 + c] & kRMask, nb)) << 4;
                         slot[c] = nb ? bo : trash_bkt;
                         v[c] = *reinterpret_cast<const uint4*>(lds_at(tab, slot[c]));
                     }
@@ -568,8 +580,8 @@ __device__ __forceinline__ void hash_pair(const FilterParams& p, uint32_t* smem,
                         const uint32_t count = fnd[c] ? (o_add[c] & kSlotCountMask) + 1u
                                                       : (won[c] ? 1u : (o_again[c] & kSlotCountMask) + 1u);
                         const uint32_t key = ~((count << 11) | (2047u - (code[k0 + c] & kRMask)));
-                        const uint32_t hdr = (d[k0 + c] >> 16) << 4;
-                        atomicMin(lds_at(tab, (pend[c] || (d[k0 + c] & 0xFFFFu) == 0) ? trash_min : hdr), key);
+                        const uint32_t hdr = (d[c] >> 16) << 4;
+                        atomicMin(lds_at(tab, (pend[c] || (d[c] & 0xFFFFu) == 0) ? trash_min : hdr), key);
                         pending |= pend[c] ? (1u << (k0 + c)) : 0u;
                     }
                 }
