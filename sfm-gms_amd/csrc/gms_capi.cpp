@@ -332,7 +332,8 @@ int filter_launch(gms_ctx* c, hipStream_t st, const float* d_pts, const int64_t*
         c->verdict_pending = false;
     }
     const int force_deal = c->opt_deal >= 0 ? c->opt_deal : knobs().deal, force_probe = c->opt_probe >= 0 ? c->opt_probe : knobs().scale_probe;
-    p.dealt = (p.dense && kpt && (force_deal >= 0 ? force_deal != 0 : c->use_dealt != 0)) ? 1 : 0;
+    const bool scales_matrix = kpt && with_scale && knobs().dense_on;  // (the byte-matrix kernel of the scale hypotheses deals too)
+    p.dealt = ((p.dense || scales_matrix) && kpt && (force_deal >= 0 ? force_deal != 0 : c->use_dealt != 0)) ? 1 : 0;
     // First-round stagger: the spread is about two thirds of a pair's duration on the path the launch will mostly take -- 16 us (byte
     // matrix) / 72 us (hashed) at 10k matches, in proportion to max_m -- in ticks of the 100 MHz wall clock. Only launches of
     // at least four dispatch rounds are staggered, and none with scale hypotheses on the byte matrix: a pair takes ten times as
@@ -363,6 +364,13 @@ int filter_launch(gms_ctx* c, hipStream_t st, const float* d_pts, const int64_t*
         // scale hypotheses: scales 0..3 on the byte matrix, the last on the hashed path (two launches, one record per pair)
         p.partial = (uint32_t*)c->partial_ws.p;
         GMS_HIP(gms::launch_filter_scales(p, kpt, n_pairs, st));
+        if (!capturing && p.probe_stats == nullptr && (c->dense_launches++ & 15u) == 0u) {  // the spatial-order probe of this batch, for later launches (one verdict event: not beside a measuring launch)
+            void* dflag = nullptr;
+            GMS_HIP(hipHostGetDevicePointer(&dflag, c->verdict, 0));
+            GMS_HIP(gms::launch_order_probe(p, (uint32_t*)dflag, st));
+            GMS_HIP(hipEventRecord(c->verdict_event, st));
+            c->verdict_pending = true;
+        }
         if (p.probe_stats != nullptr) {
             void* dflag = nullptr;
             GMS_HIP(hipHostGetDevicePointer(&dflag, c->verdict, 0));

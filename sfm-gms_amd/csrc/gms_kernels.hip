@@ -1985,6 +1985,14 @@ __device__ __forceinline__ bool dense_scales_pair(const FilterParams& p, uint32_
     static_assert(KPT % kChunk == 0, "KPT must be a multiple of the chunk");
     const int lane = tid & 63;
     const int wave = tid >> 6;
+    // Lane mapping (see dense_pair): in list order a wave instruction holds 64 consecutive matches; DEALT (a run-time choice here: it
+    // only moves the loads and the record's bits) gives the wave's eight 8-lane groups eight consecutive matches each from places
+    // KPT * 128 matches apart -- a detector that emits keypoints row by row puts consecutive matches into the same cells, and 64 of
+    // them in one LDS atomic instruction serialise on a handful of entries.
+    const bool dealt = p.dealt != 0;
+    const int m_base = dealt ? ((((lane >> 3) * (KPT * (NT / 64)) + wave) << 3) | (lane & 7)) : tid;
+    const int m_stride = dealt ? (NT / 64) * 8 : NT;
+    auto match_of = [&](int k) -> int { return m_base + k * m_stride; };
 
     const gms_pair pr = uniform(p.pairs[pair_idx]);
     const int m = pr.m;
@@ -2035,7 +2043,7 @@ __device__ __forceinline__ bool dense_scales_pair(const FilterParams& p, uint32_
     }
     uint2 qt[KPT];
 #pragma unroll
-    for (int k = 0; k < KPT; ++k) qt[k] = *reinterpret_cast<const uint2*>(&matches[min(k * NT + tid, m - 1)]);
+    for (int k = 0; k < KPT; ++k) qt[k] = *reinterpret_cast<const uint2*>(&matches[min(match_of(k), m - 1)]);
     const uint32_t staged16 = staged ? qA + qB : 0u;
     {
         const uint4 z4 = make_uint4(0, 0, 0, 0);
@@ -2074,7 +2082,7 @@ __device__ __forceinline__ bool dense_scales_pair(const FilterParams& p, uint32_
         bool any_bad = false, spill = false;
 #pragma unroll
         for (int k = 0; k < KPT; ++k) {
-            const bool live = k * NT + tid < m;
+            const bool live = match_of(k) < m;
             const uint32_t cell = ca[k] >> kLCellShift;  // under grid type 1; kLCellNever / kLCellBad above the grid
             const bool ok = ((int)(qt[k].x < (uint32_t)nA) & (int)(qt[k].y < (uint32_t)nB) & (int)(cell != kLCellBad) & (int)((cb[k] & kSCodeBad) == 0u)) != 0;
             const bool binned = live & ok & (cell < kLCellNever);
@@ -2496,13 +2504,29 @@ __device__ __forceinline__ bool dense_scales_pair(const FilterParams& p, uint32_
         part[2] = (uint32_t)best_scale;
         part[3] = (uint32_t)best_rot;
     }
+    // the inlier bit of every match, as a bit mask over the list (bit i & 31 of dword i >> 5). List order: slot k of a wave is one chunk of
+    // 64 consecutive matches = one ballot. Dealt: an 8-lane group holds eight consecutive matches = one byte of the mask.
+    if (dealt) {
+        uint8_t* mask8 = reinterpret_cast<uint8_t*>(part + kPartialHeaderDw);
+        // (the lane's first match worked out again from a thread index the compiler cannot connect with the one above: kept alive
+        //  from the loads to here, it would cost a register through every scale)
+        int t2 = (int)threadIdx.x;
+        asm volatile("" : "+v"(t2));
+        const int l2 = t2 & 63, base2 = (((l2 >> 3) * (KPT * (NT / 64)) + (t2 >> 6)) << 3) | (l2 & 7);
 #pragma unroll
-    for (int k = 0; k < KPT; ++k) {  // the inlier bit of match k * NT + tid: chunk of 64 consecutive matches = one ballot
-        const unsigned long long bsel = __ballot((bestbits >> k) & 1u);
-        if (lane == 0) {
-            const int ch = k * (NT / 64) + wave;
-            part[kPartialHeaderDw + 2 * ch] = (uint32_t)bsel;
-            part[kPartialHeaderDw + 2 * ch + 1] = (uint32_t)(bsel >> 32);
+        for (int k = 0; k < KPT; ++k) {
+            const unsigned long long bsel = __ballot((bestbits >> k) & 1u);
+            if ((l2 & 7) == 0) mask8[(base2 + k * (NT / 64) * 8) >> 3] = (uint8_t)(bsel >> l2);
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < KPT; ++k) {
+            const unsigned long long bsel = __ballot((bestbits >> k) & 1u);
+            if (lane == 0) {
+                const int ch = k * (NT / 64) + wave;
+                part[kPartialHeaderDw + 2 * ch] = (uint32_t)bsel;
+                part[kPartialHeaderDw + 2 * ch + 1] = (uint32_t)(bsel >> 32);
+            }
         }
     }
     GMS_STAMP_OUT(9, 11);  // record written
