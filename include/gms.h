@@ -114,7 +114,7 @@ int  gms_ctx_reserve(gms_ctx* ctx, int n_pairs, int max_m, int with_rotation, in
  * library picks between bit-identical kernel variants from what earlier launches of the context saw: a probe kernel behind
  * every sixteenth launch writes a verdict, and the first later launch that finds that kernel complete adopts it. */
 #define GMS_QUERY_LAST_DEALT        1 /* 1: the byte-matrix kernel dealt the matches to its lanes (inputs in spatial order) */
-#define GMS_QUERY_LAST_SCALE_PROBE  2 /* bit s set: scale hypothesis s was bounded by a probe before being evaluated       */
+#define GMS_QUERY_LAST_SCALE_PROBE  2 /* bit s set: scale hypothesis s was bounded by a probe before being evaluated; bit 8 + s: with four-bit entries first */
 #define GMS_QUERY_LAST_KPT          3 /* matches per thread of the workgroup kernel (0: the large-pair kernels ran)        */
 #define GMS_QUERY_LAUNCHES          4 /* filter launches of the context so far                                             */
 #define GMS_QUERY_CUS               5 /* compute units of the context's device                                             */

@@ -54,6 +54,7 @@ namespace {
 //   GMS_DENSE=0          keep every pair on the hashed path
 //   GMS_BAND=0           keep large pairs on the HBM-slab kernel alone
 //   GMS_STREAM=0         pairs of 16 385 .. 65 536 matches: the 16-bit band / tile kernels instead of the streamed byte-matrix kernels
+//   GMS_PROBE_NIBBLE=m   which scale probes try four-bit entries first: 8 = the 28 x 28 grid, 16 = the 40 x 40 grid (default), 24 = both, 0 = none
 //   GMS_STAGGER_US=n     spread of the first dispatch round's start times at 10k matches per pair (0 = off)
 //   GMS_BAND_WS_BYTES=n  budget of the large-pair workspace (default 4 GiB); a batch is filtered in slices that fit it
 //   GMS_DEAL=0|1         never / always deal the matches to the lanes of the byte-matrix kernel (default: what the probe saw)
@@ -63,6 +64,8 @@ namespace {
 //                        the pair a places ahead (default: the number of CUs = the pair its CU's next workgroup takes)
 struct Knobs {
     bool dense_on = true, band_on = true, stream_on = true;
+    int probe_nibble = 16;  // which fine right grids (bit 3: 28 x 28, bit 4: 40 x 40) a scale probe tries with four-bit entries first when the probe is forced on
+    bool probe_nibble_set = false;  // GMS_PROBE_NIBBLE given: also a limit on what the library chooses by itself
     int stagger_us = -1, deal = -1, scale_probe = -1, check_pairs = -1;
     int prefetch_type = 3, prefetch_ahead = 0;
     size_t band_ws_budget = (size_t)4 << 30;
@@ -74,6 +77,7 @@ const Knobs& knobs()
         if (const char* e = std::getenv("GMS_DENSE")) v.dense_on = std::atoi(e) != 0;
         if (const char* e = std::getenv("GMS_BAND")) v.band_on = std::atoi(e) != 0;
         if (const char* e = std::getenv("GMS_STREAM")) v.stream_on = std::atoi(e) != 0;
+        if (const char* e = std::getenv("GMS_PROBE_NIBBLE")) { v.probe_nibble = (int)std::strtol(e, nullptr, 0) & 24; v.probe_nibble_set = true; }
         if (const char* e = std::getenv("GMS_STAGGER_US")) v.stagger_us = std::atoi(e);
         if (const char* e = std::getenv("GMS_DEAL")) v.deal = std::atoi(e) != 0 ? 1 : 0;
         if (const char* e = std::getenv("GMS_SCALE_PROBE")) v.scale_probe = std::atoi(e) != 0 ? 1 : 0;
@@ -181,7 +185,7 @@ struct gms_ctx {
     // between. verdict[2] (below) is different: a counter the streamed kernels add to, read without waiting -- it only steers which of
     // two bit-identical paths the next launches of large pairs take (and with it which workspace such a launch asks for).
     // last_* = what the most recent launch ran with (gms_ctx_query).
-    int use_dealt = 0, use_probe = 1, last_dealt = 0, last_probe = 0, last_kpt = 0, last_stagger_ticks = 0;
+    int use_dealt = 0, use_probe = 0x1D | (16 << 8), last_dealt = 0, last_probe = 0, last_kpt = 0, last_stagger_ticks = 0;
     hipEvent_t verdict_event = nullptr;
     bool verdict_pending = false;
     unsigned filter_launches = 0;  // every launch of the context (pair-table validation every sixteenth)
@@ -328,7 +332,7 @@ int filter_launch(gms_ctx* c, hipStream_t st, const float* d_pts, const int64_t*
     p.dense = (knobs().dense_on && !with_scale) ? 1 : 0;
     if (c->verdict_pending && !capturing && hipEventQuery(c->verdict_event) == hipSuccess) {
         c->use_dealt = c->verdict[0] != 0u ? 1 : 0;
-        c->use_probe = c->verdict[1] != 0u ? 1 : 0;
+        c->use_probe = (int)c->verdict[1];
         c->verdict_pending = false;
     }
     const int force_deal = c->opt_deal >= 0 ? c->opt_deal : knobs().deal, force_probe = c->opt_probe >= 0 ? c->opt_probe : knobs().scale_probe;
@@ -356,8 +360,12 @@ int filter_launch(gms_ctx* c, hipStream_t st, const float* d_pts, const int64_t*
     if (kpt && with_scale) {
         // the scales finer than 20 x 20 and the 14 x 14 one are probed (2, 3, 4); the measuring launches are left out of stream captures
         const bool measuring = force_probe < 0 && !capturing && (c->scale_launches++ & 15u) == 0u;
-        const bool on = force_probe >= 0 ? force_probe != 0 : (measuring || c->use_probe != 0);
-        p.probe_scales = on ? 0x1D : 0;  // every scale but 1, which the byte-matrix kernel evaluates first
+        // which scales are probed (every scale but 1, which the byte-matrix kernel evaluates first) and which of the two fine ones try
+        // four-bit entries first: forced, or everything in a measuring launch, or what the last verdict said paid -- scale by scale
+        const int all = 0x1D | (24 << 8);
+        const int mask = force_probe >= 0 ? (force_probe != 0 ? 0x1D | (knobs().probe_nibble << 8) : 0) : (measuring ? all : c->use_probe);
+        p.probe_scales = mask & 0x1D;
+        p.probe_nibble = (mask >> 8) & 24 & (knobs().probe_nibble_set ? knobs().probe_nibble : 24);
         p.probe_stats = measuring ? (uint32_t*)c->probe_stats.p : nullptr;
     }
     if (kpt && with_scale && knobs().dense_on) {
@@ -415,13 +423,13 @@ int filter_launch(gms_ctx* c, hipStream_t st, const float* d_pts, const int64_t*
         GMS_HIP(gms::launch_filter_big(p, w.mcap, n_wg, (uint32_t*)c->big_ws.p, st));
     }
     c->last_dealt = p.dealt;
-    c->last_probe = p.probe_scales;
+    c->last_probe = p.probe_scales | (p.probe_scales ? p.probe_nibble << 8 : 0);
     c->last_kpt = kpt;
     c->last_stagger_ticks = p.stagger_ticks;
     // pair-table validation (ranges [match_off, match_off + m) must be disjoint: include/gms.h), behind the filter: offenders'
     // status becomes GMS_ERR_BAD_ARG. The first launch of a context and every sixteenth; never inside a stream capture.
     if (validate_pairs && n_pairs > 1 && !capturing && knobs().check_pairs != 0 && (knobs().check_pairs == 1 || (c->filter_launches & 15u) == 0u))
-        GMS_HIP(gms::launch_check_pairs(d_pairs, n_pairs, d_results, (uint32_t*)c->probe_stats.p + 8 + (c->filter_launches & 7u), st));  // (a flag word of its own per launch: launches of one context may run on different streams)
+        GMS_HIP(gms::launch_check_pairs(d_pairs, n_pairs, d_results, (uint32_t*)c->probe_stats.p + 16 + (c->filter_launches & 7u), st));  // (a flag word of its own per launch: launches of one context may run on different streams)
     if (!capturing) ++c->filter_launches;
     if (uses_ws && !capturing) {
         GMS_HIP(hipEventRecord(c->ws_event, st));
@@ -609,11 +617,11 @@ int gms_ctx_create(int device, gms_ctx** out_ctx)
     if (e == hipSuccess) e = hipHostMalloc((void**)&c->verdict, 64, hipHostMallocDefault);
     if (e == hipSuccess) {
         c->verdict[0] = 0;
-        c->verdict[1] = 1;
+        c->verdict[1] = 0x1D | (16 << 8);
         c->verdict[2] = 0;
     }
-    if (e == hipSuccess) e = c->probe_stats.reserve(64);
-    if (e == hipSuccess) e = hipMemset(c->probe_stats.p, 0, 64);
+    if (e == hipSuccess) e = c->probe_stats.reserve(128);  // [0..13] probe counters (probe_verdict_kernel), [16..23] flag words of the pair-table check
+    if (e == hipSuccess) e = hipMemset(c->probe_stats.p, 0, 128);
     if (e == hipSuccess) e = gms::init_filter_kernels();
     if (e == hipSuccess) e = gms::init_band_kernels();
     if (e == hipSuccess) e = gms::init_stream_kernels();
@@ -691,7 +699,7 @@ int gms_ctx_synchronize(gms_ctx* c)
     GMS_HIP(hipStreamSynchronize(c->stream));
     if (c->verdict_pending && hipEventQuery(c->verdict_event) == hipSuccess) {  // (recorded on another stream: maybe not yet)
         c->use_dealt = c->verdict[0] != 0u ? 1 : 0;
-        c->use_probe = c->verdict[1] != 0u ? 1 : 0;
+        c->use_probe = (int)c->verdict[1];
         c->verdict_pending = false;
     }
     return GMS_OK;

@@ -42,6 +42,7 @@ struct FilterParams {
     const uint32_t* pair_flags; // large-pair kernel only: when set, it filters just the pairs whose flag word has bit 1 set
     int dealt;                  // byte-matrix kernel: deal the matches to the lanes (inputs in spatial order; see dense_pair)
     int probe_scales;           // scale hypotheses: bit s set = bound scale s's inlier count first and skip the scale when it cannot win
+    int probe_nibble;           // scale hypotheses: bit 3 / bit 4 = bound the 28 x 28 / 40 x 40 grid with four-bit entries first (half the bands of the byte probe)
     uint32_t* probe_stats;      // optional device counters: [0] scales probed, [1] scales the probe let skip
     uint32_t* overflow_events;  // streamed byte-matrix kernels: a word (pinned host memory) that counts the pairs they had to hand on because an entry left its byte
     int prefetch_type, prefetch_ahead;  // byte-matrix kernel: before grid type prefetch_type a workgroup touches the records of pair + prefetch_ahead (0 = off)

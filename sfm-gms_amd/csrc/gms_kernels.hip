@@ -736,7 +736,7 @@ __device__ __forceinline__ void hash_pair(const FilterParams& p, uint32_t* smem,
             __syncthreads();
             if (tid == 0) {
                 misc[0] = 0;
-                if (p.probe_stats != nullptr) atomicAdd(&p.probe_stats[skip_scale ? 1 : 0], 1u);
+                if (p.probe_stats != nullptr) atomicAdd(&p.probe_stats[2 * s + (skip_scale ? 1 : 0)], 1u);
             }
         }
         }
@@ -2106,6 +2106,7 @@ __device__ __forceinline__ bool dense_scales_pair(const FilterParams& p, uint32_
         // the current pass works on its lane's sink instead. Bit 31 is never cleared (increments land in byte 0, keys end below it).
         if (tid < 16) trash[tid] = 0x80000000u;
         if (tid == 0) misc[15] = 0xFFFFFFFFu;  // "no header": what a match reads in the marking pass when the grid type leaves it out (E = 2047: equal to no E -- a never-binned match carries E = 0 --, and no rotation bits)
+        if (tid == 0) misc[14] = 0x7FFu;       // the same for probes, whose nibble form also tests the low 20 bits for the "dirty row" key
     }
     __syncthreads();
     if (misc[8] != 0) {  // an input outside the parity domain (workgroup-uniform)
@@ -2114,7 +2115,7 @@ __device__ __forceinline__ bool dense_scales_pair(const FilterParams& p, uint32_
     }
     const bool spilled = misc[13] != 0;  // a half cell above 255 matches: crowded from the start (see dense_pair)
     uint32_t* nl32 = nfine32;            // crowded mode: nLeft as 16-bit counters, two buffers of 400
-    const uint32_t sink_at = kDenseTrashOff + 4u * (uint32_t)(lane & 15), none_at = kDenseMiscOff + 4u * 15u;
+    const uint32_t sink_at = kDenseTrashOff + 4u * (uint32_t)(lane & 15), none_at = kDenseMiscOff + 4u * 15u, none_probe_at = kDenseMiscOff + 4u * 14u;
 
     const bool thr_fast = threshold_fast_ok(p.threshold_factor);
     const uint32_t f2i = dense_factor_sq(p.threshold_factor);
@@ -2138,12 +2139,21 @@ __device__ __forceinline__ bool dense_scales_pair(const FilterParams& p, uint32_
 
     // returns 0 = done, 1 = a cell above 255 matches (everything is run again CROWDED), 2 = a matrix entry at its limit,
     // 3 = PROBE only: the scale cannot win
-    auto run_scale = [&](auto banded_c, auto crowded_c, auto probe_c, const int s) -> int {
+    auto run_scale = [&](auto banded_c, auto crowded_c, auto probe_c, auto nib_c, const int s) -> int {
         constexpr bool BANDED = decltype(banded_c)::value;
         constexpr bool CROWDED = decltype(crowded_c)::value;
         constexpr bool PROBE = decltype(probe_c)::value;
+        // NIB (probes of the two fine grids only): one NIBBLE per entry -- rows half as long, so scale 3's matrix fits whole (400 rows
+        // of 396 bytes: a probe in four passes instead of eight) and scale 4's in two bands of ten rows (eight passes instead of
+        // sixteen). A probe is an upper bound, so an entry that passes 15 need not stop anything: the add that sees 15 come back (its
+        // carry has spoilt the neighbour entry of the same row, never another row: rows are dword-aligned) marks the ROW dirty --
+        // the largest key the pass can hold -- and every match of a dirty row counts as a possible inlier: a superset of the exact
+        // probe's set, a few matches larger where a row overflowed.
+        constexpr bool NIB = decltype(nib_c)::value;
+        static_assert(!NIB || (PROBE && !CROWDED), "nibble entries: probes of uncrowded pairs only");
         const uint32_t wr = (uint32_t)p.right_w[s], nr = wr * wr;
-        const uint32_t stride = 4u + nr;                 // header dword + one byte per right cell
+        const uint32_t stride = 4u + (NIB ? nr >> 1 : nr);   // header dword + one byte (nibble) per right cell
+        const uint32_t e_top = NIB ? nr + 7u : nr + 3u;       // E(r) = e_top - r: the entry's byte (nibble) offset in its row
         const uint32_t wr_magic = 65535u / wr + 1u;      // j / wr == (j * magic) >> 16 for j * wr < 65536
         // scale 4 (probe only): E(r) up to 1603 takes 11 bits and reaches into the rotation bits, which a probe does not use
         const uint32_t emask = (PROBE && s == 4) ? 0x7FFu : kSEMask;
@@ -2163,7 +2173,7 @@ __device__ __forceinline__ bool dense_scales_pair(const FilterParams& p, uint32_
                     const uint32_t fy = (fine * (s == 1 ? 3277u : 2341u)) >> 16, fx = fine - fy * wf;  // fine / wf for fine < 784
                     r = (fy >> 1) * (wf >> 1) + (fx >> 1);
                 }
-                if (!(code[k] & kDNever)) code[k] = (code[k] & ~(emask << kDEShift)) | ((nr + 3u - r) << kDEShift);
+                if (!(code[k] & kDNever)) code[k] = (code[k] & ~(emask << kDEShift)) | ((e_top - r) << kDEShift);
             }
         }
         int status = 0;
@@ -2188,7 +2198,7 @@ __device__ __forceinline__ bool dense_scales_pair(const FilterParams& p, uint32_
             }
             // bands: 8 own rows + a halo row on either side (verify reads the neighbour rows); a probe needs no neighbours, so its
             // bands are as many whole rows as fit: 10 at 28 x 28 right cells, 5 at 40 x 40
-            const int band_rows = PROBE ? (s == 4 ? 5 : 10) : 8, halo = PROBE ? 0 : 1;
+            const int band_rows = PROBE ? (s == 4 && !NIB ? 5 : 10) : 8, halo = PROBE ? 0 : 1;
             const int n_bands = BANDED ? (kLeftH + band_rows - 1) / band_rows : 1;
             for (int band = 0; band < n_bands; ++band) {
                 const int lo = BANDED ? band * band_rows : 0, hi = BANDED ? min(lo + band_rows, kLeftH) : kLeftH;      // own rows
@@ -2211,25 +2221,28 @@ __device__ __forceinline__ bool dense_scales_pair(const FilterParams& p, uint32_
                         const uint32_t cw = code[k0 + c];
                         const uint32_t l = (aux[k0 + c] & 0x1FFu) + (cw & q_mask) - cell0;
                         in[c] = (cw & out_mask) == 0 && (!BANDED || l < n_held);
+                        // at[c]: the entry's bit offset in its dword (bytes: 8 (E & 3); nibbles: 4 (E & 7)); rows are dword-aligned
                         if constexpr (BANDED) {
                             row[c] = __umul24(l, stride);
                             ee[c] = (cw >> kDEShift) & emask;
-                            at[c] = row[c] + ee[c];
+                            at[c] = NIB ? (ee[c] & 7u) << 2 : (ee[c] & 3u) << 3;
                             old[c] = 0;
-                            if (in[c]) old[c] = ldsa_add_rtn(at[c] & ~3u, 1u << ((at[c] << 3) & 31u));
+                            if (in[c]) old[c] = ldsa_add_rtn(row[c] + (NIB ? (ee[c] >> 3) << 2 : ee[c] & ~3u), 1u << at[c]);
                         } else {
                             row[c] = in[c] ? __umul24(l, stride) : sink_at;  // (not binned under this grid type: the lane's sink, E = 0)
                             ee[c] = in[c] ? ((cw >> kDEShift) & emask) : 0u;
-                            at[c] = row[c] + ee[c];
-                            old[c] = ldsa_add_rtn(at[c] & ~3u, 1u << ((at[c] << 3) & 31u));
+                            at[c] = NIB ? (ee[c] & 7u) << 2 : (ee[c] & 3u) << 3;
+                            old[c] = ldsa_add_rtn(row[c] + (NIB ? (ee[c] >> 3) << 2 : ee[c] & ~3u), 1u << at[c]);
                         }
                     }
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int c = 0; c < kChunk; ++c) {
-                        const uint32_t before = __builtin_amdgcn_ubfe(old[c], at[c] << 3, 8);
+                        const uint32_t before = __builtin_amdgcn_ubfe(old[c], at[c], NIB ? 4 : 8);
                         if (CROWDED && in[c] && before == 255u) misc[12] = 1;  // the entry's byte has just wrapped
-                        if (!BANDED || in[c]) ldsa_max(row[c], key_tag | (before << 11) | ee[c]);
+                        // (nibbles: the entry has just wrapped -> the row is dirty: the largest key of this pass, no later one replaces it)
+                        const uint32_t key = (NIB && before == 15u) ? 0xFFFFFu : (before << 11) | ee[c];
+                        if (!BANDED || in[c]) ldsa_max(row[c], key_tag | key);
                     }
                 }
                 GMS_STAMP_IN(3);  // insert
@@ -2336,24 +2349,27 @@ __device__ __forceinline__ bool dense_scales_pair(const FilterParams& p, uint32_
                         const uint32_t cw = code[k];
                         const uint32_t l = (aux[k] & 0x1FFu) + (cw & q_mask);
                         const bool in = (cw & out_mask) == 0 && (!BANDED || l - cell0 < n_held);
+                        // the undo is a zero BYTE over the entry: with nibbles that clears the neighbour entry too -- every entry that was
+                        // touched is cleared by somebody, nobody reads entries in this phase, all writers store the same value
+                        const uint32_t ebyte = NIB ? ((cw >> kDEShift) & emask) >> 1 : (cw >> kDEShift) & emask;
                         if constexpr (BANDED) {
                             const uint32_t row = __umul24(l - cell0, stride);
-                            cr[k] = 0xFFFFFFFFu;  // "no header" (reads as E = 2047)
+                            cr[k] = PROBE ? 0x7FFu : 0xFFFFFFFFu;  // "no header" (reads as E = 2047; a probe also tests the low 20 bits for "dirty")
                             if (in) {
                                 if (l - own0 < n_own) cr[k] = ldsa_ld32(row);
-                                ldsa_st8(row + ((cw >> kDEShift) & emask), 0u);  // (every reader of the entry is past the barrier: see dense_pair)
+                                ldsa_st8(row + ebyte, 0u);  // (every reader of the entry is past the barrier: see dense_pair)
                             }
                         } else {
                             const uint32_t row = in ? __umul24(l - cell0, stride) : sink_at;
-                            const uint32_t at = row + (in ? ((cw >> kDEShift) & emask) : 0u);
-                            cr[k] = ldsa_ld32(in ? row : none_at);
+                            const uint32_t at = row + (in ? ebyte : 0u);
+                            cr[k] = ldsa_ld32(in ? row : (PROBE ? none_probe_at : none_at));
                             ldsa_st8(at, 0u);
                         }
                     }
 #pragma unroll
                     for (int k = 0; k < KPT; ++k) {
                         if constexpr (PROBE) {  // the header still holds the arg-max key: [tag | count - 1 | E(j*)]; (a row not owned reads as E = 2047)
-                            if ((cr[k] & 0x7FFu) == ((code[k] >> kDEShift) & emask)) code[k] |= 1u << kSProbeBit;
+                            if ((cr[k] & 0x7FFu) == ((code[k] >> kDEShift) & emask) || (NIB && (cr[k] & 0xFFFFFu) == 0xFFFFFu)) code[k] |= 1u << kSProbeBit;
                         } else {
                             const uint32_t x = cr[k] ^ (code[k] & (kSEMask << kDEShift));
                             if (x < 256u) code[k] |= x << kSAccShift;
@@ -2368,7 +2384,7 @@ __device__ __forceinline__ bool dense_scales_pair(const FilterParams& p, uint32_
         if (status != 0) return status;
         // the next scale lays its rows out differently: no header of this one may survive as a count byte
         for (uint32_t c = tid; c < (uint32_t)kLeftN; c += NT)
-            if (!BANDED || c < (uint32_t)((PROBE ? (s == 4 ? 5 : 10) : 10) * kLeftW)) smem[c * (stride >> 2)] = 0;
+            if (!BANDED || c < (uint32_t)((PROBE ? (s == 4 && !NIB ? 5 : 10) : 10) * kLeftW)) smem[c * (stride >> 2)] = 0;
 
         if constexpr (PROBE) {  // ---- how many matches could be inliers at this scale at all
             uint32_t c0 = 0;
@@ -2383,7 +2399,7 @@ __device__ __forceinline__ bool dense_scales_pair(const FilterParams& p, uint32_
             if (tid < 8) misc[tid] = 0;
             // (a scale that comes BEFORE the best one in the reference's order would also win a tie)
             const bool can_win = bound > best_count || (bound == best_count && s < best_scale);
-            if (tid == 0 && p.probe_stats != nullptr) atomicAdd(&p.probe_stats[can_win ? 0 : 1], 1u);
+            if (tid == 0 && p.probe_stats != nullptr) atomicAdd(&p.probe_stats[(NIB ? 4 + 2 * s : 2 * s) + (can_win ? 0 : 1)], 1u);  // (nibble probes of scales 3, 4: words 10..13)
             GMS_STAMP_IN(7);
             return can_win ? 0 : 3;
         }
@@ -2444,11 +2460,20 @@ __device__ __forceinline__ bool dense_scales_pair(const FilterParams& p, uint32_
     // one scale: the probe first where the launch asks for it and there is a best count to beat
     auto eval_scale = [&](auto banded_c, auto crowded_c, const int s) -> int {
         if (((p.probe_scales >> s) & 1) != 0 && best_count > 0) {
-            const int pr = run_scale(banded_c, crowded_c, std::true_type{}, s);
+            constexpr bool kCrowded = decltype(crowded_c)::value;
+            if constexpr (!kCrowded) {
+                if (s == 3 && (p.probe_nibble & 8) != 0) {  // the cheap bound first: nibble entries, the whole matrix at once
+                    const int pn = run_scale(std::false_type{}, crowded_c, std::true_type{}, std::true_type{}, s);
+                    GMS_STAMP_SCALE(5 + s);
+                    if (pn == 3) return 0;
+                    if (pn != 0) return pn;
+                }
+            }
+            const int pr = run_scale(banded_c, crowded_c, std::true_type{}, std::false_type{}, s);
             GMS_STAMP_SCALE(5 + s);
             if (pr != 0) return pr == 3 ? 0 : pr;
         }
-        const int ev = run_scale(banded_c, crowded_c, std::false_type{}, s);
+        const int ev = run_scale(banded_c, crowded_c, std::false_type{}, std::false_type{}, s);
         GMS_STAMP_SCALE(s);
         return ev;
     };
@@ -2485,8 +2510,14 @@ __device__ __forceinline__ bool dense_scales_pair(const FilterParams& p, uint32_
     // when it does not, the record says so and the hashed kernel does not probe again.
     uint32_t decided = 4u;
     if (status == 0 && ((p.probe_scales >> 4) & 1) != 0 && best_count > 0 && p.right_w[4] == 40 && p.right_h[4] == 40) {
-        const int pr = crowded_mode ? run_scale(std::true_type{}, std::true_type{}, std::true_type{}, 4)
-                                    : run_scale(std::true_type{}, std::false_type{}, std::true_type{}, 4);
+        int pr = 0;
+        if (crowded_mode) {
+            pr = run_scale(std::true_type{}, std::true_type{}, std::true_type{}, std::false_type{}, 4);
+        } else {
+            // the cheap bound first (nibble entries: two bands instead of four); when it cannot bound the scale out, the exact one
+            if ((p.probe_nibble & 16) != 0) pr = run_scale(std::true_type{}, std::false_type{}, std::true_type{}, std::true_type{}, 4);
+            if ((p.probe_nibble & 16) == 0 || pr == 0) pr = run_scale(std::true_type{}, std::false_type{}, std::true_type{}, std::false_type{}, 4);
+        }
         GMS_STAMP_SCALE(9);
         if (pr == 3) decided = 5u;
         else if (pr == 0) decided = 4u | 16u;
@@ -2689,13 +2720,25 @@ hipError_t launch_compact_survivors(const gms_pair* d_pairs, const gms_pair_resu
     return hipGetLastError();
 }
 
-// Scale probes of the launches so far: [0] probed and evaluated anyway, [1] probed and skipped. A probe costs about 45 % of a
-// scale and saves the rest when it lets the scale skip: it pays from a skip rate of one half.
+// Scale probes of the launches so far, per scale hypothesis s: stats[2 s] probed and evaluated anyway, stats[2 s + 1] probed and
+// skipped; the same for the four-bit first attempts of scales 3 and 4 at stats[10 + 2 (s - 3)]. A probe costs about 45 % of a scale
+// and saves the rest when it lets the scale skip: it pays from a skip rate of one half (a four-bit attempt costs half a byte probe
+// and saves a whole one: the same rule is on the safe side). *flag: bit s = probe scale s, bit 8 + s = try four-bit entries first;
+// a scale that was not probed often enough since the last verdict keeps its bit.
 __global__ void probe_verdict_kernel(uint32_t* stats, uint32_t* flag)
 {
-    const uint32_t kept = stats[0], skipped = stats[1];
-    if (kept + skipped >= 8u) *flag = skipped >= kept ? 1u : 0u;
-    stats[0] = stats[1] = 0u;
+    uint32_t mask = *flag;
+    for (int s = 0; s < 5; ++s) {
+        const uint32_t kept = stats[2 * s], skipped = stats[2 * s + 1];
+        if (kept + skipped >= 8u) mask = (mask & ~(1u << s)) | (skipped >= kept ? 1u << s : 0u);
+        stats[2 * s] = stats[2 * s + 1] = 0u;
+    }
+    for (int s = 3; s < 5; ++s) {
+        const uint32_t kept = stats[4 + 2 * s], skipped = stats[5 + 2 * s];
+        if (kept + skipped >= 8u) mask = (mask & ~(1u << (8 + s))) | (skipped >= kept ? 1u << (8 + s) : 0u);
+        stats[4 + 2 * s] = stats[5 + 2 * s] = 0u;
+    }
+    *flag = mask;
 }
 
 hipError_t launch_probe_verdict(uint32_t* stats, uint32_t* flag, hipStream_t stream)

@@ -37,7 +37,7 @@ for name, val in (('on', 1), ('off', 0)):
 ctx.set_option(2, -1)
 if {zoom}:
     z = bench.zoom_leg(ctx, pkg, stream, dev)
-    out['zoom'] = dict(auto=z['auto']['pairs_per_s'], off=z['off']['pairs_per_s'], on=z['on']['pairs_per_s'], bad=z['parity']['mismatches'])
+    out['zoom'] = dict(auto=z['auto']['pairs_per_s'], off=z['off']['pairs_per_s'], on=z['on']['pairs_per_s'], bad=z['parity']['mismatches'], auto_mask=z['auto']['probe_mask'])
 print(json.dumps(out))
 """
 
