@@ -147,14 +147,17 @@ find_essential_kernel(EssentialParams prm, const gms_pair* __restrict__ pairs, c
     } else if (n > 5) {
         tv::CvRng rng;
         rng.seed(0xFFFFFFFFFFFFFFFFull);  // RNG rng((uint64)-1)
-        for (int it0 = 0;; it0 += kSolvers) {
-            // (1) the samples of iterations it0 .. it0 + 15, in cv::RNG's order
+        // (A round solves sixteen samples in lockstep. Measured and dropped: a first round of four -- the lanes of a round run as many
+        //  sweeps of the root finder as the slowest of them -- costs more in second rounds, each a whole solve's latency, than it saves:
+        //  4.2 -> 5.0 ms per 1024 pairs at SfMUtil.cpp:39's confidence of 0.7, where the mean iteration count is 3.2.)
+        for (int it0 = 0, width = kSolvers;; it0 += width) {
+            // (1) the samples of iterations it0 .. it0 + width - 1, in cv::RNG's order
             if (tid == 0)
-                for (int k = 0; k < kSolvers; ++k) rng.sample5(n, s_samples + 5 * k);
+                for (int k = 0; k < width; ++k) rng.sample5(n, s_samples + 5 * k);
             if (tid < kSolvers * 10) s_counts[tid] = 0u;
             __syncthreads();
             const int bound = s_ctl[0];
-            const int live = min(kSolvers, bound - it0);  // iterations of this round that can still be reached
+            const int live = min(width, bound - it0);  // iterations of this round that can still be reached
             // (2) sixteen minimal solves, one lane each
             if (tid < kSolvers) {
                 if (tid < live) solve(tid);
@@ -182,7 +185,7 @@ find_essential_kernel(EssentialParams prm, const gms_pair* __restrict__ pairs, c
             // (4) the reference's loop over the round's iterations, in order
             if (tid == 0) {
                 int niters = s_ctl[0], best = s_ctl[2], it = it0;
-                for (int k = 0; k < kSolvers && it < niters; ++k, ++it) {
+                for (int k = 0; k < live && it < niters; ++k, ++it) {
                     for (int j = 0; j < s_nmodels[k]; ++j) {
                         const int good = (int)s_counts[k * 10 + j];
                         if (good > max(best, 4)) {  // goodCount > MAX(maxGoodCount, modelPoints - 1)
@@ -266,6 +269,10 @@ recover_pose_batch_kernel(double fx, double fy, double cx, double cy, double dis
     __shared__ double s_P[4][12];
     __shared__ unsigned s_votes[4];
     __shared__ int s_ok, s_winner;
+    // the four votes of every correspondence, kept from the counting pass for the mask pass (pairs up to kVoteCache points; beyond
+    // that the winner's test is worked out again): the mask then IS the set that was counted, and the second triangulation is saved
+    constexpr int kVoteCache = 16384;
+    __shared__ uint8_t s_bits[kVoteCache];
     const int p = (int)blockIdx.x, tid = (int)threadIdx.x, lane = tid & 63;
     const gms_pair pr = pairs[p];
     const bool have_e = tv[p].status == GMS_OK;
@@ -299,6 +306,7 @@ recover_pose_batch_kernel(double fx, double fy, double cx, double cy, double dis
             const double x2 = ((double)c2[i].x - cx) / fx, y2 = ((double)c2[i].y - cy) / fy;
             bits = tv::pose_votes(s_P, dist_thresh, x1, y1, x2, y2);
         }
+        if (i < min(n, kVoteCache)) s_bits[i] = (uint8_t)bits;
         for (int h = 0; h < 4; ++h) {
             const unsigned long long b = __ballot((bits >> h) & 1u);
             if (lane == 0 && b) atomicAdd(&s_votes[h], (unsigned)__popcll(b));
@@ -330,9 +338,13 @@ recover_pose_batch_kernel(double fx, double fy, double cx, double cy, double dis
         uint8_t out = 0;
         const uint8_t in = use_in_mask ? mk[i] : (uint8_t)255;
         if (ok && in != 0) {
-            const double x1 = ((double)c1[i].x - cx) / fx, y1 = ((double)c1[i].y - cy) / fy;
-            const double x2 = ((double)c2[i].x - cx) / fx, y2 = ((double)c2[i].y - cy) / fy;
-            out = tv::pose_vote_one(s_P, w, dist_thresh, x1, y1, x2, y2) ? in : (uint8_t)0;
+            if (i < kVoteCache) {
+                out = ((s_bits[i] >> w) & 1u) ? in : (uint8_t)0;
+            } else {
+                const double x1 = ((double)c1[i].x - cx) / fx, y1 = ((double)c1[i].y - cy) / fy;
+                const double x2 = ((double)c2[i].x - cx) / fx, y2 = ((double)c2[i].y - cy) / fy;
+                out = tv::pose_vote_one(s_P, w, dist_thresh, x1, y1, x2, y2) ? in : (uint8_t)0;
+            }
         }
         mk[i] = out;
     }
