@@ -536,7 +536,7 @@ def poses_leg(ctx, pkg, stream, dev, n_frames=46, n_kp=10000, n_pairs=1024, step
     desc_h = d_desc.cpu().numpy()
     bad = 0
     failed_checks = []
-    checked = [0, n_pairs - 1]
+    checked = sorted(set(int(v) for v in np.linspace(0, n_pairs - 1, 16)))   # sixteen pairs spread over the launch, first and last included
     for i in checked:
         a, b = int(pairs["frame_a"][i]), int(pairs["frame_b"][i])
         want_m = oracle.bf_match(desc_h[a * n_kp:(a + 1) * n_kp], desc_h[b * n_kp:(b + 1) * n_kp], True)
@@ -562,7 +562,7 @@ def poses_leg(ctx, pkg, stream, dev, n_frames=46, n_kp=10000, n_pairs=1024, step
             "mean_triangulated_per_pair": float(tv["n_triangulated"][ok].mean()) if ok.any() else None,
             "median_rotation_error_deg": float(np.median(rot_err)) if rot_err else None,
             "parity": {"pairs_checked": len(checked), "mismatches": bad, "ok": bad == 0, "failed_checks": failed_checks,
-                       "rule": "first and last pair: matches, survivors and results bit-exact vs oracle/bf_ref.c + oracle/gms_ref.c; RANSAC decisions "
+                       "rule": "sixteen pairs spread over the launch: matches, survivors and results bit-exact vs oracle/bf_ref.c + oracle/gms_ref.c; RANSAC decisions "
                                "(iterations, masks, counts) equal and E, R within 1e-9 of oracle/sfm_ref.py (fp64, parity unpinned: OpenCV's calib3d "
                                "is an import library in the reference)"}}
 
@@ -670,8 +670,10 @@ def real_pixels_leg(ctx, pkg, stream, dev, copies=2048, steps=6):
             torch.cuda.synchronize()
             ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
             with torch.cuda.stream(stream):
-                for s in range(-3, steps):
-                    if s == -1:  # the library picks its lane mapping from what an earlier launch saw: let that verdict land before timing
+                for s in range(-20, steps):
+                    # the library picks its lane mapping (and which scales it probes) from what earlier launches of the context saw, every
+                    # sixteenth launch: the timed launches are its steady state on THIS input, so a verdict cycle runs -- and lands -- first
+                    if s < 0 and s % 4 == 0:
                         torch.cuda.synchronize()
                     if s >= 0:
                         ev[s][0].record(stream)

@@ -12,7 +12,9 @@ for src, dst in (("bench.json", "bench.json"), ("phase.json", "phase_cycles.json
                  ("config4_bench.json", "config4_bench.json"), ("kernel_stats_rot_scale_64.csv", "kernel_stats_config4_rot_scale.csv"),
                  ("kernel_stats_default_256.csv", "kernel_stats_config4_default_flags.csv"), ("matcher_limits.txt", "matcher_limits.txt"),
                  ("matcher_counters_orb.csv", "matcher_counters_orb.csv"), ("matcher_counters_sift.csv", "matcher_counters_sift.csv"),
-                 ("image_pair_sparse.json", "image_pair_sparse.json"), ("image_pair_dense.json", "image_pair_dense.json")):
+                 ("image_pair_sparse.json", "image_pair_sparse.json"), ("image_pair_dense.json", "image_pair_dense.json"),
+                 ("host_copy_rate.json", "host_copy_rate.json"), ("host_batch_rate.json", "host_batch_rate.json"), ("host_batch_python.json", "host_batch_python.json"),
+                 ("real_pixels.json", "real_pixels.json"), ("real_pixels_list_order.json", "real_pixels_list_order.json"), ("ab_scales.txt", "ab_scales_probe_forms.txt")):
     shutil.copy(F + src, f"profiles/{tag}_{dst}")
 for name in ("kernel_stats_config4_rot_scale.csv", "kernel_stats_config4_default_flags.csv"):   # kernel names cut, as in the main stats files
     rows = list(csv.DictReader(open(f"profiles/{tag}_{name}")))

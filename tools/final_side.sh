@@ -18,3 +18,11 @@ for k in orb sift; do bash tools/bf_pmc.sh $k > "$F/bf_pmc_$k.txt" 2>&1 && cp gp
   echo "== tools/bf_bench.py orb 1024"; python3 tools/bf_bench.py orb 1024 2>/dev/null; } > "$F/matcher_limits.txt" 2>&1 && echo matcher limits ok
 python3 tools/gms_image_pair.py --check > "$F/image_pair_sparse.json" 2>/dev/null && python3 tools/gms_image_pair.py --dense --check > "$F/image_pair_dense.json" 2>/dev/null && echo image pair ok
 python3 tools/crowded_bench.py > "$F/crowded.json" 2>/dev/null && echo crowded ok
+# round 4: the host-pointer batch through the C ABI from C++ with the box's copy ceilings beside it, the real-pixel scenario, the scale
+# probes per scale hypothesis
+{ /opt/rocm/bin/hipcc -O2 -pthread tools/ubench/host_copy_rate.cpp -o /tmp/host_copy_rate 2>/dev/null && /tmp/host_copy_rate > "$F/host_copy_rate.json"; } && echo host copy rate ok
+{ /opt/rocm/bin/hipcc -O2 -pthread -Iinclude tools/ubench/host_batch_rate.cpp -Lsfm-gms_amd/csrc -lgms_hip -Wl,-rpath,$PWD/sfm-gms_amd/csrc -o /tmp/host_batch_rate 2>/dev/null && /tmp/host_batch_rate > "$F/host_batch_rate.json"; } && echo host batch rate ok
+python3 tools/host_batch_bench.py > "$F/host_batch_python.json" 2>/dev/null && echo host batch python ok
+python3 tools/real_pixels_bench.py > "$F/real_pixels.json" 2>/dev/null && echo real pixels ok
+GMS_DEAL=0 python3 tools/real_pixels_bench.py > "$F/real_pixels_list_order.json" 2>/dev/null && echo real pixels undealt ok
+python3 tools/ab_scales.py --zoom --rounds 1 default:libgms_hip.so byte_probes:libgms_hip.so:GMS_PROBE_NIBBLE=0 > "$F/ab_scales.txt" 2>&1 && echo ab scales ok
