@@ -1525,16 +1525,19 @@ __device__ __forceinline__ bool dense_pair_plain(const FilterParams& p, uint32_t
         const uint4* src = j < qA ? srcA + j : srcB + (j - qA);
         tb[i] = *src;
     }
-    constexpr bool kKeepRec = KPT <= 10;
-    uint4 rec[kKeepRec ? KPT : 1];
-    uint2 qt[kKeepRec ? 1 : KPT];
+    // The records of a thread's first kKeep matches stay in registers from here to the copy-out (all of them up to ten matches per
+    // thread; at sixteen the first eight: as many registers as ten whole records + ten code words take); the others are loaded as
+    // (queryIdx, trainIdx) alone and the survivors among them are read again at the end.
+    constexpr int kKeep = KPT <= 10 ? KPT : 8;
+    uint4 rec[kKeep];
+    uint2 qt[KPT > kKeep ? KPT - kKeep : 1];
 #pragma unroll
     for (int k = 0; k < KPT; ++k) {
-        if (kKeepRec) { const u32x4_t rv = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(&matches[min(match_of(k), m - 1)])); rec[k] = make_uint4(rv.x, rv.y, rv.z, rv.w); }
-        else qt[k] = *reinterpret_cast<const uint2*>(&matches[min(match_of(k), m - 1)]);
+        if (k < kKeep) { const u32x4_t rv = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(&matches[min(match_of(k), m - 1)])); rec[k] = make_uint4(rv.x, rv.y, rv.z, rv.w); }
+        else qt[k - kKeep] = *reinterpret_cast<const uint2*>(&matches[min(match_of(k), m - 1)]);
     }
-    auto query_of = [&](int k) -> uint32_t { return kKeepRec ? rec[k].x : qt[k].x; };
-    auto train_of = [&](int k) -> uint32_t { return kKeepRec ? rec[k].y : qt[k].y; };
+    auto query_of = [&](int k) -> uint32_t { return k < kKeep ? rec[k < kKeep ? k : 0].x : qt[k < kKeep ? 0 : k - kKeep].x; };
+    auto train_of = [&](int k) -> uint32_t { return k < kKeep ? rec[k < kKeep ? k : 0].y : qt[k < kKeep ? 0 : k - kKeep].y; };
     const uint32_t staged16 = staged ? qA + qB : 0u;
     {
         const uint4 z4 = make_uint4(0, 0, 0, 0);
@@ -1852,7 +1855,7 @@ __device__ __forceinline__ bool dense_pair_plain(const FilterParams& p, uint32_t
                 if (mask_out) mask_out[i] = in ? 1 : 0;
                 if (in) {
                     const uint32_t pos = base + (uint32_t)__popcll(keep[k] & ((1ull << lane) - 1ull));
-                    { const uint4 rv = kKeepRec ? rec[k] : *reinterpret_cast<const uint4*>(&matches[i]); __builtin_nontemporal_store(u32x4_t{rv.x, rv.y, rv.z, rv.w}, reinterpret_cast<u32x4_t*>(&out[pos])); }
+                    { const uint4 rv = k < kKeep ? rec[k < kKeep ? k : 0] : *reinterpret_cast<const uint4*>(&matches[i]); __builtin_nontemporal_store(u32x4_t{rv.x, rv.y, rv.z, rv.w}, reinterpret_cast<u32x4_t*>(&out[pos])); }
                 }
             }
         }
@@ -1895,7 +1898,7 @@ __device__ __forceinline__ bool dense_pair_plain(const FilterParams& p, uint32_t
                 if (mask_out) mask_out[i] = in ? 1 : 0;
                 if (in) {
                     const uint32_t pos = cnt_tab[i >> 3] + (uint32_t)__popc(byte & ((1u << (lane & 7)) - 1u));
-                    { const uint4 rv = kKeepRec ? rec[k] : *reinterpret_cast<const uint4*>(&matches[i]); __builtin_nontemporal_store(u32x4_t{rv.x, rv.y, rv.z, rv.w}, reinterpret_cast<u32x4_t*>(&out[pos])); }
+                    { const uint4 rv = k < kKeep ? rec[k < kKeep ? k : 0] : *reinterpret_cast<const uint4*>(&matches[i]); __builtin_nontemporal_store(u32x4_t{rv.x, rv.y, rv.z, rv.w}, reinterpret_cast<u32x4_t*>(&out[pos])); }
                 }
             }
         }
