@@ -1529,7 +1529,7 @@ __device__ __forceinline__ bool dense_pair_plain(const FilterParams& p, uint32_t
     // thread; at sixteen the first twelve: 16 384 matches per pair 5.58 M pairs/s keeping none, 6.06 M keeping eight, 6.41 M twelve,
     // 6.67 M fourteen -- with 8 bytes of scratch --, 6.21 M all sixteen with 36); the others are loaded as (queryIdx, trainIdx) alone and
     // the survivors among them are read again at the end.
-    constexpr int kKeep = KPT <= 10 ? KPT : 12;
+    constexpr int kKeep = KPT <= 10 ? KPT : (DEALT ? 10 : 12);  // (the dealt instantiation has two registers less to spare)
     uint4 rec[kKeep];
     uint2 qt[KPT > kKeep ? KPT - kKeep : 1];
 #pragma unroll
