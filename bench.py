@@ -684,7 +684,11 @@ def real_pixels_leg(ctx, pkg, stream, dev, copies=2048, steps=6):
             torch.cuda.synchronize()
             ms = float(np.median([a.elapsed_time(bb) for a, bb in ev]))
             res = d_res.cpu().numpy().view(pkg.RESULT_DTYPE).reshape(-1)
-            rc, want, _, want_res = oracle.match(sizes[0], sizes[b], kps[0], kps[b], matches, rot, scale, 6.0)
+            t_cpu = []
+            for _ in range(3):  # the oracle on the same pair, one thread of the box's host (median of three)
+                t0 = time.perf_counter()
+                rc, want, _, want_res = oracle.match(sizes[0], sizes[b], kps[0], kps[b], matches, rot, scale, 6.0)
+                t_cpu.append(time.perf_counter() - t0)
             k = len(want)
             bad = 0
             for i in (0, copies - 1):
@@ -695,6 +699,7 @@ def real_pixels_leg(ctx, pkg, stream, dev, copies=2048, steps=6):
             alg = (32.0 * m + 16.0 * k) * copies
             rec[tag] = {"flags": [rot, scale, 6.0], "value": copies / (ms * 1e-3), "unit": "pairs/s", "ms_per_launch": ms, "kept": k,
                         "winner": [int(want_res[1]), int(want_res[2])], "dealt_lane_mapping": bool(ctx.query(1)),
+                        "cpu_oracle_pairs_per_s_1_thread": 1.0 / float(np.median(t_cpu)),
                         "roofline": {"bound": "hbm", "achieved": alg / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                                      "frac": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "traffic": None,
                                      "kernel": "all kernels of the launch (HIP events around gms_filter_device)", "kernel_ms_per_launch": ms,
