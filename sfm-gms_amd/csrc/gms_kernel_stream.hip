@@ -10,13 +10,16 @@
 //   stream_index_kernel<1>   the same walk again, now placing every entry in the slot of its row: the entry array is sorted by the
 //                            left row of grid type 1, so that a band of left rows is a contiguous range of it (plus nLeft of every
 //                            cell under the four grid types, 16 bits each);
-//   stream_filter_kernel     grid (scale hypotheses, pairs). Per grid type and band: clear the band's rows, stream the band's range
-//                            of entries to bin them (one returning LDS atomic on the entry's byte, one atomicMax on the row header:
-//                            the running arg-max), verify the band's own cells under all rotations, stream again to mark
-//                            (an accepted match ORs its rotation bits into its byte of the scale's array, by its ORIGINAL index);
-//   stream_count_kernel      the scales' byte arrays counted by bit: run()'s return value per (scale, rotation);
-//   stream_select_kernel     getInlierMask's strict '>' over the (scale, rotation) counts in the reference's order, the winner's bit of
-//                            every match into the pair's mask;
+//   stream_filter_kernel     one workgroup per (pair, scale, grid type, band of left rows): clear the band's rows, stream the band's
+//                            range of entries to bin them (one returning LDS atomic on the entry's byte, one atomicMax on the row
+//                            header: the running arg-max), verify the band's own cells under all rotations, and leave per own cell
+//                            [E(cellPairs[cell]) | the rotations that accept the pair] in the pair's TABLE of this (scale, grid type):
+//                            400 words -- everything the marking loop of run() needs to know;
+//   stream_mark_kernel       run()'s marking loop for all scales and grid types in ONE pass over the entries (the pair's twenty
+//                            tables in LDS): per match and scale the rotations under which some grid type accepts it, counted per
+//                            (scale, rotation) = run()'s return values;
+//   stream_select_kernel     getInlierMask's strict '>' over the (scale, rotation) counts in the reference's order, then the winner's
+//                            bit of every match (four table look-ups) into the pair's mask, by the match's ORIGINAL index;
 //   band_compact_kernel      (gms_kernel_band.hip) order-preserving copy-out by the mask.
 // Right grids: 10 x 10, 14 x 14 and 20 x 20 fit the LDS whole; 28 x 28 takes three bands of eight rows (+ a halo row either side),
 // 40 x 40 seven bands of three. A band streams only the rows it holds -- not the pair.
@@ -72,7 +75,7 @@ struct StreamWs {
     uint32_t* counts;    // [n][5][8]
     uint32_t* flags;     // [n]
     uint32_t* state;     // [n][4]: best count, scale, rotation
-    uint8_t* rotbits;    // [n][scales][4 grid types][mcap]
+    uint32_t* tables;    // [n][scales][4 grid types][400]: E(cellPairs[cell]) << 8 | the rotations that accept the cell pair (0: none)
     uint8_t* bestmask;   // [n][mcap] (when the caller gave no mask array)
 };
 
@@ -240,8 +243,8 @@ __device__ __forceinline__ void stream_scale(const FilterParams& p, const Stream
         if (flag & (kSFlagDomain | kSFlagGeneral)) return;
     }
     const uint2* __restrict__ ents = w.entries + (size_t)pi * mcap;
-    // the byte array of this (scale, grid type): a match is marked by the one band that owns its left row, so a byte has one writer
-    uint8_t* rb = w.rotbits + (((size_t)pi * n_scales + (n_scales == 5 ? S : 0)) * 4 + (size_t)g) * mcap;
+    // the table of this (scale, grid type): a cell is written by the one band that owns its left row
+    uint32_t* tab = w.tables + (((size_t)pi * n_scales + (n_scales == 5 ? S : 0)) * 4 + (size_t)g) * kLeftN;
 
     const uint8_t* bytes = reinterpret_cast<const uint8_t*>(smem);
     uint16_t* nleft = reinterpret_cast<uint16_t*>(reinterpret_cast<uint8_t*>(smem) + kSNleftOff);
@@ -412,18 +415,10 @@ __device__ __forceinline__ void stream_scale(const FilterParams& p, const Stream
             }
             __syncthreads();
             GMS_SSTAMP(3);   // verify + barrier
-            // ---- mark: cellPairs[l] == r for the entries whose left cell is one of the band's own; the rotations that accept the cell go
-            //      into the match's byte of this (scale, grid type)'s array, by the match's original index
-            stream(row_start[max(lo - 1, 0)], row_start[hi], [] {}, [&](const uint2& e, int) {
-                const uint32_t cw = e.x;
-                const uint32_t l = ((cw >> kSCellShift) & 0x1FFu) + (cw & q_mask);
-                if ((cw & out_mask) == 0u && l - own0 < n_own) {
-                    const uint32_t cr = smem[__umul24(l - cell0, stride) >> 2];
-                    const uint32_t x = cr ^ ((nr + 3u - right_cell<S>(e.y)) << 8);  // < 256: the same right cell, x = the rotations that accept
-                    if (x < 256u && x != 0u) rb[entry_orig(e)] = (uint8_t)x;
-                }
-            });
-            GMS_SSTAMP(4);   // mark
+            // ---- what the marking loop needs of this band: per own cell E(cellPairs[cell]) and the rotations that accept the pair
+            //      (a cell without matches under this grid type still holds the zero of the clear: accepts nothing)
+            for (uint32_t c = (uint32_t)tid; c < n_own; c += 1024u) tab[own0 + c] = smem[(own0 + c - cell0) * (stride >> 2)];
+            GMS_SSTAMP(4);   // table
             GMS_SSTAMP_FLUSH;
         }
     }
@@ -465,46 +460,106 @@ stream_filter_kernel(FilterParams p, StreamWs w, int mcap, int n_scales)
     }
 }
 
-// ---- run()'s return value per (scale, rotation): the bytes of the scales' arrays, counted by bit (grid: 16k-match tiles x scales x pairs)
+// ---- run()'s marking loop for every scale and grid type in one pass over the entries -----------------------------------------------
+namespace {
+constexpr int kSMarkTile = 8192;  // entries per workgroup of the marking / selecting kernels
+
+// the left cell of an entry under the four grid types (kLeftN = "under this grid type the match is outside the left grid": its
+// table slot holds zero)
+__device__ __forceinline__ void left_cells(uint32_t cw, uint32_t (&lg)[4])
+{
+    const uint32_t l1 = (cw >> kSCellShift) & 0x1FFu;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const uint32_t q_mask = (uint32_t)((g & 1) + 20 * (g >> 1));
+        const uint32_t out_mask = (1u << 5) | ((g & 1) ? 1u << 6 : 0u) | ((g >> 1) ? 1u << 7 : 0u);
+        lg[g] = (cw & out_mask) == 0u ? l1 + (cw & q_mask) : (uint32_t)kLeftN;
+    }
+}
+
+// the rotations under which a match is an inlier of scale hypothesis S: cellPairs[l] == r under some grid type, and that cell pair
+// verified (tab = the scale's four tables, kSTabStride words apart)
+constexpr uint32_t kSTabStride = kLeftN + 1;  // (+ the always-zero slot)
+template <int S>
+__device__ __forceinline__ uint32_t inlier_rotations(const uint32_t* tab, uint32_t aux, const uint32_t (&lg)[4])
+{
+    constexpr uint32_t wr = S == 0 ? 20u : S == 1 ? 10u : S == 2 ? 14u : S == 3 ? 28u : 40u, nr = wr * wr;
+    const uint32_t e8 = (nr + 3u - right_cell<S>(aux)) << 8;
+    uint32_t rot = 0;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const uint32_t x = tab[g * kSTabStride + lg[g]] ^ e8;  // < 256: the same right cell, x = the rotations that accept
+        rot |= x < 256u ? x : 0u;
+    }
+    return rot;
+}
+
+__device__ __forceinline__ void load_tables(uint32_t* tab, const uint32_t* src, int n_tables, int tid)
+{
+    for (int i = tid; i < n_tables * (int)kSTabStride; i += 1024) {
+        const int t = i / (int)kSTabStride, c = i - t * (int)kSTabStride;
+        tab[i] = c < kLeftN ? src[t * kLeftN + c] : 0u;
+    }
+}
+}  // namespace
+
 template <bool ROT>
 __global__ void __launch_bounds__(1024)
-stream_count_kernel(FilterParams p, StreamWs w, int mcap, int n_scales)
+stream_mark_kernel(FilterParams p, StreamWs w, int mcap, int n_scales)
 {
-    __shared__ uint32_t cnt[8];
-    const int tile = blockIdx.x, s = blockIdx.y, pi = blockIdx.z, tid = threadIdx.x, lane = tid & 63;
+    __shared__ uint32_t tab[5 * 4 * kSTabStride];
+    __shared__ uint32_t cnt[5 * 4];  // per scale: rotations (0, 2) (1, 3) (4, 6) (5, 7) as two 16-bit fields each
+    const int tile = blockIdx.x, pi = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
     const int m = p.pairs[pi].m;
-    if (m <= 0 || m > mcap || tile * 16384 >= m || (w.flags[pi] & (kSFlagDomain | kSFlagGeneral))) return;
-    constexpr int kNRot = ROT ? 8 : 1;
-    if (tid < 8) cnt[tid] = 0;
+    if (m <= 0 || m > mcap || tile * kSMarkTile >= m || (w.flags[pi] & (kSFlagDomain | kSFlagGeneral))) return;
+    load_tables(tab, w.tables + (size_t)pi * n_scales * 4 * kLeftN, n_scales * 4, tid);
+    if (tid < 20) cnt[tid] = 0;
     __syncthreads();
-    const int first = tile * 16384 + tid * 16;  // 16 consecutive bytes per thread (the arrays are 64-byte aligned, zero beyond m)
-    uint32_t wd[4] = {0u, 0u, 0u, 0u};
-    if (first < m) {
+    const uint2* __restrict__ ents = w.entries + (size_t)pi * mcap;
+    uint32_t acc_lo[5] = {0u, 0u, 0u, 0u, 0u}, acc_hi[5] = {0u, 0u, 0u, 0u, 0u};  // four byte fields each: a thread adds at most eight
+    constexpr int kPer = kSMarkTile / 1024;
+    uint2 e[kPer];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {  // the mask of a hypothesis is the OR over the four grid types (run(), DLL@0x180048ae0)
-            const uint4 v = *reinterpret_cast<const uint4*>(w.rotbits + (((size_t)pi * n_scales + s) * 4 + g) * mcap + first);
-            wd[0] |= v.x;
-            wd[1] |= v.y;
-            wd[2] |= v.z;
-            wd[3] |= v.w;
+    for (int k = 0; k < kPer; ++k) {
+        const int pos = tile * kSMarkTile + k * 1024 + tid;
+        e[k] = pos < m ? ents[pos] : make_uint2(1u << 5, 0u);  // (an entry binned under no grid type)
+    }
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) {
+        uint32_t lg[4];
+        left_cells(e[k].x, lg);
+        auto one = [&](auto sc, int slot) {
+            constexpr int S = decltype(sc)::value;
+            const uint32_t rot = inlier_rotations<S>(tab + slot * 4 * kSTabStride, e[k].y, lg);
+            acc_lo[S] += __umul24(rot & 15u, 0x204081u) & 0x01010101u;  // bit i of the nibble to bit 8 i
+            if (ROT) acc_hi[S] += __umul24(rot >> 4, 0x204081u) & 0x01010101u;
+        };
+        one(std::integral_constant<int, 0>{}, 0);
+        if (n_scales == 5) {
+            one(std::integral_constant<int, 1>{}, 1);
+            one(std::integral_constant<int, 2>{}, 2);
+            one(std::integral_constant<int, 3>{}, 3);
+            one(std::integral_constant<int, 4>{}, 4);
         }
     }
-    uint32_t c[kNRot];
-#pragma unroll
-    for (int r = 0; r < kNRot; ++r) {
-        uint32_t acc = 0;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) acc += (((wd[q] >> r) & 0x01010101u) * 0x01010101u) >> 24;  // bytes with bit r set
-        c[r] = acc;
-    }
-#pragma unroll
-    for (int r = 0; r < kNRot; ++r) {
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) c[r] += __shfl_xor(c[r], d);
-        if (lane == 0 && c[r]) atomicAdd(&cnt[r], c[r]);
+    for (int s = 0; s < n_scales; ++s) {
+        const uint32_t lo = s == 0 ? acc_lo[0] : s == 1 ? acc_lo[1] : s == 2 ? acc_lo[2] : s == 3 ? acc_lo[3] : acc_lo[4];
+        const uint32_t hi = s == 0 ? acc_hi[0] : s == 1 ? acc_hi[1] : s == 2 ? acc_hi[2] : s == 3 ? acc_hi[3] : acc_hi[4];
+        const uint32_t f0 = wave_sum(lo & 0x00FF00FFu), f1 = wave_sum((lo >> 8) & 0x00FF00FFu);
+        if (lane == 0 && f0) atomicAdd(&cnt[s * 4 + 0], f0);
+        if (lane == 0 && f1) atomicAdd(&cnt[s * 4 + 1], f1);
+        if (ROT) {
+            const uint32_t f2 = wave_sum(hi & 0x00FF00FFu), f3 = wave_sum((hi >> 8) & 0x00FF00FFu);
+            if (lane == 0 && f2) atomicAdd(&cnt[s * 4 + 2], f2);
+            if (lane == 0 && f3) atomicAdd(&cnt[s * 4 + 3], f3);
+        }
     }
     __syncthreads();
-    if (tid < kNRot && cnt[tid]) atomicAdd(&w.counts[((size_t)pi * 5 + s) * 8 + tid], cnt[tid]);
+    if (tid < n_scales * 8) {
+        const int s = tid >> 3, r = tid & 7;
+        const uint32_t c = (cnt[s * 4 + (r >> 2) * 2 + (r & 1)] >> ((r & 2) << 3)) & 0xFFFFu;
+        if (c) atomicAdd(&w.counts[((size_t)pi * 5 + s) * 8 + r], c);
+    }
 }
 
 // ---- getInlierMask over the scales' counts; the winner's bit of every match into the pair's mask --------------------------------------
@@ -512,10 +567,11 @@ template <bool ROT>
 __global__ void __launch_bounds__(1024)
 stream_select_kernel(FilterParams p, StreamWs w, int mcap, int n_scales)
 {
+    __shared__ uint32_t tab[4 * kSTabStride];
     const int tile = blockIdx.x, pi = blockIdx.y, tid = threadIdx.x;
     const gms_pair pr = p.pairs[pi];
     const int m = pr.m;
-    if (m <= 0 || m > mcap || (w.flags[pi] & (kSFlagDomain | kSFlagGeneral))) return;
+    if (m <= 0 || m > mcap || tile * kSMarkTile >= m || (w.flags[pi] & (kSFlagDomain | kSFlagGeneral))) return;
     constexpr int kNRot = ROT ? 8 : 1;
     // scale outer, rotation inner, strict '>' from 0 (DLL@0x180047dc0): the first hypothesis with the largest count
     uint32_t best = 0;
@@ -536,9 +592,33 @@ stream_select_kernel(FilterParams p, StreamWs w, int mcap, int n_scales)
         w.state[pi * 4 + 2] = (uint32_t)(br + 1);
     }
     uint8_t* bm = p.mask ? p.mask + pr.match_off : w.bestmask + (size_t)pi * mcap;
-    const uint8_t* rb = w.rotbits + ((size_t)pi * n_scales + (bs < 0 ? 0 : bs)) * 4 * mcap;
-    for (int i = tile * 16384 + tid; i < min(m, (tile + 1) * 16384); i += 1024)
-        bm[i] = bs >= 0 ? ((rb[i] | rb[(size_t)mcap + i] | rb[2 * (size_t)mcap + i] | rb[3 * (size_t)mcap + i]) >> br) & 1u : 0u;
+    const uint2* __restrict__ ents = w.entries + (size_t)pi * mcap;
+    if (bs >= 0) load_tables(tab, w.tables + ((size_t)pi * n_scales + bs) * 4 * kLeftN, 4, tid);
+    __syncthreads();
+    constexpr int kPer = kSMarkTile / 1024;
+    uint2 e[kPer];
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) {
+        const int pos = tile * kSMarkTile + k * 1024 + tid;
+        e[k] = pos < m ? ents[pos] : make_uint2(1u << 5, 0u);
+    }
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) {
+        const int pos = tile * kSMarkTile + k * 1024 + tid;
+        if (pos >= m) continue;
+        uint32_t lg[4];
+        left_cells(e[k].x, lg);
+        uint32_t rot = 0;
+        switch (bs) {  // (workgroup-uniform)
+            case 0: rot = inlier_rotations<0>(tab, e[k].y, lg); break;
+            case 1: rot = inlier_rotations<1>(tab, e[k].y, lg); break;
+            case 2: rot = inlier_rotations<2>(tab, e[k].y, lg); break;
+            case 3: rot = inlier_rotations<3>(tab, e[k].y, lg); break;
+            case 4: rot = inlier_rotations<4>(tab, e[k].y, lg); break;
+            default: break;
+        }
+        bm[entry_orig(e[k])] = bs >= 0 ? (uint8_t)((rot >> br) & 1u) : (uint8_t)0;
+    }
 }
 
 // ================================================================================================================================
@@ -1280,11 +1360,11 @@ int stream_max_matches() { return kSMaxMatches; }
 size_t stream_ws_bytes_per_pair(const FilterParams& p, int mcap, bool need_mask)
 {
     const size_t n_scales = p.with_scale ? 5 : 1;
-    return (size_t)mcap * 8 + (size_t)kFineN * 4 + 64 * 4 + 4 * (size_t)kLeftN * 2 + 5 * 8 * 4 + 4 + 16 + 4 * n_scales * (size_t)mcap +
+    return (size_t)mcap * 8 + (size_t)kFineN * 4 + 64 * 4 + 4 * (size_t)kLeftN * 2 + 5 * 8 * 4 + 4 + 16 + 4 * n_scales * (size_t)kLeftN * 4 +
            (need_mask ? (size_t)mcap : 0) + 128;  // (+ the alignment of the arrays of a slice)
 }
 
-// ws layout for n pairs: entries | nfine | row_cnt | counts | flags | state | nleft | rotbits | bestmask; *flags_out marks the pairs left
+// ws layout for n pairs: entries | nfine | row_cnt | counts | flags | state | tables | nleft | bestmask; *flags_out marks the pairs left
 // to launch_filter_big (bit 1)
 hipError_t launch_filter_stream(const FilterParams& p, int mcap, void* ws, const uint32_t** flags_out, hipStream_t stream)
 {
@@ -1298,7 +1378,7 @@ hipError_t launch_filter_stream(const FilterParams& p, int mcap, void* ws, const
     char* q = reinterpret_cast<char*>(ws);
     w.entries = reinterpret_cast<uint2*>(q);
     q += align16s((size_t)n * mcap * 8);
-    char* zero_from = q;  // everything from here to the entries' end of rotbits starts at zero
+    char* zero_from = q;  // the histograms, counters and flags start at zero (the tables do not need to: every cell has one writer)
     w.nfine = reinterpret_cast<uint32_t*>(q);
     q += (size_t)n * kFineN * 4;
     w.row_cnt = reinterpret_cast<uint32_t*>(q);
@@ -1309,9 +1389,9 @@ hipError_t launch_filter_stream(const FilterParams& p, int mcap, void* ws, const
     q += align16s((size_t)n * 4);
     w.state = reinterpret_cast<uint32_t*>(q);
     q += (size_t)n * 16;
-    w.rotbits = reinterpret_cast<uint8_t*>(q);
-    q += align16s((size_t)n * n_scales * 4 * mcap);
     char* zero_to = q;
+    w.tables = reinterpret_cast<uint32_t*>(q);
+    q += align16s((size_t)n * n_scales * 4 * kLeftN * 4);
     w.nleft = reinterpret_cast<uint16_t*>(q);
     q += align16s((size_t)n * 4 * kLeftN * 2);
     w.bestmask = reinterpret_cast<uint8_t*>(q);
@@ -1321,15 +1401,14 @@ hipError_t launch_filter_stream(const FilterParams& p, int mcap, void* ws, const
     hipLaunchKernelGGL(stream_index_kernel<0>, ig, dim3(1024), 0, stream, p, w, mcap);
     hipLaunchKernelGGL(stream_index_kernel<1>, ig, dim3(1024), 0, stream, p, w, mcap);
     const bool rot = p.with_rotation != 0;
-    const dim3 fg((unsigned)(n_scales == 5 ? kSItemsScales : 4) * (unsigned)n), sg((unsigned)((mcap + 16383) / 16384), (unsigned)n);
-    const dim3 cg((unsigned)((mcap + 16383) / 16384), (unsigned)n_scales, (unsigned)n);
+    const dim3 fg((unsigned)(n_scales == 5 ? kSItemsScales : 4) * (unsigned)n), sg((unsigned)((mcap + kSMarkTile - 1) / kSMarkTile), (unsigned)n);
     if (rot) {
         hipLaunchKernelGGL(stream_filter_kernel<true>, fg, dim3(1024), kSLdsBytes, stream, p, w, mcap, n_scales);
-        hipLaunchKernelGGL(stream_count_kernel<true>, cg, dim3(1024), 0, stream, p, w, mcap, n_scales);
+        hipLaunchKernelGGL(stream_mark_kernel<true>, sg, dim3(1024), 0, stream, p, w, mcap, n_scales);
         hipLaunchKernelGGL(stream_select_kernel<true>, sg, dim3(1024), 0, stream, p, w, mcap, n_scales);
     } else {
         hipLaunchKernelGGL(stream_filter_kernel<false>, fg, dim3(1024), kSLdsBytes, stream, p, w, mcap, n_scales);
-        hipLaunchKernelGGL(stream_count_kernel<false>, cg, dim3(1024), 0, stream, p, w, mcap, n_scales);
+        hipLaunchKernelGGL(stream_mark_kernel<false>, sg, dim3(1024), 0, stream, p, w, mcap, n_scales);
         hipLaunchKernelGGL(stream_select_kernel<false>, sg, dim3(1024), 0, stream, p, w, mcap, n_scales);
     }
     e = launch_band_compact(p, mcap, w.flags, w.bestmask, w.state, stream);

@@ -15,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 capi = importlib.import_module("sfm-gms_amd.capi")
-capi.library_path = lambda: os.path.join(ROOT, "sfm-gms_amd", "csrc", "libgms_hip_diag.so")
+capi.library_path = lambda: os.path.join(ROOT, "sfm-gms_amd", "csrc", os.environ.get("GMS_DIAG_LIB", "libgms_hip_diag.so"))
 import measure_misc as mm  # noqa: E402
 
 m = int(sys.argv[1]) if len(sys.argv) > 1 else 50000
