@@ -64,7 +64,8 @@ static_assert(10u * 20u * (4u + 784u) <= kSMatrixBytes && 5u * 20u * (4u + 1600u
 // (the low 8 bits of x are the dense code word's, the low 21 of y the frame table's scale code as it stands)
 constexpr int kSCellShift = 8, kSOrigShift = 17, kSOrigHiShift = 21;
 constexpr uint32_t kSFlagDomain = 1u, kSFlagGeneral = 2u;  // (the values gms_kernel_band.hip / gms_kernel_big.hip use)
-constexpr int kSItemsScales = 4 * (7 + 3 + 1 + 1 + 1);     // (scale, grid type, band) work items of a pair with scale hypotheses
+constexpr int kSItemsScales = 4 * (7 + 3 + 1);             // (scale, grid type, band) work items of a pair with scale hypotheses (the 10 x 10 and
+                                                           // 14 x 14 grids ride on the 20 x 20 and 28 x 28 items)
 constexpr int kSRowBuckets = 21;                           // 20 left rows + "binned under no grid type"
 
 struct StreamWs {
@@ -219,8 +220,137 @@ stream_index_kernel(FilterParams p, StreamWs w, int mcap)
         if (base + k * 1024 + tid < m) ents[row_start[bucket[k]] + base_g[bucket[k]] + rank[k]] = ent[k];
 }
 
+// ---- verifyCellPairs for the own cells of a band (dense_scales_pair's: two lanes per cell without rotation, four lanes per cell and
+//      two rotations per lane with). The matrix rows are STRIDE bytes apart; a row's header word holds the arg-max key
+//      ((count - 1) << 11 | E, E = WR * WR + 3 - right cell) and receives [E << 8 | the rotations that accept the cell pair].
+//      POOLED: the row holds a finer grid's counts summed two by two (pool_rows below) -- 16-bit entries, the one of right cell
+//      (rx, ry) at byte 4 WR * WR + 2 - 4 WR ry - 2 rx of the row; otherwise bytes, at WR * WR + 3 - (ry WR + rx).
+template <bool ROT, uint32_t WR, uint32_t STRIDE, bool POOLED>
+__device__ __forceinline__ void verify_cells(const FilterParams& p, uint32_t* smem, const uint16_t* nleft, const uint32_t own0, const uint32_t n_own,
+                                             const uint32_t cell0, const bool thr_fast)
+{
+    constexpr uint32_t wr = WR, nr = WR * WR, stride = STRIDE;
+    constexpr uint32_t wr_magic = 65535u / wr + 1u;  // j / wr == (j * magic) >> 16 for j * wr < 65536
+    const int tid = threadIdx.x;
+    const uint8_t* bytes = reinterpret_cast<const uint8_t*>(smem);
+    auto count_at = [&](uint32_t rowb, bool ok, int rx, int ry) -> uint32_t {
+        if (POOLED) return reinterpret_cast<const uint16_t*>(bytes)[(rowb + (ok ? 4u * nr + 2u - 4u * wr * (uint32_t)ry - 2u * (uint32_t)rx : 4u)) >> 1];
+        return bytes[rowb + (ok ? nr + 3u - (uint32_t)(rx + ry * (int)wr) : 4u)];
+    };
+    {
+        constexpr int kNR = ROT ? 2 : 1;
+        constexpr int kLanesPerCell = ROT ? 4 : 2, kCellShift = ROT ? 2 : 1;
+        const int n_items = (int)n_own * kLanesPerCell;
+        for (int item = tid; item < ((n_items + 63) & ~63); item += 1024) {
+            const bool live = item < n_items;
+            const int i = (int)own0 + (live ? (item >> kCellShift) : 0);
+            const int sub = item & (kLanesPerCell - 1);
+            const int half = item & 1;  // !ROT only
+            const int ix = i % kLeftW, iy = i / kLeftW;
+            const uint32_t ni = live ? (uint32_t)nleft[i] : 0u;
+            if (__ballot(ni != 0) == 0ull) continue;  // none of this wave's cells has a match under this grid type
+            const uint32_t hdr = ((uint32_t)i - cell0) * (stride >> 2);
+            const uint32_t best = smem[hdr];  // ((max count - 1) << 11) | E(j*), lowest j* among maxima
+            const uint32_t ej = ni ? (best & 0x7FFu) : nr + 3u;
+            const uint32_t j = nr + 3u - ej;
+            const int jy = (int)((j * wr_magic) >> 16), jx = (int)j - jy * (int)wr;
+            uint32_t score[kNR], tn[kNR], rpack[kNR];  // tn = (sum of nLeft << 4) | numpair
+#pragma unroll
+            for (int jr = 0; jr < kNR; ++jr) {
+                score[jr] = tn[jr] = 0;
+                rpack[jr] = sub == 0 ? rotation_pack(jr) : sub == 1 ? rotation_pack(2 + jr) : sub == 2 ? rotation_pack(4 + jr) : rotation_pack(6 + jr);
+            }
+#pragma unroll
+            for (int c = 0; c < (ROT ? 8 : 4); ++c) {
+                int ldx, ldy;
+                if (ROT) {
+                    const int k = c < 4 ? c : c + 1;
+                    ldx = (k % 3) - 1; ldy = (k / 3) - 1;
+                } else {
+                    ldx = half ? ((c + 5) % 3) - 1 : (c % 3) - 1;
+                    ldy = half ? ((c + 5) / 3) - 1 : (c / 3) - 1;
+                }
+                const int lx = ix + ldx, ly = iy + ldy;
+                const bool okl = ni != 0 && (uint32_t)lx < (uint32_t)kLeftW && (uint32_t)ly < (uint32_t)kLeftH;
+                const uint32_t ll = okl ? (uint32_t)(lx + ly * kLeftW) : (uint32_t)i;  // within one row of an own row: held
+                const uint32_t nll = (uint32_t)nleft[ll];
+                const uint32_t rowb = (ll - cell0) * stride;
+#pragma unroll
+                for (int jr = 0; jr < kNR; ++jr) {
+                    int rdx = ldx, rdy = ldy;
+                    if (ROT) {
+                        rdx = (int)((rpack[jr] >> (4 * c)) & 3u) - 1;
+                        rdy = (int)((rpack[jr] >> (4 * c + 2)) & 3u) - 1;
+                    }
+                    const int rx = jx + rdx, ry = jy + rdy;
+                    const bool okp = okl && (uint32_t)rx < wr && (uint32_t)ry < wr;
+                    const uint32_t cnt = count_at(rowb, okp, rx, ry);
+                    score[jr] += okp ? cnt : 0u;
+                    tn[jr] += okp ? ((nll << 4) | 1u) : 0u;
+                }
+            }
+            uint32_t vbits = 0;
+            if (!ROT) {
+                score[0] += dpp_xor1(score[0]);
+                tn[0] += dpp_xor1(tn[0]);
+            }
+#pragma unroll
+            for (int jr = 0; jr < kNR; ++jr) {
+                const uint32_t sc = score[jr] + (best >> 11) + 1u, t = tn[jr] + ((ni << 4) | 1u);
+                uint32_t pass = 0;
+                if (ni != 0 && (ROT || half == 0)) pass = threshold_rejects(t >> 4, t & 15u, sc, p.threshold_factor, thr_fast) ? 0u : 1u;
+                vbits |= pass << jr;
+            }
+            if (ROT) {  // the cell's four lanes hold rotations (0,1) (2,3) (4,5) (6,7): gather the quad's bit pairs
+                const uint32_t b0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)vbits, 0x00, 0xF, 0xF, false);
+                const uint32_t b1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)vbits, 0x55, 0xF, 0xF, false);
+                const uint32_t b2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)vbits, 0xAA, 0xF, 0xF, false);
+                const uint32_t b3 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)vbits, 0xFF, 0xF, 0xF, false);
+                vbits = b0 | (b1 << 2) | (b2 << 4) | (b3 << 6);
+            }
+            if (ni != 0 && sub == 0) smem[hdr] = (ej << 8) | vbits;  // cellPairs[i] and the rotations that accept it
+        }
+    }
+}
+
+// ---- a finer grid's rows summed two by two: the motion matrix of the 10 x 10 (14 x 14) right grid from the 20 x 20 (28 x 28) one's ----
+// A right cell of the coarse grid is four cells of the fine one (right_cell<1>, <2>), the left grid is the same: the coarse matrix is
+// the fine one pooled along its rows -- no second binning pass. In place: a row's bytes sit at WF * WF + 3 - (y WF + x), so an
+// aligned word holds x = 4 t + 3 ... 4 t of one fine row; the word of row 2 Ry and the one of row 2 Ry + 1 (WF bytes below) add up, byte
+// pairs as 16-bit fields, to the counts of coarse cells (Ry, 2 t) [high half] and (Ry, 2 t + 1) [low half], written back over the first
+// word: nobody else reads or writes it. Sixteen lanes share a row; its arg-max key (count - 1) << 11 | E goes into the row's header.
+template <uint32_t WF>
+__device__ __forceinline__ void pool_rows(uint32_t* smem, const uint32_t n_rows)
+{
+    constexpr uint32_t nrf = WF * WF, stride = 4u + nrf, wc = WF / 2u, nrc = wc * wc, wpr = WF / 4u, upr = wc * wpr;  // words per fine row, units per row
+    static_assert(WF % 4u == 0u && stride % 4u == 0u, "rows are whole words");
+    const uint32_t sub = threadIdx.x & 15u, grp = threadIdx.x >> 4;
+    for (uint32_t row = grp; row < ((n_rows + 3u) & ~3u); row += 64u) {  // (a wave's four groups stay together for the DPP steps)
+        const uint32_t rowb = row * stride;
+        uint32_t best = 0;
+        if (row < n_rows)
+            for (uint32_t u = sub; u < upr; u += 16u) {
+                const uint32_t ry = u / wpr, t = u - ry * wpr;
+                const uint32_t at = (rowb + nrf - 2u * ry * WF - 4u * t) >> 2;
+                const uint32_t a = smem[at], b = smem[at - wpr];
+                const uint32_t sum = (a & 0x00FF00FFu) + ((a >> 8) & 0x00FF00FFu) + (b & 0x00FF00FFu) + ((b >> 8) & 0x00FF00FFu);
+                smem[at] = sum;
+                const uint32_t e0 = nrc + 3u - (ry * wc + 2u * t), c0 = sum >> 16, c1 = sum & 0xFFFFu;
+                if (c0) best = max(best, ((c0 - 1u) << 11) | e0);
+                if (c1) best = max(best, ((c1 - 1u) << 11) | (e0 - 1u));
+            }
+        best = max(best, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)best, 0x111, 0xF, 0xF, true));  // row_shr 1, 2, 4, 8: lane 15 of the
+        best = max(best, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)best, 0x112, 0xF, 0xF, true));  // sixteen ends with their maximum
+        best = max(best, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)best, 0x114, 0xF, 0xF, true));
+        best = max(best, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)best, 0x118, 0xF, 0xF, true));
+        if (row < n_rows && sub == 15u) smem[rowb >> 2] = best;
+    }
+}
+
 // ---- one scale hypothesis of one pair --------------------------------------------------------------------------------------------------
-template <bool ROT, int S>
+// POOL (scales 0 and 3 of a launch with scale hypotheses): the item goes on to the coarser grid whose cells are this one's two by two
+// -- scale 1 after 0, scale 2 after 3 -- on the pooled rows, and leaves that scale's table as well.
+template <bool ROT, int S, bool POOL>
 __device__ __forceinline__ void stream_scale(const FilterParams& p, const StreamWs& w, uint32_t* smem, const int mcap, const int n_scales, const int pi,
                                              const int g, const int band)
 {
@@ -246,7 +376,6 @@ __device__ __forceinline__ void stream_scale(const FilterParams& p, const Stream
     // the table of this (scale, grid type): a cell is written by the one band that owns its left row
     uint32_t* tab = w.tables + (((size_t)pi * n_scales + (n_scales == 5 ? S : 0)) * 4 + (size_t)g) * kLeftN;
 
-    const uint8_t* bytes = reinterpret_cast<const uint8_t*>(smem);
     uint16_t* nleft = reinterpret_cast<uint16_t*>(reinterpret_cast<uint8_t*>(smem) + kSNleftOff);
     uint32_t* row_start = smem + kSRowOff / 4;
     uint32_t* misc = smem + kSMiscOff / 4;
@@ -261,7 +390,6 @@ __device__ __forceinline__ void stream_scale(const FilterParams& p, const Stream
     if (tid < 16) misc[tid] = 0;
 
     constexpr uint32_t wr = S == 0 ? 20u : S == 1 ? 10u : S == 2 ? 14u : S == 3 ? 28u : 40u, nr = wr * wr, stride = 4u + nr;  // (checked by the launcher)
-    constexpr uint32_t wr_magic = 65535u / wr + 1u;  // j / wr == (j * magic) >> 16 for j * wr < 65536
     constexpr int band_rows = S == 4 ? 3 : S == 3 ? 8 : kLeftH;
     const bool thr_fast = threshold_fast_ok(p.threshold_factor);
     static_assert((kLeftH + band_rows - 1) / band_rows == (S == 4 ? 7 : S == 3 ? 3 : 1), "bands per scale as the item table assumes");
@@ -337,88 +465,26 @@ __device__ __forceinline__ void stream_scale(const FilterParams& p, const Stream
                 }
                 return;
             }
-            // ---- verifyCellPairs for the own cells (dense_scales_pair's: two lanes per cell without rotation, four lanes per cell and
-            //      two rotations per lane with)
-            {
-                constexpr int kNR = ROT ? 2 : 1;
-                constexpr int kLanesPerCell = ROT ? 4 : 2, kCellShift = ROT ? 2 : 1;
-                const int n_items = (int)n_own * kLanesPerCell;
-                for (int item = tid; item < ((n_items + 63) & ~63); item += 1024) {
-                    const bool live = item < n_items;
-                    const int i = (int)own0 + (live ? (item >> kCellShift) : 0);
-                    const int sub = item & (kLanesPerCell - 1);
-                    const int half = item & 1;  // !ROT only
-                    const int ix = i % kLeftW, iy = i / kLeftW;
-                    const uint32_t ni = live ? (uint32_t)nleft[i] : 0u;
-                    if (__ballot(ni != 0) == 0ull) continue;  // none of this wave's cells has a match under this grid type
-                    const uint32_t hdr = ((uint32_t)i - cell0) * (stride >> 2);
-                    const uint32_t best = smem[hdr];  // ((max count - 1) << 11) | E(j*), lowest j* among maxima
-                    const uint32_t ej = ni ? (best & 0x7FFu) : nr + 3u;
-                    const uint32_t j = nr + 3u - ej;
-                    const int jy = (int)((j * wr_magic) >> 16), jx = (int)j - jy * (int)wr;
-                    uint32_t score[kNR], tn[kNR], rpack[kNR];  // tn = (sum of nLeft << 4) | numpair
-#pragma unroll
-                    for (int jr = 0; jr < kNR; ++jr) {
-                        score[jr] = tn[jr] = 0;
-                        rpack[jr] = sub == 0 ? rotation_pack(jr) : sub == 1 ? rotation_pack(2 + jr) : sub == 2 ? rotation_pack(4 + jr) : rotation_pack(6 + jr);
-                    }
-#pragma unroll
-                    for (int c = 0; c < (ROT ? 8 : 4); ++c) {
-                        int ldx, ldy;
-                        if (ROT) {
-                            const int k = c < 4 ? c : c + 1;
-                            ldx = (k % 3) - 1; ldy = (k / 3) - 1;
-                        } else {
-                            ldx = half ? ((c + 5) % 3) - 1 : (c % 3) - 1;
-                            ldy = half ? ((c + 5) / 3) - 1 : (c / 3) - 1;
-                        }
-                        const int lx = ix + ldx, ly = iy + ldy;
-                        const bool okl = ni != 0 && (uint32_t)lx < (uint32_t)kLeftW && (uint32_t)ly < (uint32_t)kLeftH;
-                        const uint32_t ll = okl ? (uint32_t)(lx + ly * kLeftW) : (uint32_t)i;  // within one row of an own row: held
-                        const uint32_t nll = (uint32_t)nleft[ll];
-                        const uint32_t rowb = (ll - cell0) * stride;
-#pragma unroll
-                        for (int jr = 0; jr < kNR; ++jr) {
-                            int rdx = ldx, rdy = ldy;
-                            if (ROT) {
-                                rdx = (int)((rpack[jr] >> (4 * c)) & 3u) - 1;
-                                rdy = (int)((rpack[jr] >> (4 * c + 2)) & 3u) - 1;
-                            }
-                            const int rx = jx + rdx, ry = jy + rdy;
-                            const bool okp = okl && (uint32_t)rx < wr && (uint32_t)ry < wr;
-                            const uint32_t cnt = bytes[rowb + (okp ? nr + 3u - (uint32_t)(rx + ry * (int)wr) : 4u)];
-                            score[jr] += okp ? cnt : 0u;
-                            tn[jr] += okp ? ((nll << 4) | 1u) : 0u;
-                        }
-                    }
-                    uint32_t vbits = 0;
-                    if (!ROT) {
-                        score[0] += dpp_xor1(score[0]);
-                        tn[0] += dpp_xor1(tn[0]);
-                    }
-#pragma unroll
-                    for (int jr = 0; jr < kNR; ++jr) {
-                        const uint32_t sc = score[jr] + (best >> 11) + 1u, t = tn[jr] + ((ni << 4) | 1u);
-                        uint32_t pass = 0;
-                        if (ni != 0 && (ROT || half == 0)) pass = threshold_rejects(t >> 4, t & 15u, sc, p.threshold_factor, thr_fast) ? 0u : 1u;
-                        vbits |= pass << jr;
-                    }
-                    if (ROT) {  // the cell's four lanes hold rotations (0,1) (2,3) (4,5) (6,7): gather the quad's bit pairs
-                        const uint32_t b0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)vbits, 0x00, 0xF, 0xF, false);
-                        const uint32_t b1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)vbits, 0x55, 0xF, 0xF, false);
-                        const uint32_t b2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)vbits, 0xAA, 0xF, 0xF, false);
-                        const uint32_t b3 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)vbits, 0xFF, 0xF, 0xF, false);
-                        vbits = b0 | (b1 << 2) | (b2 << 4) | (b3 << 6);
-                    }
-                    if (ni != 0 && sub == 0) smem[hdr] = (ej << 8) | vbits;  // cellPairs[i] and the rotations that accept it
-                }
-            }
+            verify_cells<ROT, wr, stride, false>(p, smem, nleft, own0, n_own, cell0, thr_fast);
             __syncthreads();
             GMS_SSTAMP(3);   // verify + barrier
             // ---- what the marking loop needs of this band: per own cell E(cellPairs[cell]) and the rotations that accept the pair
             //      (a cell without matches under this grid type still holds the zero of the clear: accepts nothing)
             for (uint32_t c = (uint32_t)tid; c < n_own; c += 1024u) tab[own0 + c] = smem[(own0 + c - cell0) * (stride >> 2)];
             GMS_SSTAMP(4);   // table
+            if constexpr (POOL) {
+                static_assert(S == 0 || S == 3, "the grids with a coarser one of half the width");
+                constexpr int kCoarse = S == 0 ? 1 : 2;
+                __syncthreads();  // (the headers have been copied out)
+                pool_rows<wr>(smem, n_held);
+                __syncthreads();
+                GMS_SSTAMP(5);   // pooling + barriers
+                verify_cells<ROT, wr / 2u, stride, true>(p, smem, nleft, own0, n_own, cell0, thr_fast);
+                __syncthreads();
+                uint32_t* tab2 = w.tables + (((size_t)pi * n_scales + kCoarse) * 4 + (size_t)g) * kLeftN;
+                for (uint32_t c = (uint32_t)tid; c < n_own; c += 1024u) tab2[own0 + c] = smem[(own0 + c - cell0) * (stride >> 2)];
+                GMS_SSTAMP(6);   // the coarser scale's verify + table
+            }
             GMS_SSTAMP_FLUSH;
         }
     }
@@ -430,8 +496,9 @@ stream_filter_kernel(FilterParams p, StreamWs w, int mcap, int n_scales)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     // One workgroup per (pair, scale, grid type, band of left rows): all independent (each clears its rows and writes its own cells'
-    // verdicts into its (scale, grid type)'s byte array). Items of a pair in the order 40 x 40 (seven bands x four grid types), 28 x 28
-    // (three x four), then the whole-matrix scales 0, 2, 1 (four each): 52 with scale hypotheses, 4 without.
+    // verdicts into its (scale, grid type)'s table). Items of a pair, longest first: 20 x 20 (four grid types; each goes on to the
+    // 10 x 10 grid on the pooled rows), 28 x 28 (three bands x four; each goes on to 14 x 14), 40 x 40 (seven x four): 44 with scale
+    // hypotheses, 4 without.
     // Workgroups are handed to the eight XCDs round-robin; the items of a pair all stream the pair's entry array, so they are dealt to
     // ONE XCD (its L2 then serves every re-read): workgroup L = 8 slot + xcd works on pair 8 (slot / items) + xcd, item slot % items.
     const int items = n_scales == 5 ? kSItemsScales : 4;
@@ -446,17 +513,13 @@ stream_filter_kernel(FilterParams p, StreamWs w, int mcap, int n_scales)
         item = (L - n8 * items) % items;
     }
     if (n_scales != 5) {
-        stream_scale<ROT, 0>(p, w, smem, mcap, n_scales, pi, item & 3, 0);
-    } else if (item < 28) {
-        stream_scale<ROT, 4>(p, w, smem, mcap, n_scales, pi, item & 3, item >> 2);
-    } else if (item < 40) {
-        stream_scale<ROT, 3>(p, w, smem, mcap, n_scales, pi, (item - 28) & 3, (item - 28) >> 2);
-    } else if (item < 44) {
-        stream_scale<ROT, 0>(p, w, smem, mcap, n_scales, pi, item - 40, 0);
-    } else if (item < 48) {
-        stream_scale<ROT, 2>(p, w, smem, mcap, n_scales, pi, item - 44, 0);
+        stream_scale<ROT, 0, false>(p, w, smem, mcap, n_scales, pi, item & 3, 0);
+    } else if (item < 4) {
+        stream_scale<ROT, 0, true>(p, w, smem, mcap, n_scales, pi, item, 0);
+    } else if (item < 16) {
+        stream_scale<ROT, 3, true>(p, w, smem, mcap, n_scales, pi, (item - 4) & 3, (item - 4) >> 2);
     } else {
-        stream_scale<ROT, 1>(p, w, smem, mcap, n_scales, pi, item - 48, 0);
+        stream_scale<ROT, 4, false>(p, w, smem, mcap, n_scales, pi, (item - 16) & 3, (item - 16) >> 2);
     }
 }
 

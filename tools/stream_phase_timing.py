@@ -22,7 +22,7 @@ m = int(sys.argv[1]) if len(sys.argv) > 1 else 50000
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 lib = mm.pkg.load_library()
 ctx = mm.pkg.GmsContext(0)
-items = 52
+items = 44
 dbuf = torch.zeros(n * items * 8 + 64, dtype=torch.int64, device="cuda:0")
 lib.gms_diag_set_buffer.argtypes = [C.c_void_p]
 lib.gms_diag_set_buffer(dbuf.data_ptr())
@@ -32,14 +32,13 @@ raw = dbuf.cpu().numpy()[: n * items * 8].reshape(-1, 8).astype(np.float64)
 L = np.arange(n * items)
 n8 = n & ~7
 item = np.where(L < n8 * items, (L >> 3) % items, (L - n8 * items) % items)
-names = ["start (pair, flags, row counts)", "clear + barrier", "bin + barrier", "verify + barrier", "mark"]
-classes = {"40x40 band (28 per pair)": item < 28, "28x28 band (12)": (item >= 28) & (item < 40), "20x20 (4)": (item >= 40) & (item < 44),
-           "14x14 (4)": (item >= 44) & (item < 48), "10x10 (4)": item >= 48}
+names = ["start (pair, flags, row counts)", "clear + barrier", "bin + barrier", "verify + barrier", "table", "pooling", "coarser verify + table"]
+classes = {"20x20 -> 10x10 (4 per pair)": item < 4, "28x28 -> 14x14 band (12)": (item >= 4) & (item < 16), "40x40 band (28)": item >= 16}
 out = {"matches": m, "pairs": n, "pairs_per_s": res["pairs_per_s"], "ms_per_launch": res["ms_per_launch"], "by_item_class": {}}
 tot_all = 0.0
 for cname, sel in classes.items():
     mean = raw[sel].mean(axis=0)
-    out["by_item_class"][cname] = {"total_cycles": float(mean[:5].sum()), "phases": {nm: float(v) for nm, v in zip(names, mean[:5])}}
-    tot_all += float(raw[sel][:, :5].sum())
+    out["by_item_class"][cname] = {"total_cycles": float(mean[:7].sum()), "phases": {nm: float(v) for nm, v in zip(names, mean[:7])}}
+    tot_all += float(raw[sel][:, :7].sum())
 out["sum_of_workgroup_cycles_per_pair"] = tot_all / n
 print(json.dumps(out, indent=1))
