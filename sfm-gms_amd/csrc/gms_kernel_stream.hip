@@ -322,28 +322,34 @@ __device__ __forceinline__ void verify_cells(const FilterParams& p, uint32_t* sm
 template <uint32_t WF>
 __device__ __forceinline__ void pool_rows(uint32_t* smem, const uint32_t n_rows)
 {
-    constexpr uint32_t nrf = WF * WF, stride = 4u + nrf, wc = WF / 2u, nrc = wc * wc, wpr = WF / 4u, upr = wc * wpr;  // words per fine row, units per row
+    constexpr uint32_t nrf = WF * WF, stride = 4u + nrf, wc = WF / 2u, nrc = wc * wc, wpr = WF / 4u;  // words per fine row
     static_assert(WF % 4u == 0u && stride % 4u == 0u, "rows are whole words");
-    const uint32_t sub = threadIdx.x & 15u, grp = threadIdx.x >> 4;
+    // of the sixteen lanes of a row, 16 / wpr groups of wpr take coarse rows ph, ph + 16 / wpr, ...: lane (ph, t) walks one column of words
+    constexpr uint32_t kPhases = 16u / wpr;
+    const uint32_t sub = threadIdx.x & 15u, grp = threadIdx.x >> 4, ph = sub / wpr, t = sub - ph * wpr;
     for (uint32_t row = grp; row < ((n_rows + 3u) & ~3u); row += 64u) {  // (a wave's four groups stay together for the DPP steps)
         const uint32_t rowb = row * stride;
-        uint32_t best = 0;
-        if (row < n_rows)
-            for (uint32_t u = sub; u < upr; u += 16u) {
-                const uint32_t ry = u / wpr, t = u - ry * wpr;
-                const uint32_t at = (rowb + nrf - 2u * ry * WF - 4u * t) >> 2;
-                const uint32_t a = smem[at], b = smem[at - wpr];
-                const uint32_t sum = (a & 0x00FF00FFu) + ((a >> 8) & 0x00FF00FFu) + (b & 0x00FF00FFu) + ((b >> 8) & 0x00FF00FFu);
-                smem[at] = sum;
-                const uint32_t e0 = nrc + 3u - (ry * wc + 2u * t), c0 = sum >> 16, c1 = sum & 0xFFFFu;
-                if (c0) best = max(best, ((c0 - 1u) << 11) | e0);
-                if (c1) best = max(best, ((c1 - 1u) << 11) | (e0 - 1u));
+        int best = 0;
+        if (row < n_rows && ph < kPhases) {
+            uint32_t at = (rowb + nrf - 2u * ph * WF - 4u * t) >> 2;
+            int e0 = (int)(nrc + 3u - (ph * wc + 2u * t)) - 2048;  // key = (count << 11) + E - 2048 = (count - 1) << 11 | E; negative for a count of zero
+#pragma unroll
+            for (uint32_t ry = 0; ry < (wc + kPhases - 1u) / kPhases; ++ry) {
+                if (wc % kPhases == 0u || ph + ry * kPhases < wc) {
+                    const uint32_t a = smem[at], b = smem[at - wpr];
+                    const uint32_t sum = (a & 0x00FF00FFu) + ((a >> 8) & 0x00FF00FFu) + (b & 0x00FF00FFu) + ((b >> 8) & 0x00FF00FFu);
+                    smem[at] = sum;
+                    best = max(best, max((int)((sum >> 16) << 11) + e0, (int)((sum & 0xFFFFu) << 11) + e0 - 1));
+                }
+                at -= kPhases * (WF / 2u);
+                e0 -= (int)(kPhases * wc);
             }
-        best = max(best, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)best, 0x111, 0xF, 0xF, true));  // row_shr 1, 2, 4, 8: lane 15 of the
-        best = max(best, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)best, 0x112, 0xF, 0xF, true));  // sixteen ends with their maximum
-        best = max(best, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)best, 0x114, 0xF, 0xF, true));
-        best = max(best, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)best, 0x118, 0xF, 0xF, true));
-        if (row < n_rows && sub == 15u) smem[rowb >> 2] = best;
+        }
+        best = max(best, __builtin_amdgcn_update_dpp(0, best, 0x111, 0xF, 0xF, true));  // row_shr 1, 2, 4, 8: lane 15 of the sixteen ends
+        best = max(best, __builtin_amdgcn_update_dpp(0, best, 0x112, 0xF, 0xF, true));  // with their maximum
+        best = max(best, __builtin_amdgcn_update_dpp(0, best, 0x114, 0xF, 0xF, true));
+        best = max(best, __builtin_amdgcn_update_dpp(0, best, 0x118, 0xF, 0xF, true));
+        if (row < n_rows && sub == 15u) smem[rowb >> 2] = (uint32_t)best;
     }
 }
 
@@ -360,18 +366,6 @@ __device__ __forceinline__ void stream_scale(const FilterParams& p, const Stream
     const gms_pair pr = p.pairs[pi];
     const int m = pr.m;
     if (m <= 0 || m > mcap) return;
-    // One decision for the whole workgroup: the index kernels write this word before the launch, but the pair's OTHER workgroups of this
-    // launch may OR kSFlagGeneral into it at any time (below) -- waves reading it one by one could disagree and a part of the workgroup
-    // would run the barriers alone. One thread reads it into the workgroup's scratch word [15], everybody takes that value.
-    {
-        uint32_t* flag_word = smem + kSMiscOff / 4 + 15;
-        __syncthreads();  // (the previous item of this workgroup is done with its scratch words)
-        if (tid == 0) *flag_word = __hip_atomic_load(&w.flags[pi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __syncthreads();
-        const uint32_t flag = *flag_word;
-        __syncthreads();  // (the words are zeroed below)
-        if (flag & (kSFlagDomain | kSFlagGeneral)) return;
-    }
     const uint2* __restrict__ ents = w.entries + (size_t)pi * mcap;
     // the table of this (scale, grid type): a cell is written by the one band that owns its left row
     uint32_t* tab = w.tables + (((size_t)pi * n_scales + (n_scales == 5 ? S : 0)) * 4 + (size_t)g) * kLeftN;
@@ -379,15 +373,24 @@ __device__ __forceinline__ void stream_scale(const FilterParams& p, const Stream
     uint16_t* nleft = reinterpret_cast<uint16_t*>(reinterpret_cast<uint8_t*>(smem) + kSNleftOff);
     uint32_t* row_start = smem + kSRowOff / 4;
     uint32_t* misc = smem + kSMiscOff / 4;
-    if (tid == 0) {
+    // Wave 0 fetches what the workgroup decides on: the pair's flag word -- the index kernels write it before the launch, but the pair's
+    // OTHER workgroups of this launch may OR kSFlagGeneral into it at any time (below); waves reading it one by one could disagree and a
+    // part of the workgroup would run the barriers alone, so one thread reads it into scratch word [15] and everybody takes that value
+    // behind the first barrier -- and the first entry of every left row (the running sum of the row counts, over the wave's lanes).
+    if (tid < 64) {
         const uint32_t* rc = w.row_cnt + (size_t)pi * 64;
-        uint32_t acc = 0;
-        for (int r = 0; r <= 20; ++r) {
-            row_start[r] = acc;
-            acc += r < 20 ? rc[r] : 0u;
+        const uint32_t flag = tid == 0 ? __hip_atomic_load(&w.flags[pi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+        const uint32_t mine = tid < 20 ? rc[tid] : 0u;
+        uint32_t incl = mine;
+#pragma unroll
+        for (int d = 1; d < 32; d <<= 1) {
+            const uint32_t up = __shfl_up(incl, d);
+            if (tid >= d) incl += up;
         }
+        if (tid <= 20) row_start[tid] = incl - mine;
+        if (tid == 0) misc[15] = flag;
+        if (tid < 15) misc[tid] = 0;
     }
-    if (tid < 16) misc[tid] = 0;
 
     constexpr uint32_t wr = S == 0 ? 20u : S == 1 ? 10u : S == 2 ? 14u : S == 3 ? 28u : 40u, nr = wr * wr, stride = 4u + nr;  // (checked by the launcher)
     constexpr int band_rows = S == 4 ? 3 : S == 3 ? 8 : kLeftH;
@@ -395,14 +398,18 @@ __device__ __forceinline__ void stream_scale(const FilterParams& p, const Stream
     static_assert((kLeftH + band_rows - 1) / band_rows == (S == 4 ? 7 : S == 3 ? 3 : 1), "bands per scale as the item table assumes");
 
     // One pass over the entries at positions [p_lo, p_hi): a thread takes p_lo rounded down to a multiple of 1024, plus tid, plus
-    // 1024 k -- kChunk entries loaded before the first is worked on. body(entry, slot in the chunk).
+    // 1024 k -- kChunk entries loaded before the first is worked on. body(entry, slot in the chunk). The loads are UNCONDITIONAL (a
+    // position outside the range reads the pair's last entry and is turned into "binned under no grid type" afterwards): a load
+    // under a condition is a branch with its own wait, and sixteen of those are sixteen round trips one after the other.
     auto stream = [&](uint32_t p_lo, uint32_t p_hi, auto&& load_done, auto&& body) {
         for (uint32_t pos0 = (p_lo & ~1023u) + (uint32_t)tid; pos0 < p_hi; pos0 += kChunk * 1024u) {
             uint2 e[kChunk];
 #pragma unroll
+            for (int j = 0; j < kChunk; ++j) e[j] = ents[min(pos0 + (uint32_t)j * 1024u, (uint32_t)m - 1u)];
+#pragma unroll
             for (int j = 0; j < kChunk; ++j) {
                 const uint32_t pos = pos0 + (uint32_t)j * 1024u;
-                e[j] = (pos >= p_lo && pos < p_hi) ? ents[pos] : make_uint2(1u << 5, 0u);  // (an entry binned under no grid type)
+                if (!(pos >= p_lo && pos < p_hi)) e[j].x = 1u << 5;
             }
             load_done();
 #pragma unroll
@@ -414,8 +421,8 @@ __device__ __forceinline__ void stream_scale(const FilterParams& p, const Stream
         const int gx = g & 1, gy = g >> 1;
         const uint32_t q_mask = (uint32_t)(gx + 20 * gy);                               // l = l1 + (q & q_mask)
         const uint32_t out_mask = (1u << 5) | (gx ? 1u << 6 : 0u) | (gy ? 1u << 7 : 0u);  // never | x >= 20 | y >= 20 under this grid type
-        if (tid < kLeftN / 2)
-            reinterpret_cast<uint32_t*>(nleft)[tid] = reinterpret_cast<const uint32_t*>(w.nleft + ((size_t)pi * 4 + g) * kLeftN)[tid];
+        if (tid >= 64 && tid < 64 + kLeftN / 2)
+            reinterpret_cast<uint32_t*>(nleft)[tid - 64] = reinterpret_cast<const uint32_t*>(w.nleft + ((size_t)pi * 4 + g) * kLeftN)[tid - 64];
         {
             const int lo = band * band_rows, hi = min(lo + band_rows, kLeftH);          // own rows
             const int hlo = max(lo - 1, 0), hhi = min(hi + 1, kLeftH);                  // rows held (own + halo)
@@ -428,6 +435,7 @@ __device__ __forceinline__ void stream_scale(const FilterParams& p, const Stream
                 for (uint32_t i = tid; i < (n_held * stride + 15u) / 16u; i += 1024) d4[i] = z4;
             }
             __syncthreads();
+            if (misc[15] & (kSFlagDomain | kSFlagGeneral)) return;  // (workgroup-uniform: one word, read behind the barrier)
             GMS_SSTAMP(1);   // clear + barrier
             // ---- assignMatchPairs for the rows held: entries of grid-type-1 rows hlo - 1 (the y-shifted types move a match one row
             //      down) .. hhi - 1. +1 on the entry's byte; the count it produced goes into the row's running arg-max.
@@ -585,7 +593,8 @@ stream_mark_kernel(FilterParams p, StreamWs w, int mcap, int n_scales)
 #pragma unroll
     for (int k = 0; k < kPer; ++k) {
         const int pos = tile * kSMarkTile + k * 1024 + tid;
-        e[k] = pos < m ? ents[pos] : make_uint2(1u << 5, 0u);  // (an entry binned under no grid type)
+        e[k] = ents[min(pos, m - 1)];  // (unconditional loads: all of them in flight together)
+        if (pos >= m) e[k].x = 1u << 5;  // an entry binned under no grid type
     }
 #pragma unroll
     for (int k = 0; k < kPer; ++k) {
@@ -663,7 +672,7 @@ stream_select_kernel(FilterParams p, StreamWs w, int mcap, int n_scales)
 #pragma unroll
     for (int k = 0; k < kPer; ++k) {
         const int pos = tile * kSMarkTile + k * 1024 + tid;
-        e[k] = pos < m ? ents[pos] : make_uint2(1u << 5, 0u);
+        e[k] = ents[min(pos, m - 1)];
     }
 #pragma unroll
     for (int k = 0; k < kPer; ++k) {
