@@ -71,7 +71,7 @@ constexpr int kSRowBuckets = 21;                           // 20 left rows + "bi
 struct StreamWs {
     uint2* entries;      // [n][mcap], sorted by left row
     uint32_t* nfine;     // [n][1600] half-cell histogram
-    uint32_t* row_cnt;   // [n][32]: matches per row bucket; [n][32 + r]: fill cursors
+    uint32_t* row_cnt;   // [n][96]: [r] matches per row bucket; [32 + r] fill cursors; [64 + r] first entry of row r ([64 + 20]: entries binned)
     uint16_t* nleft;     // [n][4][400]
     uint32_t* counts;    // [n][5][8]
     uint32_t* flags;     // [n]
@@ -130,7 +130,7 @@ stream_index_kernel(FilterParams p, StreamWs w, int mcap)
         return;
     }
     if (PASS == 1 && (w.flags[pi] & (kSFlagDomain | kSFlagGeneral))) return;  // (written by pass 0)
-    uint32_t* rc = w.row_cnt + (size_t)pi * 64;
+    uint32_t* rc = w.row_cnt + (size_t)pi * 96;
     if (PASS == 1 && blockIdx.x == 0) {
         // nLeft of every cell under the four grid types (16 bits: a cell above 65 535 matches flags the pair)
         const uint32_t* __restrict__ nf = w.nfine + (size_t)pi * kFineN;
@@ -164,6 +164,7 @@ stream_index_kernel(FilterParams p, StreamWs w, int mcap)
         uint32_t acc = 0;
         for (int r = 0; r < kSRowBuckets; ++r) {
             row_start[r] = acc;
+            if (blockIdx.x == 0) rc[64 + r] = acc;  // (for the filter's workgroups: a band of left rows is a range of entries)
             acc += rc[r];
         }
     }
@@ -360,7 +361,7 @@ template <bool ROT, int S, bool POOL>
 __device__ __forceinline__ void stream_scale(const FilterParams& p, const StreamWs& w, uint32_t* smem, const int mcap, const int n_scales, const int pi,
                                              const int g, const int band)
 {
-    constexpr int kChunk = 16;
+    constexpr int kChunk = 8;  // entries per thread and round; two rounds in flight
     GMS_SSTAMP_DECL
     const int tid = threadIdx.x;
     const gms_pair pr = p.pairs[pi];
@@ -371,49 +372,32 @@ __device__ __forceinline__ void stream_scale(const FilterParams& p, const Stream
     uint32_t* tab = w.tables + (((size_t)pi * n_scales + (n_scales == 5 ? S : 0)) * 4 + (size_t)g) * kLeftN;
 
     uint16_t* nleft = reinterpret_cast<uint16_t*>(reinterpret_cast<uint8_t*>(smem) + kSNleftOff);
-    uint32_t* row_start = smem + kSRowOff / 4;
     uint32_t* misc = smem + kSMiscOff / 4;
-    // Wave 0 fetches what the workgroup decides on: the pair's flag word -- the index kernels write it before the launch, but the pair's
-    // OTHER workgroups of this launch may OR kSFlagGeneral into it at any time (below); waves reading it one by one could disagree and a
-    // part of the workgroup would run the barriers alone, so one thread reads it into scratch word [15] and everybody takes that value
-    // behind the first barrier -- and the first entry of every left row (the running sum of the row counts, over the wave's lanes).
-    if (tid < 64) {
-        const uint32_t* rc = w.row_cnt + (size_t)pi * 64;
-        const uint32_t flag = tid == 0 ? __hip_atomic_load(&w.flags[pi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-        const uint32_t mine = tid < 20 ? rc[tid] : 0u;
-        uint32_t incl = mine;
-#pragma unroll
-        for (int d = 1; d < 32; d <<= 1) {
-            const uint32_t up = __shfl_up(incl, d);
-            if (tid >= d) incl += up;
-        }
-        if (tid <= 20) row_start[tid] = incl - mine;
-        if (tid == 0) misc[15] = flag;
-        if (tid < 15) misc[tid] = 0;
-    }
+    // The pair's flag word: the index kernels write it before the launch, but the pair's OTHER workgroups of this launch may OR
+    // kSFlagGeneral into it at any time (below); waves reading it one by one could disagree and a part of the workgroup would run the
+    // barriers alone, so one thread reads it into scratch word [15] and everybody takes that value behind the first barrier.
+    if (tid == 0) misc[15] = __hip_atomic_load(&w.flags[pi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid < 15) misc[tid] = 0;
+    const uint32_t* __restrict__ first_of_row = w.row_cnt + (size_t)pi * 96 + 64;  // (written by stream_index_kernel<1>)
 
     constexpr uint32_t wr = S == 0 ? 20u : S == 1 ? 10u : S == 2 ? 14u : S == 3 ? 28u : 40u, nr = wr * wr, stride = 4u + nr;  // (checked by the launcher)
     constexpr int band_rows = S == 4 ? 3 : S == 3 ? 8 : kLeftH;
     const bool thr_fast = threshold_fast_ok(p.threshold_factor);
     static_assert((kLeftH + band_rows - 1) / band_rows == (S == 4 ? 7 : S == 3 ? 3 : 1), "bands per scale as the item table assumes");
 
-    // One pass over the entries at positions [p_lo, p_hi): a thread takes p_lo rounded down to a multiple of 1024, plus tid, plus
-    // 1024 k -- kChunk entries loaded before the first is worked on. body(entry, slot in the chunk). The loads are UNCONDITIONAL (a
-    // position outside the range reads the pair's last entry and is turned into "binned under no grid type" afterwards): a load
-    // under a condition is a branch with its own wait, and sixteen of those are sixteen round trips one after the other.
-    auto stream = [&](uint32_t p_lo, uint32_t p_hi, auto&& load_done, auto&& body) {
-        for (uint32_t pos0 = (p_lo & ~1023u) + (uint32_t)tid; pos0 < p_hi; pos0 += kChunk * 1024u) {
-            uint2 e[kChunk];
+    // The entries at positions [p_lo, p_hi): a thread takes p_lo rounded down to a multiple of 1024, plus tid, plus 1024 k, kChunk
+    // entries per round. The loads are UNCONDITIONAL (a position outside the range reads the pair's last entry and is turned into
+    // "binned under no grid type" afterwards): a load under a condition is a branch with its own wait, and sixteen of those are sixteen
+    // round trips one after the other.
+    auto load_chunk = [&](uint2 (&e)[kChunk], uint32_t pos0) {
 #pragma unroll
-            for (int j = 0; j < kChunk; ++j) e[j] = ents[min(pos0 + (uint32_t)j * 1024u, (uint32_t)m - 1u)];
+        for (int j = 0; j < kChunk; ++j) e[j] = ents[min(pos0 + (uint32_t)j * 1024u, (uint32_t)m - 1u)];
+    };
+    auto clip_chunk = [&](uint2 (&e)[kChunk], uint32_t pos0, uint32_t p_lo, uint32_t p_hi) {
 #pragma unroll
-            for (int j = 0; j < kChunk; ++j) {
-                const uint32_t pos = pos0 + (uint32_t)j * 1024u;
-                if (!(pos >= p_lo && pos < p_hi)) e[j].x = 1u << 5;
-            }
-            load_done();
-#pragma unroll
-            for (int j = 0; j < kChunk; ++j) body(e[j], j);
+        for (int j = 0; j < kChunk; ++j) {
+            const uint32_t pos = pos0 + (uint32_t)j * 1024u;
+            if (!(pos >= p_lo && pos < p_hi)) e[j].x = 1u << 5;
         }
     };
 
@@ -428,6 +412,12 @@ __device__ __forceinline__ void stream_scale(const FilterParams& p, const Stream
             const int hlo = max(lo - 1, 0), hhi = min(hi + 1, kLeftH);                  // rows held (own + halo)
             const uint32_t cell0 = (uint32_t)(hlo * kLeftW), n_held = (uint32_t)((hhi - hlo) * kLeftW);
             const uint32_t own0 = (uint32_t)(lo * kLeftW), n_own = (uint32_t)((hi - lo) * kLeftW);
+            // the entries of grid-type-1 rows hlo - 1 (the y-shifted types move a match one row down) .. hhi - 1; the first round of
+            // them is on its way while the rows are cleared
+            const uint32_t p_lo = first_of_row[max(hlo - 1, 0)], p_hi = first_of_row[hhi];
+            uint32_t pos0 = (p_lo & ~1023u) + (uint32_t)tid;
+            uint2 ea[kChunk], eb[kChunk];
+            load_chunk(ea, pos0);
             {   // motion.setTo(0) for the rows held, headers included
                 const uint4 z4 = make_uint4(0, 0, 0, 0);
                 uint4* d4 = reinterpret_cast<uint4*>(smem);
@@ -437,33 +427,45 @@ __device__ __forceinline__ void stream_scale(const FilterParams& p, const Stream
             __syncthreads();
             if (misc[15] & (kSFlagDomain | kSFlagGeneral)) return;  // (workgroup-uniform: one word, read behind the barrier)
             GMS_SSTAMP(1);   // clear + barrier
-            // ---- assignMatchPairs for the rows held: entries of grid-type-1 rows hlo - 1 (the y-shifted types move a match one row
-            //      down) .. hhi - 1. +1 on the entry's byte; the count it produced goes into the row's running arg-max.
+            // ---- assignMatchPairs for the rows held: +1 on the entry's byte; the count it produced goes into the row's running
+            //      arg-max. The next round's entries are requested before this round's atomics.
             {
-                uint32_t old[kChunk], at[kChunk], hdr[kChunk], key[kChunk];
-                stream(row_start[max(hlo - 1, 0)], row_start[hhi], [] {}, [&](const uint2& e, int j) {
-                    const uint32_t cw = e.x;
-                    const uint32_t l = ((cw >> kSCellShift) & 0x1FFu) + (cw & q_mask) - cell0;
-                    const bool in = (cw & out_mask) == 0u && l < n_held;
-                    const uint32_t er = nr + 3u - right_cell<S>(e.y);  // the byte's offset in its row
-                    const uint32_t row = __umul24(l, stride);
-                    at[j] = row + er;
-                    hdr[j] = in ? row : 0xFFFFFFFFu;
-                    key[j] = er;
-                    old[j] = 0u;
-                    if (in) old[j] = atomicAdd(lds_at(smem, at[j] & ~3u), 1u << ((at[j] << 3) & 31u));
-                    if (j == kChunk - 1) {
-                        __builtin_amdgcn_sched_barrier(0);  // all of the chunk's atomics are issued before any result is read
+                auto bin_chunk = [&](const uint2 (&e)[kChunk]) {
+                    uint32_t old[kChunk], at[kChunk], hdr[kChunk], key[kChunk];
 #pragma unroll
-                        for (int c = 0; c < kChunk; ++c) {
-                            const uint32_t before = (old[c] >> ((at[c] << 3) & 31u)) & 255u;
-                            if (hdr[c] != 0xFFFFFFFFu) {
-                                if (before == 255u) misc[8] = 1u;  // the entry's byte has just wrapped
-                                atomicMax(lds_at(smem, hdr[c]), (before << 11) | key[c]);  // highest count, then lowest right cell
-                            }
+                    for (int j = 0; j < kChunk; ++j) {
+                        const uint32_t cw = e[j].x;
+                        const uint32_t l = ((cw >> kSCellShift) & 0x1FFu) + (cw & q_mask) - cell0;
+                        const bool in = (cw & out_mask) == 0u && l < n_held;
+                        const uint32_t er = nr + 3u - right_cell<S>(e[j].y);  // the byte's offset in its row
+                        const uint32_t row = __umul24(l, stride);
+                        at[j] = row + er;
+                        hdr[j] = in ? row : 0xFFFFFFFFu;
+                        key[j] = er;
+                        old[j] = 0u;
+                        if (in) old[j] = atomicAdd(lds_at(smem, at[j] & ~3u), 1u << ((at[j] << 3) & 31u));
+                    }
+                    __builtin_amdgcn_sched_barrier(0);  // all of the round's atomics are issued before any result is read
+#pragma unroll
+                    for (int c = 0; c < kChunk; ++c) {
+                        const uint32_t before = (old[c] >> ((at[c] << 3) & 31u)) & 255u;
+                        if (hdr[c] != 0xFFFFFFFFu) {
+                            if (before == 255u) misc[8] = 1u;  // the entry's byte has just wrapped
+                            atomicMax(lds_at(smem, hdr[c]), (before << 11) | key[c]);  // highest count, then lowest right cell
                         }
                     }
-                });
+                };
+                while (pos0 < p_hi) {  // (per thread: no barrier inside)
+                    const uint32_t pos1 = pos0 + kChunk * 1024u, pos2 = pos1 + kChunk * 1024u;
+                    if (pos1 < p_hi) load_chunk(eb, pos1);
+                    clip_chunk(ea, pos0, p_lo, p_hi);
+                    bin_chunk(ea);
+                    if (pos1 >= p_hi) break;
+                    if (pos2 < p_hi) load_chunk(ea, pos2);
+                    clip_chunk(eb, pos1, p_lo, p_hi);
+                    bin_chunk(eb);
+                    pos0 = pos2;
+                }
             }
             __syncthreads();
             GMS_SSTAMP(2);   // bin + barrier
@@ -1432,7 +1434,7 @@ int stream_max_matches() { return kSMaxMatches; }
 size_t stream_ws_bytes_per_pair(const FilterParams& p, int mcap, bool need_mask)
 {
     const size_t n_scales = p.with_scale ? 5 : 1;
-    return (size_t)mcap * 8 + (size_t)kFineN * 4 + 64 * 4 + 4 * (size_t)kLeftN * 2 + 5 * 8 * 4 + 4 + 16 + 4 * n_scales * (size_t)kLeftN * 4 +
+    return (size_t)mcap * 8 + (size_t)kFineN * 4 + 96 * 4 + 4 * (size_t)kLeftN * 2 + 5 * 8 * 4 + 4 + 16 + 4 * n_scales * (size_t)kLeftN * 4 +
            (need_mask ? (size_t)mcap : 0) + 128;  // (+ the alignment of the arrays of a slice)
 }
 
@@ -1454,7 +1456,7 @@ hipError_t launch_filter_stream(const FilterParams& p, int mcap, void* ws, const
     w.nfine = reinterpret_cast<uint32_t*>(q);
     q += (size_t)n * kFineN * 4;
     w.row_cnt = reinterpret_cast<uint32_t*>(q);
-    q += (size_t)n * 64 * 4;
+    q += (size_t)n * 96 * 4;
     w.counts = reinterpret_cast<uint32_t*>(q);
     q += (size_t)n * 5 * 8 * 4;
     w.flags = reinterpret_cast<uint32_t*>(q);
