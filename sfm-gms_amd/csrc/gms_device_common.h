@@ -152,15 +152,54 @@ __device__ __forceinline__ int64_t uniform(int64_t v)
     const uint32_t lo = (uint32_t)uniform((int)(uint32_t)v), hi = (uint32_t)uniform((int)(uint32_t)((uint64_t)v >> 32));
     return (int64_t)(((uint64_t)hi << 32) | lo);
 }
-__device__ __forceinline__ gms_pair uniform(const gms_pair& pr)
+// A pair's record in scalar registers. Its three 8-byte words are requested TOGETHER and only then moved: a v_readfirstlane per
+// field straight behind each field's load waits for every load in turn -- five round trips at the start of every pair.
+__device__ __forceinline__ gms_pair load_pair(const gms_pair* pairs, int idx)
 {
+    const uint2* __restrict__ q = reinterpret_cast<const uint2*>(pairs + idx);
+    uint2 a = q[0], b = q[1], c = q[2];
+    asm volatile("" : "+v"(a.x), "+v"(a.y), "+v"(b.x), "+v"(c.x), "+v"(c.y));  // (all of them have arrived before the first is used)
     gms_pair u;
-    u.frame_a = uniform(pr.frame_a);
-    u.frame_b = uniform(pr.frame_b);
-    u.m = uniform(pr.m);
+    u.frame_a = uniform((int)a.x);
+    u.frame_b = uniform((int)a.y);
+    u.m = uniform((int)b.x);
     u.reserved = 0;
-    u.match_off = uniform(pr.match_off);
+    u.match_off = (int64_t)(((uint64_t)(uint32_t)uniform((int)c.y) << 32) | (uint32_t)uniform((int)c.x));
     return u;
+}
+
+// The same with the frame table's header word fetched alongside (table_total_kp): one round trip for both.
+__device__ __forceinline__ gms_pair load_pair(const gms_pair* pairs, int idx, const FilterParams& p, int64_t& total_kp)
+{
+    const uint2* __restrict__ q = reinterpret_cast<const uint2*>(pairs + idx);
+    const uint32_t* __restrict__ h = reinterpret_cast<const uint32_t*>(p.pts) - kTableHeaderBytes / 4;
+    uint2 a = q[0], b = q[1], c = q[2];
+    uint2 magic = *reinterpret_cast<const uint2*>(h), total = *reinterpret_cast<const uint2*>(h + 2);
+    asm volatile("" : "+v"(a.x), "+v"(a.y), "+v"(b.x), "+v"(c.x), "+v"(c.y), "+v"(magic.x), "+v"(magic.y), "+v"(total.x), "+v"(total.y));
+    gms_pair u;
+    u.frame_a = uniform((int)a.x);
+    u.frame_b = uniform((int)a.y);
+    u.m = uniform((int)b.x);
+    u.reserved = 0;
+    u.match_off = (int64_t)(((uint64_t)(uint32_t)uniform((int)c.y) << 32) | (uint32_t)uniform((int)c.x));
+    const bool ok = (uint32_t)uniform((int)magic.x) == kTableMagic0 && (uint32_t)uniform((int)magic.y) == kTableMagic1;
+    const int64_t t = (int64_t)(((uint64_t)(uint32_t)uniform((int)total.y) << 32) | (uint32_t)uniform((int)total.x));
+    total_kp = ok ? t : (int64_t)-1;
+    return u;
+}
+
+// first keypoint and number of keypoints of two frames of the table, in scalar registers: four loads requested together (see load_pair)
+__device__ __forceinline__ void load_frame_ranges(const int64_t* frame_off, int fa, int fb, int64_t& offA, int& nA, int64_t& offB, int& nB)
+{
+    const uint2* __restrict__ qa = reinterpret_cast<const uint2*>(frame_off + fa);
+    const uint2* __restrict__ qb = reinterpret_cast<const uint2*>(frame_off + fb);
+    uint2 a0 = qa[0], a1 = qa[1], b0 = qb[0], b1 = qb[1];
+    asm volatile("" : "+v"(a0.x), "+v"(a0.y), "+v"(a1.x), "+v"(a1.y), "+v"(b0.x), "+v"(b0.y), "+v"(b1.x), "+v"(b1.y));
+    auto s64 = [](const uint2& v) { return (int64_t)(((uint64_t)(uint32_t)uniform((int)v.y) << 32) | (uint32_t)uniform((int)v.x)); };
+    offA = s64(a0);
+    offB = s64(b0);
+    nA = (int)(s64(a1) - offA);
+    nB = (int)(s64(b1) - offB);
 }
 
 // lane ^ 1 exchange on the VALU (DPP quad_perm [1,0,3,2]), no LDS round trip

@@ -379,7 +379,8 @@ band_compact_kernel(FilterParams p, const uint32_t* flags, uint8_t* mask_ws, con
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
             const int i = wbase + j * 64 + lane;
-            mb[j] = i < m ? mask[i] : (uint8_t)0;
+            mb[j] = mask[min(i, m - 1)];  // (unconditional loads: sixteen in flight, not sixteen round trips)
+            if (i >= m) mb[j] = (uint8_t)0;
         }
         unsigned long long bal[16];
         uint32_t wave_count = 0;
@@ -401,11 +402,20 @@ band_compact_kernel(FilterParams p, const uint32_t* flags, uint8_t* mask_ws, con
         }
         pos += before_total;
         const unsigned long long lt = (1ull << lane) - 1ull;
+        // the wave's records, eight loads in flight at a time (requested unconditionally and pinned before the stores: a load that
+        // only a conditional store uses is sunk into the branch by the compiler and waited for there, one round trip per record)
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const int i = wbase + j * 64 + lane;
-            if (mb[j]) *reinterpret_cast<uint4*>(&out[pos + (uint32_t)__popcll(bal[j] & lt)]) = *reinterpret_cast<const uint4*>(&matches[i]);
-            pos += (uint32_t)__popcll(bal[j]);
+        for (int h = 0; h < 2; ++h) {
+            uint4 rec[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) rec[j] = *reinterpret_cast<const uint4*>(&matches[min(wbase + (h * 8 + j) * 64 + lane, m - 1)]);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) asm volatile("" : "+v"(rec[j].x), "+v"(rec[j].y), "+v"(rec[j].z), "+v"(rec[j].w));
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                if (mb[h * 8 + j]) *reinterpret_cast<uint4*>(&out[pos + (uint32_t)__popcll(bal[h * 8 + j] & lt)]) = rec[j];
+                pos += (uint32_t)__popcll(bal[h * 8 + j]);
+            }
         }
         total = before_total + tile_total;
     } else if (failed && m > 0 && m <= mcap && p.mask) {

@@ -160,12 +160,17 @@ stream_index_kernel(FilterParams p, StreamWs w, int mcap)
     if (PASS == 0)
         for (int j = tid; j < kFineN; j += 1024) hist[j] = 0;
     if (tid < 32) cnt_l[tid] = 0;
-    if (PASS == 1 && tid == 0) {
-        uint32_t acc = 0;
-        for (int r = 0; r < kSRowBuckets; ++r) {
-            row_start[r] = acc;
-            if (blockIdx.x == 0) rc[64 + r] = acc;  // (for the filter's workgroups: a band of left rows is a range of entries)
-            acc += rc[r];
+    if (PASS == 1 && tid < 64) {  // the first entry of every row bucket: the running sum of the counts, over the lanes of wave 0
+        const uint32_t mine = tid < kSRowBuckets ? rc[tid] : 0u;
+        uint32_t incl = mine;
+#pragma unroll
+        for (int d = 1; d < 32; d <<= 1) {
+            const uint32_t up = __shfl_up(incl, d);
+            if (tid >= d) incl += up;
+        }
+        if (tid < kSRowBuckets) {
+            row_start[tid] = incl - mine;
+            if (blockIdx.x == 0) rc[64 + tid] = incl - mine;  // (for the filter's workgroups: a band of left rows is a range of entries)
         }
     }
     __syncthreads();

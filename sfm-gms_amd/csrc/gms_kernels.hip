@@ -281,7 +281,7 @@ __device__ __forceinline__ void hash_pair(const FilterParams& p, uint32_t* smem,
     const int lane = tid & 63;
     const int wave = tid >> 6;
 
-    const gms_pair pr = uniform(p.pairs[pair_idx]);
+    const gms_pair pr = load_pair(p.pairs, pair_idx);
     const int m = pr.m;
     const gms_dmatch* __restrict__ matches = p.matches + pr.match_off;
 
@@ -321,10 +321,7 @@ __device__ __forceinline__ void hash_pair(const FilterParams& p, uint32_t* smem,
     int64_t offA = 0, offB = 0;
     int nA = 0, nB = 0;
     if (!bad_pair) {  // (pair-uniform values into scalar registers: see uniform())
-        offA = uniform(p.frame_off[pr.frame_a]);
-        offB = uniform(p.frame_off[pr.frame_b]);
-        nA = (int)(uniform(p.frame_off[pr.frame_a + 1]) - offA);
-        nB = (int)(uniform(p.frame_off[pr.frame_b + 1]) - offB);
+        load_frame_ranges(p.frame_off, pr.frame_a, pr.frame_b, offA, nA, offB, nB);
     }
     const float2* __restrict__ ptsA = p.pts + offA;
     const float2* __restrict__ ptsB = p.pts + offB;
@@ -966,17 +963,18 @@ __device__ __forceinline__ bool dense_pair(const FilterParams& p, uint32_t* smem
     const int m_stride = dealt ? (NT / 64) * 8 : NT;
     auto match_of = [&](int k) -> int { return m_base + k * m_stride; };
 
-    const gms_pair pr = uniform(p.pairs[pair_idx]);
+    int64_t total_kp;
+    const gms_pair pr = load_pair(p.pairs, pair_idx, p, total_kp);  // (and the frame table's header word)
     const int m = pr.m;
     if (p.with_scale || p.right_w[0] != kDenseRightW || p.right_h[0] != kDenseRightW || m <= 0 || m > kMcap ||
         pr.frame_a < 0 || pr.frame_a >= p.n_frames || pr.frame_b < 0 || pr.frame_b >= p.n_frames)
         return false;
-    const int64_t offA = uniform(p.frame_off[pr.frame_a]), offB = uniform(p.frame_off[pr.frame_b]);
-    const int nA = (int)(uniform(p.frame_off[pr.frame_a + 1]) - offA), nB = (int)(uniform(p.frame_off[pr.frame_b + 1]) - offB);
+    int64_t offA, offB;
+    int nA, nB;
+    load_frame_ranges(p.frame_off, pr.frame_a, pr.frame_b, offA, nA, offB, nB);
     if (nA <= 0 || nB <= 0) return false;
     const gms_dmatch* __restrict__ matches = p.matches + pr.match_off;
     // the frame table's code words (written by normalize_kernel behind the points): frame A's left codes, frame B's right codes
-    const int64_t total_kp = table_total_kp(p);
     if (total_kp < 0 || offA + nA > total_kp || offB + nB > total_kp) return false;  // (workgroup-uniform) no header, or frames beyond the table
     const uint16_t* __restrict__ lcodeA = reinterpret_cast<const uint16_t*>(p.pts + total_kp) + offA;
     const uint16_t* __restrict__ rcodeB = reinterpret_cast<const uint16_t*>(p.pts + total_kp) + total_kp + offB;
@@ -1031,13 +1029,19 @@ __device__ __forceinline__ bool dense_pair(const FilterParams& p, uint32_t* smem
     {
         const uint4 z4 = make_uint4(0, 0, 0, 0);
         uint4* d4 = reinterpret_cast<uint4*>(smem);
-        for (uint32_t i = staged16 + tid; i < kDenseBytes / 16; i += NT) d4[i] = z4;
+        // (staged: the first kStageRegs * NT slots are written below, codes or zeros)
+        for (uint32_t i = (staged ? max(staged16, (uint32_t)(kStageRegs * NT)) : 0u) + tid; i < kDenseBytes / 16; i += NT) d4[i] = z4;
     }
     if (staged) {
+        // UNCONDITIONAL stores, the data selected: a store under a condition lets the compiler sink its load into the branch, behind
+        // the clear, with a wait of its own -- one round trip per register instead of all of them in flight from the top
+        static_assert((size_t)kStageRegs * NT * 16 <= kDenseBytes, "the register-staged slots lie inside the matrix area");
         uint4* d4 = reinterpret_cast<uint4*>(smem);
 #pragma unroll
-        for (int i = 0; i < kStageRegs; ++i)
-            if ((uint32_t)(i * NT + tid) < qA + qB) d4[i * NT + tid] = tb[i];
+        for (int i = 0; i < kStageRegs; ++i) {
+            const bool in = (uint32_t)(i * NT + tid) < qA + qB;
+            d4[i * NT + tid] = make_uint4(in ? tb[i].x : 0u, in ? tb[i].y : 0u, in ? tb[i].z : 0u, in ? tb[i].w : 0u);
+        }
         for (uint32_t j = kStageRegs * NT + tid; j < qA + qB; j += NT) d4[j] = *(j < qA ? srcA + j : srcB + (j - qA));
     }
     const uint16_t* ldsA = reinterpret_cast<const uint16_t*>(smem) + phA;  // left code of frame A's keypoint q at ldsA[q]
@@ -1484,16 +1488,17 @@ __device__ __forceinline__ bool dense_pair_plain(const FilterParams& p, uint32_t
     // the absolute LDS offsets below assume the dynamic segment starts at 0 (no static LDS in the kernels that call this)
     if ((uint32_t)(uintptr_t)((lds_u32_t*)smem) != 0u) return false;
 
-    const gms_pair pr = uniform(p.pairs[pair_idx]);
+    int64_t total_kp;
+    const gms_pair pr = load_pair(p.pairs, pair_idx, p, total_kp);  // (and the frame table's header word)
     const int m = pr.m;
     if (p.with_scale || p.with_rotation || p.right_w[0] != kDenseRightW || p.right_h[0] != kDenseRightW || m <= 0 || m > kMcap ||
         pr.frame_a < 0 || pr.frame_a >= p.n_frames || pr.frame_b < 0 || pr.frame_b >= p.n_frames)
         return false;
-    const int64_t offA = uniform(p.frame_off[pr.frame_a]), offB = uniform(p.frame_off[pr.frame_b]);
-    const int nA = (int)(uniform(p.frame_off[pr.frame_a + 1]) - offA), nB = (int)(uniform(p.frame_off[pr.frame_b + 1]) - offB);
+    int64_t offA, offB;
+    int nA, nB;
+    load_frame_ranges(p.frame_off, pr.frame_a, pr.frame_b, offA, nA, offB, nB);
     if (nA <= 0 || nB <= 0) return false;
     const gms_dmatch* __restrict__ matches = p.matches + pr.match_off;
-    const int64_t total_kp = table_total_kp(p);
     if (total_kp < 0 || offA + nA > total_kp || offB + nB > total_kp) return false;  // (workgroup-uniform) no header, or frames beyond the table
     const uint16_t* __restrict__ lcodeA = reinterpret_cast<const uint16_t*>(p.pts + total_kp) + offA;
     const uint16_t* __restrict__ rcodeB = reinterpret_cast<const uint16_t*>(p.pts + total_kp) + total_kp + offB;
@@ -1543,13 +1548,19 @@ __device__ __forceinline__ bool dense_pair_plain(const FilterParams& p, uint32_t
     {
         const uint4 z4 = make_uint4(0, 0, 0, 0);
         uint4* d4 = reinterpret_cast<uint4*>(smem);
-        for (uint32_t i = staged16 + tid; i < kDenseBytes / 16; i += NT) d4[i] = z4;
+        // (staged: the first kStageRegs * NT slots are written below, codes or zeros)
+        for (uint32_t i = (staged ? max(staged16, (uint32_t)(kStageRegs * NT)) : 0u) + tid; i < kDenseBytes / 16; i += NT) d4[i] = z4;
     }
     if (staged) {
+        // UNCONDITIONAL stores, the data selected: a store under a condition lets the compiler sink its load into the branch, behind
+        // the clear, with a wait of its own -- one round trip per register instead of all of them in flight from the top
+        static_assert((size_t)kStageRegs * NT * 16 <= kDenseBytes, "the register-staged slots lie inside the matrix area");
         uint4* d4 = reinterpret_cast<uint4*>(smem);
 #pragma unroll
-        for (int i = 0; i < kStageRegs; ++i)
-            if ((uint32_t)(i * NT + tid) < qA + qB) d4[i * NT + tid] = tb[i];
+        for (int i = 0; i < kStageRegs; ++i) {
+            const bool in = (uint32_t)(i * NT + tid) < qA + qB;
+            d4[i * NT + tid] = make_uint4(in ? tb[i].x : 0u, in ? tb[i].y : 0u, in ? tb[i].z : 0u, in ? tb[i].w : 0u);
+        }
         for (uint32_t j = kStageRegs * NT + tid; j < qA + qB; j += NT) d4[j] = *(j < qA ? srcA + j : srcB + (j - qA));
     }
     const uint32_t ldsA = 2u * phA, ldsB = 16u * qA + 2u * phB;  // byte offsets: left code of frame A's keypoint q at ldsA + 2 q
@@ -1637,7 +1648,7 @@ __device__ __forceinline__ bool dense_pair_plain(const FilterParams& p, uint32_t
     {
         const int nxt = pair_idx + p.prefetch_ahead;
         if (p.prefetch_ahead > 0 && nxt < p.n_pairs) {
-            const gms_pair pn = uniform(p.pairs[nxt]);
+            const gms_pair pn = load_pair(p.pairs, nxt);
             // (only what that pair's own workgroup will read as well: a pair it would refuse before reading -- frames out of range,
             //  a negative offset -- is not touched either)
             if (pn.m > 0 && pn.m <= kMcap && pn.match_off >= 0 && pn.frame_a >= 0 && pn.frame_a < p.n_frames && pn.frame_b >= 0 &&
@@ -1998,7 +2009,8 @@ __device__ __forceinline__ bool dense_scales_pair(const FilterParams& p, uint32_
     const int m_stride = dealt ? (NT / 64) * 8 : NT;
     auto match_of = [&](int k) -> int { return m_base + k * m_stride; };
 
-    const gms_pair pr = uniform(p.pairs[pair_idx]);
+    int64_t total_kp;
+    const gms_pair pr = load_pair(p.pairs, pair_idx, p, total_kp);  // (and the frame table's header word)
     const int m = pr.m;
     if (!p.with_scale || m <= 0 || m > kMcap || pr.frame_a < 0 || pr.frame_a >= p.n_frames || pr.frame_b < 0 ||
         pr.frame_b >= p.n_frames)
@@ -2014,7 +2026,6 @@ __device__ __forceinline__ bool dense_scales_pair(const FilterParams& p, uint32_
     if (nA <= 0 || nB <= 0) return false;
     const gms_dmatch* __restrict__ matches = p.matches + pr.match_off;
     // the frame table's code words (normalize_kernel): frame A's left codes (16 bits), frame B's scale codes (32 bits)
-    const int64_t total_kp = table_total_kp(p);
     if (total_kp < 0 || offA + nA > total_kp || offB + nB > total_kp) return false;  // (workgroup-uniform) no header, or frames beyond the table
     const uint16_t* __restrict__ lcodeA = reinterpret_cast<const uint16_t*>(p.pts + total_kp) + offA;
     const uint32_t* __restrict__ scodeB = reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint16_t*>(p.pts + total_kp) + 2 * total_kp) + offB;
@@ -2052,13 +2063,19 @@ __device__ __forceinline__ bool dense_scales_pair(const FilterParams& p, uint32_
     {
         const uint4 z4 = make_uint4(0, 0, 0, 0);
         uint4* d4 = reinterpret_cast<uint4*>(smem);
-        for (uint32_t i = staged16 + tid; i < kDenseBytes / 16; i += NT) d4[i] = z4;
+        // (staged: the first kStageRegs * NT slots are written below, codes or zeros)
+        for (uint32_t i = (staged ? max(staged16, (uint32_t)(kStageRegs * NT)) : 0u) + tid; i < kDenseBytes / 16; i += NT) d4[i] = z4;
     }
     if (staged) {
+        // UNCONDITIONAL stores, the data selected: a store under a condition lets the compiler sink its load into the branch, behind
+        // the clear, with a wait of its own -- one round trip per register instead of all of them in flight from the top
+        static_assert((size_t)kStageRegs * NT * 16 <= kDenseBytes, "the register-staged slots lie inside the matrix area");
         uint4* d4 = reinterpret_cast<uint4*>(smem);
 #pragma unroll
-        for (int i = 0; i < kStageRegs; ++i)
-            if ((uint32_t)(i * NT + tid) < qA + qB) d4[i * NT + tid] = tb[i];
+        for (int i = 0; i < kStageRegs; ++i) {
+            const bool in = (uint32_t)(i * NT + tid) < qA + qB;
+            d4[i * NT + tid] = make_uint4(in ? tb[i].x : 0u, in ? tb[i].y : 0u, in ? tb[i].z : 0u, in ? tb[i].w : 0u);
+        }
         for (uint32_t j = kStageRegs * NT + tid; j < qA + qB; j += NT) d4[j] = *(j < qA ? srcA + j : srcB + (j - qA));
     }
     const uint16_t* ldsA = reinterpret_cast<const uint16_t*>(smem) + phA;  // left code of frame A's keypoint q at ldsA[q]
