@@ -306,7 +306,12 @@ __device__ __forceinline__ void hash_pair(const FilterParams& p, uint32_t* smem,
     // with scale hypotheses the byte-matrix kernel may have evaluated scales 0..2 already (see dense_scales_pair): its
     // record holds the best hypothesis so far, and this kernel continues with scale 3
     const uint32_t* __restrict__ part = p.partial ? p.partial + (size_t)pair_idx * kPartialStrideDw : nullptr;
-    const uint32_t part0 = part != nullptr ? (uint32_t)uniform((int)part[0]) : 0u;  // workgroup-uniform: 0, or what the first kernel decided:
+    uint4 part_hdr = make_uint4(0u, 0u, 0u, 0u);  // (the record's four header words in one load: see load_pair)
+    if (part != nullptr) {
+        part_hdr = *reinterpret_cast<const uint4*>(part);
+        asm volatile("" : "+v"(part_hdr.x), "+v"(part_hdr.y), "+v"(part_hdr.z), "+v"(part_hdr.w));
+    }
+    const uint32_t part0 = (uint32_t)uniform((int)part_hdr.x);  // workgroup-uniform: 0, or what the first kernel decided:
     const int scales_done = (int)(part0 & 15u);                  //   scales 0..3 (4) or all five (5: its probe bounded scale 4 out)
     const bool probed4 = (part0 >> 4) != 0;                      //   "scale 4 was probed and cannot be bounded out"
     const bool resumed = scales_done != 0;
@@ -328,8 +333,8 @@ __device__ __forceinline__ void hash_pair(const FilterParams& p, uint32_t* smem,
     const int mm = bad_pair ? 0 : m;
     const int n_scales = p.with_scale ? 5 : 1;
     const bool thr_fast = threshold_fast_ok(p.threshold_factor);
-    uint32_t best_count = resumed ? (uint32_t)uniform((int)part[1]) : 0u;
-    int best_scale = resumed ? uniform((int)part[2]) : -1, best_rot = resumed ? uniform((int)part[3]) : -1;
+    uint32_t best_count = resumed ? (uint32_t)uniform((int)part_hdr.y) : 0u;
+    int best_scale = resumed ? uniform((int)part_hdr.z) : -1, best_rot = resumed ? uniform((int)part_hdr.w) : -1;
     GMS_STAMP_DECL
     if (mm == 0 || nA <= 0 || nB <= 0) {  // workgroup-uniform: nothing to filter (or nothing valid to index)
         if (tid == 0) {
