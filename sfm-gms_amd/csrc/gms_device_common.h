@@ -188,6 +188,27 @@ __device__ __forceinline__ gms_pair load_pair(const gms_pair* pairs, int idx, co
     return u;
 }
 
+// load_frame_ranges in two halves, for a caller with loads of its own to request in between (they then travel beside these four
+// instead of behind them; the counter of outstanding loads is in order, so theirs must come AFTER these)
+struct FrameRangeWords { uint2 a0, a1, b0, b1; };
+__device__ __forceinline__ FrameRangeWords request_frame_ranges(const int64_t* frame_off, int fa, int fb)
+{
+    const uint2* __restrict__ qa = reinterpret_cast<const uint2*>(frame_off + fa);
+    const uint2* __restrict__ qb = reinterpret_cast<const uint2*>(frame_off + fb);
+    FrameRangeWords w;
+    w.a0 = qa[0]; w.a1 = qa[1]; w.b0 = qb[0]; w.b1 = qb[1];
+    return w;
+}
+__device__ __forceinline__ void take_frame_ranges(FrameRangeWords w, int64_t& offA, int& nA, int64_t& offB, int& nB)
+{
+    asm volatile("" : "+v"(w.a0.x), "+v"(w.a0.y), "+v"(w.a1.x), "+v"(w.a1.y), "+v"(w.b0.x), "+v"(w.b0.y), "+v"(w.b1.x), "+v"(w.b1.y));
+    auto s64 = [](const uint2& v) { return (int64_t)(((uint64_t)(uint32_t)uniform((int)v.y) << 32) | (uint32_t)uniform((int)v.x)); };
+    offA = s64(w.a0);
+    offB = s64(w.b0);
+    nA = (int)(s64(w.a1) - offA);
+    nB = (int)(s64(w.b1) - offB);
+}
+
 // first keypoint and number of keypoints of two frames of the table, in scalar registers: four loads requested together (see load_pair)
 __device__ __forceinline__ void load_frame_ranges(const int64_t* frame_off, int fa, int fb, int64_t& offA, int& nA, int64_t& offB, int& nB)
 {

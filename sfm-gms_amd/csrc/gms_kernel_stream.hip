@@ -7,20 +7,21 @@
 //   stream_index_kernel<0>   per match: its left point's code and its right point's scale code from the frame table (no float ->
 //                            cell arithmetic per pair: normalize_kernel did it per keypoint), the pair's half-cell histogram and the
 //                            number of matches per left-grid ROW;
-//   stream_index_kernel<1>   the same walk again, now placing every entry in the slot of its row: the entry array is sorted by the
-//                            left row of grid type 1, so that a band of left rows is a contiguous range of it (plus nLeft of every
-//                            cell under the four grid types, 16 bits each);
+//   stream_index_kernel<1>   the codes again (as pass 0 stored them: no second gather), now placing every entry in the slot of its
+//                            row: the entry array is sorted by the left row of grid type 1, so that a band of left rows is a
+//                            contiguous range of it (plus nLeft of every cell under the four grid types, 16 bits each);
 //   stream_filter_kernel     one workgroup per (pair, scale, grid type, band of left rows): clear the band's rows, stream the band's
 //                            range of entries to bin them (one returning LDS atomic on the entry's byte, one atomicMax on the row
 //                            header: the running arg-max), verify the band's own cells under all rotations, and leave per own cell
 //                            [E(cellPairs[cell]) | the rotations that accept the pair] in the pair's TABLE of this (scale, grid type):
 //                            400 words -- everything the marking loop of run() needs to know;
-//   stream_mark_kernel       run()'s marking loop for all scales and grid types in ONE pass over the entries (the pair's twenty
-//                            tables in LDS): per match and scale the rotations under which some grid type accepts it, counted per
-//                            (scale, rotation) = run()'s return values;
-//   stream_select_kernel     getInlierMask's strict '>' over the (scale, rotation) counts in the reference's order, then the winner's
-//                            bit of every match (four table look-ups) into the pair's mask, by the match's ORIGINAL index;
-//   band_compact_kernel      (gms_kernel_band.hip) order-preserving copy-out by the mask.
+//   stream_mark_kernel       run()'s marking loop for all scales and grid types in ONE pass over the matches in their original order
+//                            (their codes as stream_index_kernel<0> left them; the pair's twenty tables in LDS): per match and scale
+//                            the rotations under which some grid type accepts it, counted per (scale, rotation) = run()'s return
+//                            values -- per pair, and per tile of 8192 matches;
+//   stream_compact_kernel    getInlierMask's strict '>' over the (scale, rotation) counts in the reference's order, the winner's bit of
+//                            every match of a tile (four table look-ups), the survivors in front of the tile from the tile counts, and
+//                            the order-preserving copy-out.
 // Right grids: 10 x 10, 14 x 14 and 20 x 20 fit the LDS whole; 28 x 28 takes three bands of eight rows (+ a halo row either side),
 // 40 x 40 seven bands of three. A band streams only the rows it holds -- not the pair.
 // An entry that would exceed its byte (more than 255 matches in ONE (left cell, right cell) pair), a left cell above 65 535 matches or
@@ -67,20 +68,21 @@ constexpr uint32_t kSFlagDomain = 1u, kSFlagGeneral = 2u;  // (the values gms_ke
 constexpr int kSItemsScales = 4 * (7 + 3 + 1);             // (scale, grid type, band) work items of a pair with scale hypotheses (the 10 x 10 and
                                                            // 14 x 14 grids ride on the 20 x 20 and 28 x 28 items)
 constexpr int kSRowBuckets = 21;                           // 20 left rows + "binned under no grid type"
+constexpr int kSMarkTile = 8192;                           // matches per workgroup of the marking / compacting kernels
+constexpr int kSTilesMax = kSMaxMatches / kSMarkTile;      // 8
 
 struct StreamWs {
     uint2* entries;      // [n][mcap], sorted by left row
+    uint2* codes;        // [n][mcap], the same words in the matches' original order
     uint32_t* nfine;     // [n][1600] half-cell histogram
     uint32_t* row_cnt;   // [n][96]: [r] matches per row bucket; [32 + r] fill cursors; [64 + r] first entry of row r ([64 + 20]: entries binned)
     uint16_t* nleft;     // [n][4][400]
     uint32_t* counts;    // [n][5][8]
+    uint32_t* tile_cnt;  // [n][kSTilesMax][5][8]: the same per tile of kSMarkTile matches
     uint32_t* flags;     // [n]
-    uint32_t* state;     // [n][4]: best count, scale, rotation
     uint32_t* tables;    // [n][scales][4 grid types][400]: E(cellPairs[cell]) << 8 | the rotations that accept the cell pair (0: none)
-    uint8_t* bestmask;   // [n][mcap] (when the caller gave no mask array)
 };
 
-__device__ __forceinline__ uint32_t entry_orig(const uint2& e) { return (e.x >> kSOrigShift) | ((e.y >> kSOrigHiShift) << 15); }
 
 // E(r) - 3 = nr - r of the entry's right cell under scale hypothesis s (see dense_scales_pair: the coarse grids' cells are halves of
 // the fine ones', the 40 x 40 cell is twice the 20 x 20 one plus a stored bit)
@@ -118,112 +120,122 @@ stream_index_kernel(FilterParams p, StreamWs w, int mcap)
         if (PASS == 0 && blockIdx.x == 0 && tid == 0) atomicOr(&w.flags[pi], kSFlagDomain);
         return;
     }
-    const int64_t offA = p.frame_off[pr.frame_a], offB = p.frame_off[pr.frame_b];
-    const int nA = (int)(p.frame_off[pr.frame_a + 1] - offA), nB = (int)(p.frame_off[pr.frame_b + 1] - offB);
-    const int64_t total_kp = table_total_kp(p);
-    if (m > 0 && (nA <= 0 || nB <= 0)) {  // matches, but nothing valid to index
-        if (PASS == 0 && blockIdx.x == 0 && tid == 0) atomicOr(&w.flags[pi], kSFlagDomain);
-        return;
-    }
-    if (total_kp < 0 || offA + nA > total_kp || offB + nB > total_kp) {  // no code arrays to work from: the general kernel's pair
-        if (PASS == 0 && blockIdx.x == 0 && tid == 0) atomicOr(&w.flags[pi], kSFlagGeneral);
-        return;
-    }
-    if (PASS == 1 && (w.flags[pi] & (kSFlagDomain | kSFlagGeneral))) return;  // (written by pass 0)
     uint32_t* rc = w.row_cnt + (size_t)pi * 96;
-    if (PASS == 1 && blockIdx.x == 0) {
-        // nLeft of every cell under the four grid types (16 bits: a cell above 65 535 matches flags the pair)
-        const uint32_t* __restrict__ nf = w.nfine + (size_t)pi * kFineN;
-        bool big = false;
-        for (int item = tid; item < 4 * kLeftN; item += 1024) {
-            const int g = item / kLeftN, cell = item - g * kLeftN;
-            const int hx0 = 2 * (cell % kLeftW) - (g & 1), hy0 = 2 * (cell / kLeftW) - (g >> 1);
-            uint32_t n = 0;
-#pragma unroll
-            for (int dy = 0; dy < 2; ++dy)
-#pragma unroll
-                for (int dx = 0; dx < 2; ++dx) {
-                    const int hx = hx0 + dx, hy = hy0 + dy;
-                    if (hx >= 0 && hy >= 0) n += nf[hy * kFineW + hx];
-                }
-            big |= n > 65535u;
-            w.nleft[(size_t)pi * 4 * kLeftN + item] = (uint16_t)n;
-        }
-        if (big) atomicOr(&w.flags[pi], kSFlagGeneral);
-    }
+    uint2* codes = w.codes + (size_t)pi * mcap;
     const int base = blockIdx.x * 4096;
-    if (base >= m) return;  // workgroup-uniform
-    const gms_dmatch* __restrict__ matches = p.matches + pr.match_off;
-    const uint16_t* __restrict__ lcode = reinterpret_cast<const uint16_t*>(p.pts + total_kp) + offA;
-    const uint32_t* __restrict__ scode = reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint16_t*>(p.pts + total_kp) + 2 * total_kp) + offB;
-
-    if (PASS == 0)
-        for (int j = tid; j < kFineN; j += 1024) hist[j] = 0;
-    if (tid < 32) cnt_l[tid] = 0;
-    if (PASS == 1 && tid < 64) {  // the first entry of every row bucket: the running sum of the counts, over the lanes of wave 0
-        const uint32_t mine = tid < kSRowBuckets ? rc[tid] : 0u;
-        uint32_t incl = mine;
-#pragma unroll
-        for (int d = 1; d < 32; d <<= 1) {
-            const uint32_t up = __shfl_up(incl, d);
-            if (tid >= d) incl += up;
-        }
-        if (tid < kSRowBuckets) {
-            row_start[tid] = incl - mine;
-            if (blockIdx.x == 0) rc[64 + tid] = incl - mine;  // (for the filter's workgroups: a band of left rows is a range of entries)
-        }
-    }
-    __syncthreads();
-    uint2 qt[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) qt[k] = *reinterpret_cast<const uint2*>(&matches[min(base + k * 1024 + tid, m - 1)]);
-    uint32_t ca[4], cb[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        ca[k] = lcode[min(qt[k].x, (uint32_t)(nA - 1))];
-        cb[k] = scode[min(qt[k].y, (uint32_t)(nB - 1))];
-    }
     bool any_bad = false;
     uint32_t rank[4], bucket[4];
     uint2 ent[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int i = base + k * 1024 + tid;
-        const bool live = i < m;
-        const uint32_t cell = ca[k] >> 7;  // under grid type 1; 510 = binned under no grid type, 511 = outside the parity domain
-        const bool ok = qt[k].x < (uint32_t)nA && qt[k].y < (uint32_t)nB && cell != 511u && (cb[k] >> 31) == 0u;
-        const bool binned = live && ok && cell < 510u;
-        any_bad |= live && !ok;
-        bucket[k] = binned ? cell / (uint32_t)kLeftW : 20u;
-        rank[k] = live ? atomicAdd(&cnt_l[bucket[k]], 1u) : 0u;
-        if (PASS == 0 && binned) {
-            const uint32_t hx = 2u * (cell % (uint32_t)kLeftW) + (ca[k] & 1u), hy = 2u * (cell / (uint32_t)kLeftW) + ((ca[k] >> 2) & 1u);
-            atomicAdd(&hist[hy * kFineW + hx], 1u);
+    if constexpr (PASS == 0) {
+        const int64_t offA = p.frame_off[pr.frame_a], offB = p.frame_off[pr.frame_b];
+        const int nA = (int)(p.frame_off[pr.frame_a + 1] - offA), nB = (int)(p.frame_off[pr.frame_b + 1] - offB);
+        const int64_t total_kp = table_total_kp(p);
+        if (m > 0 && (nA <= 0 || nB <= 0)) {  // matches, but nothing valid to index
+            if (blockIdx.x == 0 && tid == 0) atomicOr(&w.flags[pi], kSFlagDomain);
+            return;
         }
-        // the dense code word's low byte (q as it stands, the two edge bits one place up, "never" for what is not binned), the cell, the index
-        const uint32_t low = binned ? ((ca[k] & 31u) | ((ca[k] & 0x60u) << 1)) : (1u << 5);
-        ent[k].x = low | ((binned ? cell : 0u) << kSCellShift) | (((uint32_t)i & 0x7FFFu) << kSOrigShift);
-        ent[k].y = (cb[k] & 0x1FFFFFu) | (((uint32_t)i >> 15) << kSOrigHiShift);
-    }
-    // an index out of range, a point outside the parity domain or outside one of the right grids: the general kernel decides what the
-    // reference would make of the pair (a domain error, or -- a right coordinate of exactly 1.0 -- a wrapped cell it counts)
-    if (PASS == 0 && any_bad) atomicOr(&w.flags[pi], kSFlagGeneral);
-    __syncthreads();
-    if (PASS == 0) {
+        if (total_kp < 0 || offA + nA > total_kp || offB + nB > total_kp) {  // no code arrays to work from: the general kernel's pair
+            if (blockIdx.x == 0 && tid == 0) atomicOr(&w.flags[pi], kSFlagGeneral);
+            return;
+        }
+        if (base >= m) return;  // workgroup-uniform
+        const gms_dmatch* __restrict__ matches = p.matches + pr.match_off;
+        const uint16_t* __restrict__ lcode = reinterpret_cast<const uint16_t*>(p.pts + total_kp) + offA;
+        const uint32_t* __restrict__ scode = reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint16_t*>(p.pts + total_kp) + 2 * total_kp) + offB;
+        for (int j = tid; j < kFineN; j += 1024) hist[j] = 0;
+        if (tid < 32) cnt_l[tid] = 0;
+        __syncthreads();
+        uint2 qt[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) qt[k] = *reinterpret_cast<const uint2*>(&matches[min(base + k * 1024 + tid, m - 1)]);
+        uint32_t ca[4], cb[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            ca[k] = lcode[min(qt[k].x, (uint32_t)(nA - 1))];
+            cb[k] = scode[min(qt[k].y, (uint32_t)(nB - 1))];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = base + k * 1024 + tid;
+            const bool live = i < m;
+            const uint32_t cell = ca[k] >> 7;  // under grid type 1; 510 = binned under no grid type, 511 = outside the parity domain
+            const bool ok = qt[k].x < (uint32_t)nA && qt[k].y < (uint32_t)nB && cell != 511u && (cb[k] >> 31) == 0u;
+            const bool binned = live && ok && cell < 510u;
+            any_bad |= live && !ok;
+            bucket[k] = binned ? cell / (uint32_t)kLeftW : 20u;
+            if (live) atomicAdd(&cnt_l[bucket[k]], 1u);
+            if (binned) {
+                const uint32_t hx = 2u * (cell % (uint32_t)kLeftW) + (ca[k] & 1u), hy = 2u * (cell / (uint32_t)kLeftW) + ((ca[k] >> 2) & 1u);
+                atomicAdd(&hist[hy * kFineW + hx], 1u);
+            }
+            // the dense code word's low byte (q as it stands, the two edge bits one place up, "never" for what is not binned), the cell, the index
+            const uint32_t low = binned ? ((ca[k] & 31u) | ((ca[k] & 0x60u) << 1)) : (1u << 5);
+            ent[k].x = low | ((binned ? cell : 0u) << kSCellShift) | (((uint32_t)i & 0x7FFFu) << kSOrigShift);
+            ent[k].y = (cb[k] & 0x1FFFFFu) | (((uint32_t)i >> 15) << kSOrigHiShift);
+            if (live) codes[i] = ent[k];  // (for pass 1, the marking pass and the copy-out: nobody gathers a second time)
+        }
+        // an index out of range, a point outside the parity domain or outside one of the right grids: the general kernel decides what
+        // the reference would make of the pair (a domain error, or -- a right coordinate of exactly 1.0 -- a wrapped cell it counts)
+        if (any_bad) atomicOr(&w.flags[pi], kSFlagGeneral);
+        __syncthreads();
         uint32_t* nf = w.nfine + (size_t)pi * kFineN;
         for (int j = tid; j < kFineN; j += 1024)
             if (hist[j]) atomicAdd(&nf[j], hist[j]);
         if (tid < kSRowBuckets && cnt_l[tid]) atomicAdd(&rc[tid], cnt_l[tid]);
-        return;
-    }
-    // this block's entries of a row go behind whatever other blocks have placed there (order inside a row does not matter: every
-    // consumer is a commutative atomic, or a write to the entry's own bits)
-    if (tid < kSRowBuckets) base_g[tid] = cnt_l[tid] ? atomicAdd(&rc[32 + tid], cnt_l[tid]) : 0u;
-    __syncthreads();
-    uint2* ents = w.entries + (size_t)pi * mcap;
+    } else {
+        if (w.flags[pi] & (kSFlagDomain | kSFlagGeneral)) return;  // (written by pass 0)
+        if (blockIdx.x == 0) {
+            // nLeft of every cell under the four grid types (16 bits: a cell above 65 535 matches flags the pair)
+            const uint32_t* __restrict__ nf = w.nfine + (size_t)pi * kFineN;
+            bool big = false;
+            for (int item = tid; item < 4 * kLeftN; item += 1024) {
+                const int g = item / kLeftN, cell = item - g * kLeftN;
+                const int hx0 = 2 * (cell % kLeftW) - (g & 1), hy0 = 2 * (cell / kLeftW) - (g >> 1);
+                uint32_t part[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k)
-        if (base + k * 1024 + tid < m) ents[row_start[bucket[k]] + base_g[bucket[k]] + rank[k]] = ent[k];
+                for (int d = 0; d < 4; ++d) part[d] = nf[max(hy0 + (d >> 1), 0) * kFineW + max(hx0 + (d & 1), 0)];  // (unconditional loads)
+                uint32_t n = 0;
+#pragma unroll
+                for (int d = 0; d < 4; ++d) n += (hx0 + (d & 1) >= 0 && hy0 + (d >> 1) >= 0) ? part[d] : 0u;
+                big |= n > 65535u;
+                w.nleft[(size_t)pi * 4 * kLeftN + item] = (uint16_t)n;
+            }
+            if (big) atomicOr(&w.flags[pi], kSFlagGeneral);
+        }
+        if (base >= m) return;  // workgroup-uniform
+#pragma unroll
+        for (int k = 0; k < 4; ++k) ent[k] = codes[min(base + k * 1024 + tid, m - 1)];
+        if (tid < 32) cnt_l[tid] = 0;
+        if (tid < 64) {  // the first entry of every row bucket: the running sum of the counts, over the lanes of wave 0
+            const uint32_t mine = tid < kSRowBuckets ? rc[tid] : 0u;
+            uint32_t incl = mine;
+#pragma unroll
+            for (int d = 1; d < 32; d <<= 1) {
+                const uint32_t up = __shfl_up(incl, d);
+                if (tid >= d) incl += up;
+            }
+            if (tid < kSRowBuckets) {
+                row_start[tid] = incl - mine;
+                if (blockIdx.x == 0) rc[64 + tid] = incl - mine;  // (for the filter's workgroups: a band of left rows is a range of entries)
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const bool live = base + k * 1024 + tid < m, binned = live && (ent[k].x & (1u << 5)) == 0u;
+            bucket[k] = binned ? ((ent[k].x >> kSCellShift) & 0x1FFu) / (uint32_t)kLeftW : 20u;
+            rank[k] = live ? atomicAdd(&cnt_l[bucket[k]], 1u) : 0u;
+        }
+        __syncthreads();
+        // this block's entries of a row go behind whatever other blocks have placed there (order inside a row does not matter: every
+        // consumer is a commutative atomic)
+        if (tid < kSRowBuckets) base_g[tid] = cnt_l[tid] ? atomicAdd(&rc[32 + tid], cnt_l[tid]) : 0u;
+        __syncthreads();
+        uint2* ents = w.entries + (size_t)pi * mcap;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (base + k * 1024 + tid < m) ents[row_start[bucket[k]] + base_g[bucket[k]] + rank[k]] = ent[k];
+    }
 }
 
 // ---- verifyCellPairs for the own cells of a band (dense_scales_pair's: two lanes per cell without rotation, four lanes per cell and
@@ -231,7 +243,9 @@ stream_index_kernel(FilterParams p, StreamWs w, int mcap)
 //      ((count - 1) << 11 | E, E = WR * WR + 3 - right cell) and receives [E << 8 | the rotations that accept the cell pair].
 //      POOLED: the row holds a finer grid's counts summed two by two (pool_rows below) -- 16-bit entries, the one of right cell
 //      (rx, ry) at byte 4 WR * WR + 2 - 4 WR ry - 2 rx of the row; otherwise bytes, at WR * WR + 3 - (ry WR + rx).
-template <bool ROT, uint32_t WR, uint32_t STRIDE, bool POOLED>
+//      WIDE (with ROT): eight lanes per cell, one rotation each, instead of four with two -- for the bands of few own cells, whose
+//      verification is a chain of latencies on a handful of waves.
+template <bool ROT, uint32_t WR, uint32_t STRIDE, bool POOLED, bool WIDE = false>
 __device__ __forceinline__ void verify_cells(const FilterParams& p, uint32_t* smem, const uint16_t* nleft, const uint32_t own0, const uint32_t n_own,
                                              const uint32_t cell0, const bool thr_fast)
 {
@@ -244,8 +258,9 @@ __device__ __forceinline__ void verify_cells(const FilterParams& p, uint32_t* sm
         return bytes[rowb + (ok ? nr + 3u - (uint32_t)(rx + ry * (int)wr) : 4u)];
     };
     {
-        constexpr int kNR = ROT ? 2 : 1;
-        constexpr int kLanesPerCell = ROT ? 4 : 2, kCellShift = ROT ? 2 : 1;
+        static_assert(ROT || !WIDE, "eight lanes per cell: one per rotation");
+        constexpr int kNR = (ROT && !WIDE) ? 2 : 1;
+        constexpr int kLanesPerCell = ROT ? (WIDE ? 8 : 4) : 2, kCellShift = ROT ? (WIDE ? 3 : 2) : 1;
         const int n_items = (int)n_own * kLanesPerCell;
         for (int item = tid; item < ((n_items + 63) & ~63); item += 1024) {
             const bool live = item < n_items;
@@ -264,7 +279,11 @@ __device__ __forceinline__ void verify_cells(const FilterParams& p, uint32_t* sm
 #pragma unroll
             for (int jr = 0; jr < kNR; ++jr) {
                 score[jr] = tn[jr] = 0;
-                rpack[jr] = sub == 0 ? rotation_pack(jr) : sub == 1 ? rotation_pack(2 + jr) : sub == 2 ? rotation_pack(4 + jr) : rotation_pack(6 + jr);
+                if (WIDE)
+                    rpack[jr] = sub == 0 ? rotation_pack(0) : sub == 1 ? rotation_pack(1) : sub == 2 ? rotation_pack(2) : sub == 3 ? rotation_pack(3)
+                              : sub == 4 ? rotation_pack(4) : sub == 5 ? rotation_pack(5) : sub == 6 ? rotation_pack(6) : rotation_pack(7);
+                else
+                    rpack[jr] = sub == 0 ? rotation_pack(jr) : sub == 1 ? rotation_pack(2 + jr) : sub == 2 ? rotation_pack(4 + jr) : rotation_pack(6 + jr);
             }
 #pragma unroll
             for (int c = 0; c < (ROT ? 8 : 4); ++c) {
@@ -307,7 +326,10 @@ __device__ __forceinline__ void verify_cells(const FilterParams& p, uint32_t* sm
                 if (ni != 0 && (ROT || half == 0)) pass = threshold_rejects(t >> 4, t & 15u, sc, p.threshold_factor, thr_fast) ? 0u : 1u;
                 vbits |= pass << jr;
             }
-            if (ROT) {  // the cell's four lanes hold rotations (0,1) (2,3) (4,5) (6,7): gather the quad's bit pairs
+            if (ROT && WIDE) {  // the cell's eight lanes hold one rotation each: their byte of the wave's ballot
+                const unsigned long long bal = __ballot(vbits != 0u);
+                vbits = (uint32_t)(bal >> (threadIdx.x & 56u)) & 0xFFu;
+            } else if (ROT) {  // the cell's four lanes hold rotations (0,1) (2,3) (4,5) (6,7): gather the quad's bit pairs
                 const uint32_t b0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)vbits, 0x00, 0xF, 0xF, false);
                 const uint32_t b1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)vbits, 0x55, 0xF, 0xF, false);
                 const uint32_t b2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)vbits, 0xAA, 0xF, 0xF, false);
@@ -480,7 +502,7 @@ __device__ __forceinline__ void stream_scale(const FilterParams& p, const Stream
                 }
                 return;
             }
-            verify_cells<ROT, wr, stride, false>(p, smem, nleft, own0, n_own, cell0, thr_fast);
+            verify_cells<ROT, wr, stride, false, ROT && S == 4>(p, smem, nleft, own0, n_own, cell0, thr_fast);
             __syncthreads();
             GMS_SSTAMP(3);   // verify + barrier
             // ---- what the marking loop needs of this band: per own cell E(cellPairs[cell]) and the rotations that accept the pair
@@ -540,8 +562,6 @@ stream_filter_kernel(FilterParams p, StreamWs w, int mcap, int n_scales)
 
 // ---- run()'s marking loop for every scale and grid type in one pass over the entries -----------------------------------------------
 namespace {
-constexpr int kSMarkTile = 8192;  // entries per workgroup of the marking / selecting kernels
-
 // the left cell of an entry under the four grid types (kLeftN = "under this grid type the match is outside the left grid": its
 // table slot holds zero)
 __device__ __forceinline__ void left_cells(uint32_t cw, uint32_t (&lg)[4])
@@ -590,19 +610,19 @@ stream_mark_kernel(FilterParams p, StreamWs w, int mcap, int n_scales)
     const int tile = blockIdx.x, pi = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
     const int m = p.pairs[pi].m;
     if (m <= 0 || m > mcap || tile * kSMarkTile >= m || (w.flags[pi] & (kSFlagDomain | kSFlagGeneral))) return;
-    load_tables(tab, w.tables + (size_t)pi * n_scales * 4 * kLeftN, n_scales * 4, tid);
-    if (tid < 20) cnt[tid] = 0;
-    __syncthreads();
-    const uint2* __restrict__ ents = w.entries + (size_t)pi * mcap;
-    uint32_t acc_lo[5] = {0u, 0u, 0u, 0u, 0u}, acc_hi[5] = {0u, 0u, 0u, 0u, 0u};  // four byte fields each: a thread adds at most eight
+    const uint2* __restrict__ codes = w.codes + (size_t)pi * mcap;
     constexpr int kPer = kSMarkTile / 1024;
     uint2 e[kPer];
 #pragma unroll
     for (int k = 0; k < kPer; ++k) {
-        const int pos = tile * kSMarkTile + k * 1024 + tid;
-        e[k] = ents[min(pos, m - 1)];  // (unconditional loads: all of them in flight together)
-        if (pos >= m) e[k].x = 1u << 5;  // an entry binned under no grid type
+        const int i = tile * kSMarkTile + k * 1024 + tid;
+        e[k] = codes[min(i, m - 1)];  // (unconditional loads: all of them in flight together, under the tables' loads)
+        if (i >= m) e[k].x = 1u << 5;  // an entry binned under no grid type
     }
+    load_tables(tab, w.tables + (size_t)pi * n_scales * 4 * kLeftN, n_scales * 4, tid);
+    if (tid < 20) cnt[tid] = 0;
+    __syncthreads();
+    uint32_t acc_lo[5] = {0u, 0u, 0u, 0u, 0u}, acc_hi[5] = {0u, 0u, 0u, 0u, 0u};  // four byte fields each: a thread adds at most eight
 #pragma unroll
     for (int k = 0; k < kPer; ++k) {
         uint32_t lg[4];
@@ -637,54 +657,74 @@ stream_mark_kernel(FilterParams p, StreamWs w, int mcap, int n_scales)
     if (tid < n_scales * 8) {
         const int s = tid >> 3, r = tid & 7;
         const uint32_t c = (cnt[s * 4 + (r >> 2) * 2 + (r & 1)] >> ((r & 2) << 3)) & 0xFFFFu;
+        w.tile_cnt[(((size_t)pi * kSTilesMax + tile) * 5 + s) * 8 + r] = c;  // (every tile in front of m writes its forty words: no clearing)
         if (c) atomicAdd(&w.counts[((size_t)pi * 5 + s) * 8 + r], c);
     }
 }
 
-// ---- getInlierMask over the scales' counts; the winner's bit of every match into the pair's mask --------------------------------------
+// ---- getInlierMask over the scales' counts, the winner's bit of every match of a tile, the survivors copied out in order -------------
 template <bool ROT>
 __global__ void __launch_bounds__(1024)
-stream_select_kernel(FilterParams p, StreamWs w, int mcap, int n_scales)
+stream_compact_kernel(FilterParams p, StreamWs w, int mcap, int n_scales)
 {
     __shared__ uint32_t tab[4 * kSTabStride];
-    const int tile = blockIdx.x, pi = blockIdx.y, tid = threadIdx.x;
+    __shared__ uint32_t wave_tile[16];
+    const int tile = blockIdx.x, pi = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const gms_pair pr = p.pairs[pi];
     const int m = pr.m;
-    if (m <= 0 || m > mcap || tile * kSMarkTile >= m || (w.flags[pi] & (kSFlagDomain | kSFlagGeneral))) return;
-    constexpr int kNRot = ROT ? 8 : 1;
-    // scale outer, rotation inner, strict '>' from 0 (DLL@0x180047dc0): the first hypothesis with the largest count
-    uint32_t best = 0;
-    int bs = -1, br = -1;
-    for (int s = 0; s < n_scales; ++s)
-#pragma unroll
-        for (int r = 0; r < kNRot; ++r) {
-            const uint32_t c = w.counts[((size_t)pi * 5 + s) * 8 + r];
-            if (c > best) {
-                best = c;
-                bs = s;
-                br = r;
-            }
+    const uint32_t fl = w.flags[pi];
+    if (fl & kSFlagGeneral) return;  // gms_kernel_big.hip produces this pair
+    const bool failed = (fl & kSFlagDomain) != 0 || m < 0 || m > mcap;
+    const int n_tiles = (failed || m <= 0) ? 1 : (m + kSMarkTile - 1) / kSMarkTile;
+    if (tile >= n_tiles) return;
+    if (failed || m <= 0) {  // nothing kept (a pair outside the reference's domain fails as a whole)
+        if (failed && m > 0 && m <= mcap && p.mask) {
+            uint8_t* mask = p.mask + pr.match_off;
+            for (int i = tid; i < m; i += 1024) mask[i] = 0;
         }
-    if (tile == 0 && tid == 0) {
-        w.state[pi * 4 + 0] = best;
-        w.state[pi * 4 + 1] = (uint32_t)bs;
-        w.state[pi * 4 + 2] = (uint32_t)(br + 1);
+        if (tid == 0) {
+            gms_pair_result r;
+            r.n_inliers = 0;
+            r.best_scale = r.best_rot = -1;
+            r.status = failed ? GMS_ERR_DOMAIN : GMS_OK;
+            p.results[pi] = r;
+        }
+        return;
     }
-    uint8_t* bm = p.mask ? p.mask + pr.match_off : w.bestmask + (size_t)pi * mcap;
-    const uint2* __restrict__ ents = w.entries + (size_t)pi * mcap;
-    if (bs >= 0) load_tables(tab, w.tables + ((size_t)pi * n_scales + bs) * 4 * kLeftN, 4, tid);
-    __syncthreads();
     constexpr int kPer = kSMarkTile / 1024;
+    const uint2* __restrict__ codes = w.codes + (size_t)pi * mcap;
+    const gms_dmatch* __restrict__ matches = p.matches + pr.match_off;
+    gms_dmatch* __restrict__ out = p.out + pr.match_off;
+    // a wave owns kPer * 64 consecutive matches of the tile, 64 at a time: loads and stores are coalesced
+    const int wbase = tile * kSMarkTile + wave * (kPer * 64);
     uint2 e[kPer];
 #pragma unroll
-    for (int k = 0; k < kPer; ++k) {
-        const int pos = tile * kSMarkTile + k * 1024 + tid;
-        e[k] = ents[min(pos, m - 1)];
+    for (int k = 0; k < kPer; ++k) e[k] = codes[min(wbase + k * 64 + lane, m - 1)];
+    // scale outer, rotation inner, strict '>' from 0 (DLL@0x180047dc0): the first hypothesis with the largest count. Lane h of every
+    // wave holds hypothesis h = 8 scale + rotation; the largest (count, -h) wins.
+    constexpr int kNRot = ROT ? 8 : 1;
+    uint32_t key = 0;
+    if (lane < 40 && (lane >> 3) < n_scales && (lane & 7) < kNRot) {
+        const uint32_t c = w.counts[(size_t)pi * 40 + lane];
+        key = c ? (c << 6) | (uint32_t)(63 - lane) : 0u;
     }
 #pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) key = max(key, (uint32_t)__shfl_xor((int)key, d));
+    const uint32_t best = key >> 6;
+    const int bh = key ? 63 - (int)(key & 63u) : -1, bs = bh < 0 ? -1 : bh >> 3, br = bh < 0 ? -1 : bh & 7;
+    // survivors in front of this tile: the winner's counts of the tiles before it
+    uint32_t before = 0;
+    if (bh >= 0) {
+        const uint32_t mine = lane < tile ? w.tile_cnt[((size_t)pi * kSTilesMax + lane) * 40 + bh] : 0u;
+        before = wave_sum(mine);
+        load_tables(tab, w.tables + ((size_t)pi * n_scales + bs) * 4 * kLeftN, 4, tid);
+    }
+    __syncthreads();
+    unsigned long long bal[kPer];
+    uint32_t wave_count = 0;
+#pragma unroll
     for (int k = 0; k < kPer; ++k) {
-        const int pos = tile * kSMarkTile + k * 1024 + tid;
-        if (pos >= m) continue;
+        const int i = wbase + k * 64 + lane;
         uint32_t lg[4];
         left_cells(e[k].x, lg);
         uint32_t rot = 0;
@@ -696,7 +736,35 @@ stream_select_kernel(FilterParams p, StreamWs w, int mcap, int n_scales)
             case 4: rot = inlier_rotations<4>(tab, e[k].y, lg); break;
             default: break;
         }
-        bm[entry_orig(e[k])] = bs >= 0 ? (uint8_t)((rot >> br) & 1u) : (uint8_t)0;
+        const bool keep = i < m && bs >= 0 && ((rot >> br) & 1u) != 0u;
+        if (p.mask && i < m) p.mask[pr.match_off + i] = keep ? 1 : 0;
+        bal[k] = __ballot(keep);
+        wave_count += (uint32_t)__popcll(bal[k]);
+    }
+    if (lane == 0) wave_tile[wave] = wave_count;
+    __syncthreads();
+    uint32_t pos = before;
+    for (int wv = 0; wv < wave; ++wv) pos += wave_tile[wv];
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    // the wave's records, all requested before the first store (a load that only a conditional store uses is sunk into the branch by
+    // the compiler and waited for there, one round trip per record)
+    uint4 rec[kPer];
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) rec[k] = *reinterpret_cast<const uint4*>(&matches[min(wbase + k * 64 + lane, m - 1)]);
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) asm volatile("" : "+v"(rec[k].x), "+v"(rec[k].y), "+v"(rec[k].z), "+v"(rec[k].w));
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) {
+        if ((bal[k] >> lane) & 1ull) *reinterpret_cast<uint4*>(&out[pos + (uint32_t)__popcll(bal[k] & lt)]) = rec[k];
+        pos += (uint32_t)__popcll(bal[k]);
+    }
+    if (tid == 0 && tile == n_tiles - 1) {
+        gms_pair_result r;
+        r.n_inliers = (int)best;
+        r.best_scale = best == 0 ? -1 : bs;
+        r.best_rot = best == 0 ? -1 : br + 1;
+        r.status = GMS_OK;
+        p.results[pi] = r;
     }
 }
 
@@ -1436,14 +1504,14 @@ hipError_t init_stream_kernels()  // once per context: see init_filter_kernels
 int stream_max_matches() { return kSMaxMatches; }
 
 
-size_t stream_ws_bytes_per_pair(const FilterParams& p, int mcap, bool need_mask)
+size_t stream_ws_bytes_per_pair(const FilterParams& p, int mcap, bool)
 {
     const size_t n_scales = p.with_scale ? 5 : 1;
-    return (size_t)mcap * 8 + (size_t)kFineN * 4 + 96 * 4 + 4 * (size_t)kLeftN * 2 + 5 * 8 * 4 + 4 + 16 + 4 * n_scales * (size_t)kLeftN * 4 +
-           (need_mask ? (size_t)mcap : 0) + 128;  // (+ the alignment of the arrays of a slice)
+    return (size_t)mcap * 16 + (size_t)kFineN * 4 + 96 * 4 + 4 * (size_t)kLeftN * 2 + 5 * 8 * 4 + (size_t)kSTilesMax * 5 * 8 * 4 + 4 +
+           4 * n_scales * (size_t)kLeftN * 4 + 128;  // (+ the alignment of the arrays of a slice)
 }
 
-// ws layout for n pairs: entries | nfine | row_cnt | counts | flags | state | tables | nleft | bestmask; *flags_out marks the pairs left
+// ws layout for n pairs: entries | codes | nfine | row_cnt | counts | flags | tile_cnt | tables | nleft; *flags_out marks the pairs left
 // to launch_filter_big (bit 1)
 hipError_t launch_filter_stream(const FilterParams& p, int mcap, void* ws, const uint32_t** flags_out, hipStream_t stream)
 {
@@ -1457,7 +1525,9 @@ hipError_t launch_filter_stream(const FilterParams& p, int mcap, void* ws, const
     char* q = reinterpret_cast<char*>(ws);
     w.entries = reinterpret_cast<uint2*>(q);
     q += align16s((size_t)n * mcap * 8);
-    char* zero_from = q;  // the histograms, counters and flags start at zero (the tables do not need to: every cell has one writer)
+    w.codes = reinterpret_cast<uint2*>(q);
+    q += align16s((size_t)n * mcap * 8);
+    char* zero_from = q;  // the histograms, counters and flags start at zero (tables and tile counts do not need to: every word has one writer)
     w.nfine = reinterpret_cast<uint32_t*>(q);
     q += (size_t)n * kFineN * 4;
     w.row_cnt = reinterpret_cast<uint32_t*>(q);
@@ -1466,14 +1536,12 @@ hipError_t launch_filter_stream(const FilterParams& p, int mcap, void* ws, const
     q += (size_t)n * 5 * 8 * 4;
     w.flags = reinterpret_cast<uint32_t*>(q);
     q += align16s((size_t)n * 4);
-    w.state = reinterpret_cast<uint32_t*>(q);
-    q += (size_t)n * 16;
     char* zero_to = q;
+    w.tile_cnt = reinterpret_cast<uint32_t*>(q);
+    q += (size_t)n * kSTilesMax * 5 * 8 * 4;
     w.tables = reinterpret_cast<uint32_t*>(q);
     q += align16s((size_t)n * n_scales * 4 * kLeftN * 4);
     w.nleft = reinterpret_cast<uint16_t*>(q);
-    q += align16s((size_t)n * 4 * kLeftN * 2);
-    w.bestmask = reinterpret_cast<uint8_t*>(q);
     hipError_t e = hipMemsetAsync(zero_from, 0, (size_t)(zero_to - zero_from), stream);
     if (e != hipSuccess) return e;
     const dim3 ig((unsigned)((mcap + 4095) / 4096), (unsigned)n);
@@ -1484,15 +1552,14 @@ hipError_t launch_filter_stream(const FilterParams& p, int mcap, void* ws, const
     if (rot) {
         hipLaunchKernelGGL(stream_filter_kernel<true>, fg, dim3(1024), kSLdsBytes, stream, p, w, mcap, n_scales);
         hipLaunchKernelGGL(stream_mark_kernel<true>, sg, dim3(1024), 0, stream, p, w, mcap, n_scales);
-        hipLaunchKernelGGL(stream_select_kernel<true>, sg, dim3(1024), 0, stream, p, w, mcap, n_scales);
+        hipLaunchKernelGGL(stream_compact_kernel<true>, sg, dim3(1024), 0, stream, p, w, mcap, n_scales);
     } else {
         hipLaunchKernelGGL(stream_filter_kernel<false>, fg, dim3(1024), kSLdsBytes, stream, p, w, mcap, n_scales);
         hipLaunchKernelGGL(stream_mark_kernel<false>, sg, dim3(1024), 0, stream, p, w, mcap, n_scales);
-        hipLaunchKernelGGL(stream_select_kernel<false>, sg, dim3(1024), 0, stream, p, w, mcap, n_scales);
+        hipLaunchKernelGGL(stream_compact_kernel<false>, sg, dim3(1024), 0, stream, p, w, mcap, n_scales);
     }
-    e = launch_band_compact(p, mcap, w.flags, w.bestmask, w.state, stream);
     *flags_out = w.flags;
-    return e != hipSuccess ? e : hipGetLastError();
+    return hipGetLastError();
 }
 
 }  // namespace gms

@@ -1499,11 +1499,26 @@ __device__ __forceinline__ bool dense_pair_plain(const FilterParams& p, uint32_t
     if (p.with_scale || p.with_rotation || p.right_w[0] != kDenseRightW || p.right_h[0] != kDenseRightW || m <= 0 || m > kMcap ||
         pr.frame_a < 0 || pr.frame_a >= p.n_frames || pr.frame_b < 0 || pr.frame_b >= p.n_frames)
         return false;
+    // the frame ranges and, right behind them, the pair's DMatch records: the records do not depend on the ranges, so they travel
+    // beside them instead of a round trip later.
+    // The records of a thread's first kKeep matches stay in registers from here to the copy-out (all of them up to ten matches per
+    // thread; at sixteen the first twelve: 16 384 matches per pair 5.58 M pairs/s keeping none, 6.06 M keeping eight, 6.41 M twelve,
+    // 6.67 M fourteen -- with 8 bytes of scratch --, 6.21 M all sixteen with 36); the others are loaded as (queryIdx, trainIdx) alone and
+    // the survivors among them are read again at the end.
+    const FrameRangeWords fr_words = request_frame_ranges(p.frame_off, pr.frame_a, pr.frame_b);
+    const gms_dmatch* __restrict__ matches = p.matches + pr.match_off;
+    constexpr int kKeep = KPT <= 10 ? KPT : (DEALT ? 10 : 12);  // (the dealt instantiation has two registers less to spare)
+    uint4 rec[kKeep];
+    uint2 qt[KPT > kKeep ? KPT - kKeep : 1];
+#pragma unroll
+    for (int k = 0; k < KPT; ++k) {
+        if (k < kKeep) { const u32x4_t rv = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(&matches[min(match_of(k), m - 1)])); rec[k] = make_uint4(rv.x, rv.y, rv.z, rv.w); }
+        else qt[k - kKeep] = *reinterpret_cast<const uint2*>(&matches[min(match_of(k), m - 1)]);
+    }
     int64_t offA, offB;
     int nA, nB;
-    load_frame_ranges(p.frame_off, pr.frame_a, pr.frame_b, offA, nA, offB, nB);
+    take_frame_ranges(fr_words, offA, nA, offB, nB);
     if (nA <= 0 || nB <= 0) return false;
-    const gms_dmatch* __restrict__ matches = p.matches + pr.match_off;
     if (total_kp < 0 || offA + nA > total_kp || offB + nB > total_kp) return false;  // (workgroup-uniform) no header, or frames beyond the table
     const uint16_t* __restrict__ lcodeA = reinterpret_cast<const uint16_t*>(p.pts + total_kp) + offA;
     const uint16_t* __restrict__ rcodeB = reinterpret_cast<const uint16_t*>(p.pts + total_kp) + total_kp + offB;
@@ -1534,18 +1549,6 @@ __device__ __forceinline__ bool dense_pair_plain(const FilterParams& p, uint32_t
         const uint32_t j = min((uint32_t)(i * NT + tid), qA + qB - 1u);
         const uint4* src = j < qA ? srcA + j : srcB + (j - qA);
         tb[i] = *src;
-    }
-    // The records of a thread's first kKeep matches stay in registers from here to the copy-out (all of them up to ten matches per
-    // thread; at sixteen the first twelve: 16 384 matches per pair 5.58 M pairs/s keeping none, 6.06 M keeping eight, 6.41 M twelve,
-    // 6.67 M fourteen -- with 8 bytes of scratch --, 6.21 M all sixteen with 36); the others are loaded as (queryIdx, trainIdx) alone and
-    // the survivors among them are read again at the end.
-    constexpr int kKeep = KPT <= 10 ? KPT : (DEALT ? 10 : 12);  // (the dealt instantiation has two registers less to spare)
-    uint4 rec[kKeep];
-    uint2 qt[KPT > kKeep ? KPT - kKeep : 1];
-#pragma unroll
-    for (int k = 0; k < KPT; ++k) {
-        if (k < kKeep) { const u32x4_t rv = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(&matches[min(match_of(k), m - 1)])); rec[k] = make_uint4(rv.x, rv.y, rv.z, rv.w); }
-        else qt[k - kKeep] = *reinterpret_cast<const uint2*>(&matches[min(match_of(k), m - 1)]);
     }
     auto query_of = [&](int k) -> uint32_t { return k < kKeep ? rec[k < kKeep ? k : 0].x : qt[k < kKeep ? 0 : k - kKeep].x; };
     auto train_of = [&](int k) -> uint32_t { return k < kKeep ? rec[k < kKeep ? k : 0].y : qt[k < kKeep ? 0 : k - kKeep].y; };
