@@ -8,8 +8,9 @@
 //                            cell arithmetic per pair: normalize_kernel did it per keypoint), the pair's half-cell histogram and the
 //                            number of matches per left-grid ROW;
 //   stream_index_kernel<1>   the codes again (as pass 0 stored them: no second gather), now placing every entry in the slot of its
-//                            row: the entry array is sorted by the left row of grid type 1, so that a band of left rows is a
-//                            contiguous range of it (plus nLeft of every cell under the four grid types, 16 bits each);
+//                            half row: the entry array is sorted by the left HALF row (2 x row under grid type 1 + the y parity), so
+//                            that a band of left rows under any grid type is a contiguous range of it (plus nLeft of every cell
+//                            under the four grid types, 16 bits each);
 //   stream_filter_kernel     one workgroup per (pair, scale, grid type, band of left rows): clear the band's rows, stream the band's
 //                            range of entries to bin them (one returning LDS atomic on the entry's byte, one atomicMax on the row
 //                            header: the running arg-max), verify the band's own cells under all rotations, and leave per own cell
@@ -67,7 +68,9 @@ constexpr int kSCellShift = 8, kSOrigShift = 17, kSOrigHiShift = 21;
 constexpr uint32_t kSFlagDomain = 1u, kSFlagGeneral = 2u;  // (the values gms_kernel_band.hip / gms_kernel_big.hip use)
 constexpr int kSItemsScales = 4 * (7 + 3 + 1);             // (scale, grid type, band) work items of a pair with scale hypotheses (the 10 x 10 and
                                                            // 14 x 14 grids ride on the 20 x 20 and 28 x 28 items)
-constexpr int kSRowBuckets = 21;                           // 20 left rows + "binned under no grid type"
+constexpr int kSRowBuckets = 41;                           // 40 half rows of the left grid (2 x row of grid type 1 + the y parity) + "binned under no grid type":
+                                                           // the rows a band holds under ANY grid type are a range of half rows
+constexpr int kSRowWords = 192;                            // per pair: [h] matches per bucket; [64 + h] fill cursors; [128 + h] first entry of bucket h
 constexpr int kSMarkTile = 8192;                           // matches per workgroup of the marking / compacting kernels
 constexpr int kSTilesMax = kSMaxMatches / kSMarkTile;      // 8
 
@@ -75,7 +78,7 @@ struct StreamWs {
     uint2* entries;      // [n][mcap], sorted by left row
     uint2* codes;        // [n][mcap], the same words in the matches' original order
     uint32_t* nfine;     // [n][1600] half-cell histogram
-    uint32_t* row_cnt;   // [n][96]: [r] matches per row bucket; [32 + r] fill cursors; [64 + r] first entry of row r ([64 + 20]: entries binned)
+    uint32_t* row_cnt;   // [n][kSRowWords]: [h] matches per half-row bucket; [64 + h] fill cursors; [128 + h] first entry of bucket h ([128 + 40]: entries binned)
     uint16_t* nleft;     // [n][4][400]
     uint32_t* counts;    // [n][5][8]
     uint32_t* tile_cnt;  // [n][kSTilesMax][5][8]: the same per tile of kSMarkTile matches
@@ -111,7 +114,7 @@ __global__ void __launch_bounds__(1024)
 stream_index_kernel(FilterParams p, StreamWs w, int mcap)
 {
     __shared__ uint32_t hist[kFineN];
-    __shared__ uint32_t cnt_l[32], base_g[32], row_start[32];
+    __shared__ uint32_t cnt_l[64], base_g[64], row_start[64];
     const int pi = blockIdx.y, tid = threadIdx.x;
     const gms_pair pr = p.pairs[pi];
     const int m = pr.m;
@@ -120,7 +123,7 @@ stream_index_kernel(FilterParams p, StreamWs w, int mcap)
         if (PASS == 0 && blockIdx.x == 0 && tid == 0) atomicOr(&w.flags[pi], kSFlagDomain);
         return;
     }
-    uint32_t* rc = w.row_cnt + (size_t)pi * 96;
+    uint32_t* rc = w.row_cnt + (size_t)pi * kSRowWords;
     uint2* codes = w.codes + (size_t)pi * mcap;
     const int base = blockIdx.x * 4096;
     bool any_bad = false;
@@ -143,7 +146,7 @@ stream_index_kernel(FilterParams p, StreamWs w, int mcap)
         const uint16_t* __restrict__ lcode = reinterpret_cast<const uint16_t*>(p.pts + total_kp) + offA;
         const uint32_t* __restrict__ scode = reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint16_t*>(p.pts + total_kp) + 2 * total_kp) + offB;
         for (int j = tid; j < kFineN; j += 1024) hist[j] = 0;
-        if (tid < 32) cnt_l[tid] = 0;
+        if (tid < 64) cnt_l[tid] = 0;
         __syncthreads();
         uint2 qt[4];
 #pragma unroll
@@ -162,7 +165,7 @@ stream_index_kernel(FilterParams p, StreamWs w, int mcap)
             const bool ok = qt[k].x < (uint32_t)nA && qt[k].y < (uint32_t)nB && cell != 511u && (cb[k] >> 31) == 0u;
             const bool binned = live && ok && cell < 510u;
             any_bad |= live && !ok;
-            bucket[k] = binned ? cell / (uint32_t)kLeftW : 20u;
+            bucket[k] = binned ? 2u * (cell / (uint32_t)kLeftW) + ((ca[k] >> 2) & 1u) : 40u;
             if (live) atomicAdd(&cnt_l[bucket[k]], 1u);
             if (binned) {
                 const uint32_t hx = 2u * (cell % (uint32_t)kLeftW) + (ca[k] & 1u), hy = 2u * (cell / (uint32_t)kLeftW) + ((ca[k] >> 2) & 1u);
@@ -205,31 +208,31 @@ stream_index_kernel(FilterParams p, StreamWs w, int mcap)
         if (base >= m) return;  // workgroup-uniform
 #pragma unroll
         for (int k = 0; k < 4; ++k) ent[k] = codes[min(base + k * 1024 + tid, m - 1)];
-        if (tid < 32) cnt_l[tid] = 0;
+        if (tid < 64) cnt_l[tid] = 0;
         if (tid < 64) {  // the first entry of every row bucket: the running sum of the counts, over the lanes of wave 0
             const uint32_t mine = tid < kSRowBuckets ? rc[tid] : 0u;
             uint32_t incl = mine;
 #pragma unroll
-            for (int d = 1; d < 32; d <<= 1) {
+            for (int d = 1; d < 64; d <<= 1) {
                 const uint32_t up = __shfl_up(incl, d);
                 if (tid >= d) incl += up;
             }
             if (tid < kSRowBuckets) {
                 row_start[tid] = incl - mine;
-                if (blockIdx.x == 0) rc[64 + tid] = incl - mine;  // (for the filter's workgroups: a band of left rows is a range of entries)
+                if (blockIdx.x == 0) rc[128 + tid] = incl - mine;  // (for the filter's workgroups: a band of left rows is a range of entries)
             }
         }
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const bool live = base + k * 1024 + tid < m, binned = live && (ent[k].x & (1u << 5)) == 0u;
-            bucket[k] = binned ? ((ent[k].x >> kSCellShift) & 0x1FFu) / (uint32_t)kLeftW : 20u;
+            bucket[k] = binned ? 2u * (((ent[k].x >> kSCellShift) & 0x1FFu) / (uint32_t)kLeftW) + ((ent[k].x >> 2) & 1u) : 40u;
             rank[k] = live ? atomicAdd(&cnt_l[bucket[k]], 1u) : 0u;
         }
         __syncthreads();
         // this block's entries of a row go behind whatever other blocks have placed there (order inside a row does not matter: every
         // consumer is a commutative atomic)
-        if (tid < kSRowBuckets) base_g[tid] = cnt_l[tid] ? atomicAdd(&rc[32 + tid], cnt_l[tid]) : 0u;
+        if (tid < kSRowBuckets) base_g[tid] = cnt_l[tid] ? atomicAdd(&rc[64 + tid], cnt_l[tid]) : 0u;
         __syncthreads();
         uint2* ents = w.entries + (size_t)pi * mcap;
 #pragma unroll
@@ -405,7 +408,7 @@ __device__ __forceinline__ void stream_scale(const FilterParams& p, const Stream
     // barriers alone, so one thread reads it into scratch word [15] and everybody takes that value behind the first barrier.
     if (tid == 0) misc[15] = __hip_atomic_load(&w.flags[pi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (tid < 15) misc[tid] = 0;
-    const uint32_t* __restrict__ first_of_row = w.row_cnt + (size_t)pi * 96 + 64;  // (written by stream_index_kernel<1>)
+    const uint32_t* __restrict__ first_of_half = w.row_cnt + (size_t)pi * kSRowWords + 128;  // (written by stream_index_kernel<1>)
 
     constexpr uint32_t wr = S == 0 ? 20u : S == 1 ? 10u : S == 2 ? 14u : S == 3 ? 28u : 40u, nr = wr * wr, stride = 4u + nr;  // (checked by the launcher)
     constexpr int band_rows = S == 4 ? 3 : S == 3 ? 8 : kLeftH;
@@ -439,9 +442,9 @@ __device__ __forceinline__ void stream_scale(const FilterParams& p, const Stream
             const int hlo = max(lo - 1, 0), hhi = min(hi + 1, kLeftH);                  // rows held (own + halo)
             const uint32_t cell0 = (uint32_t)(hlo * kLeftW), n_held = (uint32_t)((hhi - hlo) * kLeftW);
             const uint32_t own0 = (uint32_t)(lo * kLeftW), n_own = (uint32_t)((hi - lo) * kLeftW);
-            // the entries of grid-type-1 rows hlo - 1 (the y-shifted types move a match one row down) .. hhi - 1; the first round of
-            // them is on its way while the rows are cleared
-            const uint32_t p_lo = first_of_row[max(hlo - 1, 0)], p_hi = first_of_row[hhi];
+            // the entries of the rows held: half rows 2 hlo .. 2 hhi - 1, one half row down under the y-shifted grid types (whose row R
+            // is made of the odd half row 2 R - 1 and the even one 2 R); the first round of them is on its way while the rows are cleared
+            const uint32_t p_lo = first_of_half[max(2 * hlo - gy, 0)], p_hi = first_of_half[2 * hhi - gy];
             uint32_t pos0 = (p_lo & ~1023u) + (uint32_t)tid;
             uint2 ea[kChunk], eb[kChunk];
             load_chunk(ea, pos0);
@@ -587,7 +590,7 @@ __device__ __forceinline__ uint32_t inlier_rotations(const uint32_t* tab, uint32
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         const uint32_t x = tab[g * kSTabStride + lg[g]] ^ e8;  // < 256: the same right cell, x = the rotations that accept
-        rot |= x < 256u ? x : 0u;
+        rot |= min(x, 256u) & 255u;  // (x itself below 256, else nothing: two instructions, no compare + select)
     }
     return rot;
 }
@@ -1507,7 +1510,7 @@ int stream_max_matches() { return kSMaxMatches; }
 size_t stream_ws_bytes_per_pair(const FilterParams& p, int mcap, bool)
 {
     const size_t n_scales = p.with_scale ? 5 : 1;
-    return (size_t)mcap * 16 + (size_t)kFineN * 4 + 96 * 4 + 4 * (size_t)kLeftN * 2 + 5 * 8 * 4 + (size_t)kSTilesMax * 5 * 8 * 4 + 4 +
+    return (size_t)mcap * 16 + (size_t)kFineN * 4 + (size_t)kSRowWords * 4 + 4 * (size_t)kLeftN * 2 + 5 * 8 * 4 + (size_t)kSTilesMax * 5 * 8 * 4 + 4 +
            4 * n_scales * (size_t)kLeftN * 4 + 128;  // (+ the alignment of the arrays of a slice)
 }
 
@@ -1531,7 +1534,7 @@ hipError_t launch_filter_stream(const FilterParams& p, int mcap, void* ws, const
     w.nfine = reinterpret_cast<uint32_t*>(q);
     q += (size_t)n * kFineN * 4;
     w.row_cnt = reinterpret_cast<uint32_t*>(q);
-    q += (size_t)n * 96 * 4;
+    q += (size_t)n * kSRowWords * 4;
     w.counts = reinterpret_cast<uint32_t*>(q);
     q += (size_t)n * 5 * 8 * 4;
     w.flags = reinterpret_cast<uint32_t*>(q);
