@@ -414,7 +414,7 @@ def zoom_leg(ctx, pkg, stream, dev, n_frames=64, n_kp=10000, n_pairs=1024, steps
 
 def config4_leg(ctx, pkg, stream, dev, n_kp=50000, steps=5):
     """BASELINE config 4: 3840 x 2160 pairs with 50k features, M = 50k putative matches per pair -- at its stated flags (rotation + scale
-    hypotheses, 8 rot x 5 scale x 4 grids; 64 pairs per launch) and at the default flags (256 pairs per launch), device-resident."""
+    hypotheses, 8 rot x 5 scale x 4 grids; 64 pairs per launch, and 256) and at the default flags (256 pairs per launch), device-resident."""
     import torch
     synth = importlib.import_module(PKG + ".synth")
     batch = importlib.import_module(PKG + ".batch")
@@ -426,7 +426,7 @@ def config4_leg(ctx, pkg, stream, dev, n_kp=50000, steps=5):
     kp_all = np.concatenate(frames)
     wh = np.array([size] * n_frames, dtype=np.int32).reshape(-1)
     out = {"workload": f"config4: {size[0]} x {size[1]} pairs, {n_kp} keypoints per frame, M = {n_kp} putative matches per pair, device-resident"}
-    for tag, n_pairs, rot, scale in (("rot_scale", 64, True, True), ("default_flags", 256, False, False)):
+    for tag, n_pairs, rot, scale in (("rot_scale", 64, True, True), ("rot_scale_256_pairs", 256, True, True), ("default_flags", 256, False, False)):
         pairs = distmod.pair_table(n_frames, 0, n_pairs, n_kp)
         d_pairs = torch.from_numpy(pairs.view(np.uint8).reshape(-1)).to(dev)
         d_matches = distmod.synth_matches_device(0, n_pairs, n_kp, 0.5, dev)

@@ -368,3 +368,63 @@ def test_streamed_kernels_when_an_entry_leaves_its_byte(ctx, oracle, synth):
             rc, want, wmask, wres = oracle.match(size, size, frames[a], frames[b], matches[o:o + m], rot, scale, 6.0)
             assert rc == 0 and res[i].tobytes() == wres.tobytes() and np.array_equal(mask[o:o + m], wmask)
             assert out[o:o + len(want)].tobytes() == want.tobytes() and len(want) > 5000
+
+
+@pytest.mark.parametrize("n", [16385, 24576, 24577, 40959, 40961, 57344, 65535, 65536])
+def test_hypotheses_across_the_marking_tiles(ctx, oracle, n):
+    """Rotation + scale hypotheses on the streamed kernels: the marking pass and the copy-out work on tiles of 8192 matches in the
+    original order (per-tile counts of every hypothesis are the copy-out's offsets) -- sizes on and around the tile borders."""
+    c = cases.random_pair(300 + n % 13, n=n, size1=(3840, 2160), inlier_frac=0.5, theta_deg=90.0 if n % 2 else 0.0, scale=0.5 if n % 3 == 0 else 1.0)
+    kept = _check(ctx, oracle, c, True, True)
+    assert kept > n // 8
+
+
+def test_pooled_entry_above_255(ctx, oracle, synth):
+    """The 10 x 10 and 14 x 14 matrices of the streamed kernels are the 20 x 20 and 28 x 28 ones' rows summed two by two, as 16-bit
+    entries: 30 000 matches of which 800 go from one left cell to four neighbouring 20 x 20 right cells that are ONE 10 x 10 cell --
+    every byte entry stays below 256, the pooled entry does not. Same bytes as the oracle, with the 10 x 10 hypothesis winning."""
+    rng = np.random.default_rng(78)
+    size, n = (1920, 1080), 30000
+    xy1 = np.stack([rng.uniform(0, size[0] - 1, n), rng.uniform(0, size[1] - 1, n)], axis=1).astype(np.float32)
+    # the right image at half the magnification: a left cell maps into a quarter of a 20 x 20 right cell's area ... spread on purpose
+    xy2 = np.clip(xy1 * np.float32(0.5) + rng.normal(0, 1.5, (n, 2)).astype(np.float32), 0, [size[0] - 1.01, size[1] - 1.01]).astype(np.float32)
+    hot = slice(0, 800)
+    xy1[hot] = np.stack([rng.uniform(970, 1050, 800), rng.uniform(545, 590, 800)], axis=1)          # inside one 96 x 54 left cell
+    xy2[hot] = np.stack([rng.uniform(390, 570, 800), rng.uniform(220, 320, 800)], axis=1)           # 20 x 20 cells (4..5, 4..5) = 10 x 10 cell (2, 2)
+    train = np.arange(n)
+    wrong = rng.uniform(size=n) < 0.3
+    wrong[hot] = False
+    train[wrong] = rng.integers(0, n, int(wrong.sum()))
+    c = dict(size1=size, size2=size, kp1=synth.make_keypoints(xy1), kp2=synth.make_keypoints(xy2), matches=synth.make_matches(np.arange(n), train, rng))
+    for rot, scale in ((False, True), (True, True)):
+        got, res = ctx.match(c["size1"], c["size2"], c["kp1"], c["kp2"], c["matches"], rot, scale, 6.0, return_result=True)
+        rc, want, _, wres = oracle.match(c["size1"], c["size2"], c["kp1"], c["kp2"], c["matches"], rot, scale, 6.0)
+        assert rc == 0 and got.tobytes() == want.tobytes(), (len(got), len(want), res, wres)
+        assert (res["n_inliers"], res["best_scale"], res["best_rot"]) == (wres["n_inliers"], wres["best_scale"], wres["best_rot"])
+        assert len(want) > 5000 and int(wres["best_scale"]) == 1  # (the 10 x 10 grid wins: its pooled entries decided the result)
+
+
+def test_hypotheses_batch_with_mask_ragged_pairs(ctx, oracle, pkg, synth):
+    """Five pairs of 17 000 ... 61 000 matches at unaligned offsets in one launch with rotation + scale hypotheses, the optional mask
+    requested: survivors, results and mask bytes equal the oracle's, pair by pair (one of the pairs is empty of inliers by construction)."""
+    batch = importlib.import_module("sfm-gms_amd.batch")
+    size = (3840, 2160)
+    ms = [17001, 61000, 23456, 40000, 33333]
+    frames, chunks, pairs = [], [], np.zeros(len(ms), dtype=pkg.PAIR_DTYPE)
+    off = 7
+    for i, m in enumerate(ms):
+        a, b, mm = synth.make_pair(900 + i, size1=size, n1=m, inlier_frac=0.0 if i == 2 else 0.55)
+        frames += [a, b]
+        pairs[i] = (2 * i, 2 * i + 1, m, 0, off)
+        chunks.append((off, mm))
+        off += m + 3 * (i + 1)
+    matches = np.zeros(off, dtype=chunks[0][1].dtype)
+    for o, mm in chunks:
+        matches[o:o + len(mm)] = mm
+    table = batch.FrameTable(ctx, frames, [size] * len(frames))
+    out, res, mask = batch.filter_pairs(ctx, table, pairs, matches, True, True, 6.0)
+    for i, m in enumerate(ms):
+        o = int(pairs["match_off"][i])
+        rc, want, wmask, wres = oracle.match(size, size, frames[2 * i], frames[2 * i + 1], matches[o:o + m], True, True, 6.0)
+        assert rc == 0 and res[i].tobytes() == wres.tobytes(), (i, res[i], wres)
+        assert np.array_equal(mask[o:o + m], wmask) and out[o:o + len(want)].tobytes() == want.tobytes()
