@@ -848,15 +848,6 @@ hipError_t launch_filter_band(const FilterParams& p, int mcap, void* ws, const u
 }
 
 
-// the same copy-out for gms_kernel_stream.hip (mask bytes + optional state = {best count, scale, rotation} per pair)
-hipError_t launch_band_compact(const FilterParams& p, int mcap, const uint32_t* flags, uint8_t* mask_ws, const uint32_t* state, hipStream_t stream)
-{
-    if (p.n_pairs <= 0) return hipSuccess;
-    hipLaunchKernelGGL(band_compact_kernel, dim3((unsigned)((mcap + 16383) / 16384), (unsigned)p.n_pairs), dim3(1024), 0, stream, p, flags,
-                       mask_ws, state, mcap);
-    return hipGetLastError();
-}
-
 // ---- rotation / scale hypotheses for large pairs ------------------------------------------------------------------------------
 static TileGeom tile_geom(const FilterParams& p, int scale)
 {

@@ -86,7 +86,6 @@ hipError_t launch_filter_band(const FilterParams& p, int mcap, void* ws, const u
 // large pairs with rotation / scale hypotheses (gms_kernel_band.hip): tiled 16-bit matrix, three launches per scale
 size_t     tile_ws_bytes_per_pair(const FilterParams& p, int mcap, bool need_mask);
 hipError_t launch_filter_tiles(const FilterParams& p, int mcap, void* ws, const uint32_t** flags_out, hipStream_t stream);
-hipError_t launch_band_compact(const FilterParams& p, int mcap, const uint32_t* flags, uint8_t* mask_ws, const uint32_t* state, hipStream_t stream);
 // pairs of 16 385 .. 65 536 matches, every flag combination (gms_kernel_stream.hip): the byte matrix with the matches streamed from a
 // row-sorted workspace array, one workgroup per (pair, scale hypothesis); *flags_out marks the pairs left to launch_filter_big (bit 1)
 hipError_t init_stream_kernels();
