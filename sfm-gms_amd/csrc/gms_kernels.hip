@@ -824,31 +824,38 @@ __device__ __forceinline__ void hash_pair(const FilterParams& p, uint32_t* smem,
 
     gms_dmatch* __restrict__ out = p.out + pr.match_off;
     uint8_t* mask_out = p.mask ? p.mask + pr.match_off : nullptr;
+    constexpr int kOut = KPT % 10 == 0 ? 10 : KPT % 8 == 0 ? 8 : kChunk;  // records requested together (nothing else is live here)
+    static_assert(KPT % kOut == 0, "whole rounds");
 #pragma unroll
-    for (int k0 = 0; k0 < KPT; k0 += kChunk) {
-        uint32_t pos[kChunk];
-        uint4 v[kChunk];
+    for (int k0 = 0; k0 < KPT; k0 += kOut) {
+        uint32_t pos[kOut];
+        uint4 v[kOut];
         uint32_t inm = 0;
 #pragma unroll
-        for (int c = 0; c < kChunk; ++c) {
+        for (int c = 0; c < kOut; ++c) {
             const int i = (k0 + c) * NT + tid;
             const int ch = i >> 6;
             pos[c] = 0;
-            v[c] = make_uint4(0, 0, 0, 0);
+            bool in = false;
             if (i < mm) {
                 const unsigned long long bits =
                     failed ? 0ull : ((unsigned long long)bestmask[2 * ch] | ((unsigned long long)bestmask[2 * ch + 1] << 32));
-                const bool in = (bits >> lane) & 1ull;
+                in = (bits >> lane) & 1ull;
                 if (mask_out) mask_out[i] = in ? 1 : 0;
                 if (in) {
                     inm |= 1u << c;
                     pos[c] = chunk_base[ch] + (uint32_t)__popcll(bits & ((1ull << lane) - 1ull));
-                    v[c] = *reinterpret_cast<const uint4*>(&matches[i]);
                 }
             }
+            // the survivor's record -- requested UNCONDITIONALLY, the address selected (everybody else reads the pair's first record:
+            // one line): a load inside the branch is waited for inside the branch, one round trip per record, and this kernel
+            // reads the records from HBM (the byte-matrix kernel had them long ago)
+            v[c] = *reinterpret_cast<const uint4*>(&matches[in ? i : 0]);
         }
 #pragma unroll
-        for (int c = 0; c < kChunk; ++c)
+        for (int c = 0; c < kOut; ++c) asm volatile("" : "+v"(v[c].x), "+v"(v[c].y), "+v"(v[c].z), "+v"(v[c].w));  // (all of the round's records before its first store)
+#pragma unroll
+        for (int c = 0; c < kOut; ++c)
             if ((inm >> c) & 1u) *reinterpret_cast<uint4*>(&out[pos[c]]) = v[c];
     }
     GMS_STAMP(9);  // copy-out
@@ -1866,8 +1873,10 @@ __device__ __forceinline__ bool dense_pair_plain(const FilterParams& p, uint32_t
         }
         GMS_STAMP(8);
         const int wave_s = __builtin_amdgcn_readfirstlane(wave);
-#pragma unroll
-        for (int k = 0; k < KPT; ++k) {
+        // The records that were not kept in registers (KPT above kKeep) are read again, two at a time: requested together, the survivor's
+        // own or -- address selected -- the pair's first, and pinned before the stores (a load inside the survivor's branch is waited for
+        // there, one round trip per record).
+        auto put = [&](int k, const uint4& rv) {
             const int i = k * NT + tid;
             const uint32_t base = row_base[k] + (uint32_t)__builtin_amdgcn_readlane((int)excl[k >> 2], (k & 3) * 16 + wave_s);
             if (i < m) {
@@ -1875,9 +1884,26 @@ __device__ __forceinline__ bool dense_pair_plain(const FilterParams& p, uint32_t
                 if (mask_out) mask_out[i] = in ? 1 : 0;
                 if (in) {
                     const uint32_t pos = base + (uint32_t)__popcll(keep[k] & ((1ull << lane) - 1ull));
-                    { const uint4 rv = k < kKeep ? rec[k < kKeep ? k : 0] : *reinterpret_cast<const uint4*>(&matches[i]); __builtin_nontemporal_store(u32x4_t{rv.x, rv.y, rv.z, rv.w}, reinterpret_cast<u32x4_t*>(&out[pos])); }
+                    __builtin_nontemporal_store(u32x4_t{rv.x, rv.y, rv.z, rv.w}, reinterpret_cast<u32x4_t*>(&out[pos]));
                 }
             }
+        };
+#pragma unroll
+        for (int k = 0; k < kKeep; ++k) put(k, rec[k]);  // (their registers are free for the records read again)
+        constexpr int kBatch = 2;
+#pragma unroll
+        for (int k0 = kKeep; k0 < KPT; k0 += kBatch) {
+            uint4 again[kBatch];
+#pragma unroll
+            for (int j = 0; j < kBatch; ++j) {
+                const int k = k0 + j < KPT ? k0 + j : KPT - 1, i = k * NT + tid;
+                again[j] = *reinterpret_cast<const uint4*>(&matches[(i < m && ((keep[k] >> lane) & 1ull)) ? i : 0]);
+            }
+#pragma unroll
+            for (int j = 0; j < kBatch; ++j) asm volatile("" : "+v"(again[j].x), "+v"(again[j].y), "+v"(again[j].z), "+v"(again[j].w));
+#pragma unroll
+            for (int j = 0; j < kBatch; ++j)
+                if (k0 + j < KPT) put(k0 + j, again[j]);
         }
     } else {
         constexpr int kUnits = KPT * NT / 8;
@@ -1909,8 +1935,7 @@ __device__ __forceinline__ bool dense_pair_plain(const FilterParams& p, uint32_t
         }
         __syncthreads();
         GMS_STAMP(8);
-#pragma unroll
-        for (int k = 0; k < KPT; ++k) {
+        auto put = [&](int k, const uint4& rv) {
             const int i = match_of(k);
             if (i < m) {
                 const uint32_t byte = (uint32_t)(keep[k] >> (lane & 56)) & 0xFFu;
@@ -1918,9 +1943,27 @@ __device__ __forceinline__ bool dense_pair_plain(const FilterParams& p, uint32_t
                 if (mask_out) mask_out[i] = in ? 1 : 0;
                 if (in) {
                     const uint32_t pos = cnt_tab[i >> 3] + (uint32_t)__popc(byte & ((1u << (lane & 7)) - 1u));
-                    { const uint4 rv = k < kKeep ? rec[k < kKeep ? k : 0] : *reinterpret_cast<const uint4*>(&matches[i]); __builtin_nontemporal_store(u32x4_t{rv.x, rv.y, rv.z, rv.w}, reinterpret_cast<u32x4_t*>(&out[pos])); }
+                    __builtin_nontemporal_store(u32x4_t{rv.x, rv.y, rv.z, rv.w}, reinterpret_cast<u32x4_t*>(&out[pos]));
                 }
             }
+        };
+#pragma unroll
+        for (int k = 0; k < kKeep; ++k) put(k, rec[k]);
+        constexpr int kBatch = 2;  // (see the list-order branch)
+#pragma unroll
+        for (int k0 = kKeep; k0 < KPT; k0 += kBatch) {
+            uint4 again[kBatch];
+#pragma unroll
+            for (int j = 0; j < kBatch; ++j) {
+                const int k = k0 + j < KPT ? k0 + j : KPT - 1, i = match_of(k);
+                const bool in = i < m && (((uint32_t)(keep[k] >> (lane & 56)) >> (lane & 7)) & 1u) != 0u;
+                again[j] = *reinterpret_cast<const uint4*>(&matches[in ? i : 0]);
+            }
+#pragma unroll
+            for (int j = 0; j < kBatch; ++j) asm volatile("" : "+v"(again[j].x), "+v"(again[j].y), "+v"(again[j].z), "+v"(again[j].w));
+#pragma unroll
+            for (int j = 0; j < kBatch; ++j)
+                if (k0 + j < KPT) put(k0 + j, again[j]);
         }
     }
     GMS_STAMP(9);
