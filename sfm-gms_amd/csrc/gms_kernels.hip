@@ -312,6 +312,7 @@ __device__ __forceinline__ void hash_pair(const FilterParams& p, uint32_t* smem,
         asm volatile("" : "+v"(part_hdr.x), "+v"(part_hdr.y), "+v"(part_hdr.z), "+v"(part_hdr.w));
     }
     const uint32_t part0 = (uint32_t)uniform((int)part_hdr.x);  // workgroup-uniform: 0, or what the first kernel decided:
+    if (part0 == 6u) return;                                     //   6: everything, the survivors copied out as well (scales_copy_out)
     const int scales_done = (int)(part0 & 15u);                  //   scales 0..3 (4) or all five (5: its probe bounded scale 4 out)
     const bool probed4 = (part0 >> 4) != 0;                      //   "scale 4 was probed and cannot be bounded out"
     const bool resumed = scales_done != 0;
@@ -2041,6 +2042,89 @@ order_probe_kernel(FilterParams p, uint32_t* __restrict__ flag)
 // Everything is dense_pair() with a runtime row stride; the records are not kept (nothing is copied out here).
 // ------------------------------------------------------------------------------------------------
 
+// The copy-out of a pair whose five scale hypotheses are all decided in the byte-matrix kernel (the probe bounded scale 4 out): the
+// survivors in input order, the result record, the optional mask -- what the hashed kernel would otherwise start a workgroup for, read
+// the pair's record and 160 KB of DMatch records from HBM for, 100 us after this kernel had them. NOT inlined on purpose: a body of its
+// own register allocation, so that nothing here is live through the scale passes (round 3's inlined attempt paid for itself in spills).
+// A unit is eight consecutive matches = the byte of a ballot that an eight-lane group holds, in either lane mapping.
+template <int KPT, int NT>
+__device__ __noinline__ void scales_copy_out(const gms_pair* pairs, const gms_dmatch* all_matches, gms_dmatch* all_out, uint8_t* all_mask,
+                                             gms_pair_result* results, uint32_t* smem, int pair_idx, uint32_t bestbits, int dealt,
+                                             uint32_t best_count, int best_scale, int best_rot)
+{
+    constexpr int kUnits = KPT * NT / 8, kWaves = NT / 64;
+    static_assert(kUnits <= 2 * NT, "two scan entries per thread");
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const gms_pair pr = load_pair(pairs, pair_idx);
+    const int m = pr.m;
+    const gms_dmatch* __restrict__ matches = all_matches + pr.match_off;
+    gms_dmatch* __restrict__ out = all_out + pr.match_off;
+    uint32_t* cnt = smem;              // [kUnits] survivors per unit, then in front of it
+    uint32_t* wtot = smem + kUnits;    // [kWaves]
+    const int ubase = dealt ? (lane >> 3) * (KPT * kWaves) + wave : (tid >> 3);
+    const int ustep = dealt ? kWaves : NT / 8;
+    __syncthreads();  // (the matrix area is free)
+    uint32_t ranks[(KPT + 7) / 8] = {};  // four bits per match: survivors before it in its unit
+#pragma unroll
+    for (int k = 0; k < KPT; ++k) {
+        const unsigned long long bal = __ballot((bestbits >> k) & 1u);
+        const uint32_t byte = (uint32_t)(bal >> (lane & 56)) & 0xFFu;
+        if ((lane & 7) == 0) cnt[ubase + k * ustep] = (uint32_t)__popc(byte);
+        ranks[k >> 3] |= (uint32_t)__popc(byte & ((1u << (lane & 7)) - 1u)) << ((k & 7) * 4);
+    }
+    __syncthreads();
+    {   // exclusive scan over the units, two per thread
+        const uint32_t a = 2 * tid < kUnits ? cnt[2 * tid] : 0u, b = 2 * tid + 1 < kUnits ? cnt[2 * tid + 1] : 0u;
+        uint32_t incl = a + b;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t up = (uint32_t)__shfl_up((int)incl, d);
+            if (lane >= d) incl += up;
+        }
+        if (lane == 63) wtot[wave] = incl;
+        __syncthreads();
+        uint32_t before = 0;
+        for (int w = 0; w < wave; ++w) before += wtot[w];
+        const uint32_t excl = before + incl - (a + b);
+        if (2 * tid < kUnits) cnt[2 * tid] = excl;
+        if (2 * tid + 1 < kUnits) cnt[2 * tid + 1] = excl + a;
+    }
+    __syncthreads();
+    // the survivors' records: a round of them requested together, every lane from an address (its own record or the pair's first),
+    // pinned before the stores
+    constexpr int kRound = KPT % 10 == 0 ? 10 : KPT % 8 == 0 ? 8 : 4;
+    static_assert(KPT % kRound == 0, "whole rounds");
+#pragma unroll
+    for (int k0 = 0; k0 < KPT; k0 += kRound) {
+        uint4 rec[kRound];
+#pragma unroll
+        for (int c = 0; c < kRound; ++c) {
+            const int k = k0 + c, i = ((ubase + k * ustep) << 3) | (lane & 7);
+            rec[c] = *reinterpret_cast<const uint4*>(&matches[(((bestbits >> k) & 1u) && i < m) ? i : 0]);
+        }
+#pragma unroll
+        for (int c = 0; c < kRound; ++c) asm volatile("" : "+v"(rec[c].x), "+v"(rec[c].y), "+v"(rec[c].z), "+v"(rec[c].w));
+#pragma unroll
+        for (int c = 0; c < kRound; ++c) {
+            const int k = k0 + c, u = ubase + k * ustep, i = (u << 3) | (lane & 7);
+            const bool in = ((bestbits >> k) & 1u) && i < m;
+            if (all_mask && i < m) all_mask[pr.match_off + i] = in ? 1 : 0;
+            if (in) {
+                const uint32_t pos = cnt[u] + ((ranks[k >> 3] >> ((k & 7) * 4)) & 15u);
+                __builtin_nontemporal_store(u32x4_t{rec[c].x, rec[c].y, rec[c].z, rec[c].w}, reinterpret_cast<u32x4_t*>(&out[pos]));
+            }
+        }
+    }
+    if (tid == 0) {
+        gms_pair_result r;
+        r.n_inliers = (int)best_count;
+        r.best_scale = best_scale;
+        r.best_rot = best_rot;
+        r.status = GMS_OK;
+        results[pair_idx] = r;
+    }
+}
+
 template <int KPT, bool ROT, int NT>
 __device__ __forceinline__ bool dense_scales_pair(const FilterParams& p, uint32_t* smem, const int pair_idx, const int tid,
                                                   uint32_t* __restrict__ part)
@@ -2600,6 +2684,13 @@ __device__ __forceinline__ bool dense_scales_pair(const FilterParams& p, uint32_
         return false;
     }
     __syncthreads();
+    if (decided == 5u) {  // (workgroup-uniform) nothing is left for the hashed kernel but the copy-out: done here, its workgroup returns at once
+        if (tid == 0) part[0] = 6u;
+        scales_copy_out<KPT, NT>(p.pairs, p.matches, p.out, p.mask, p.results, smem, pair_idx, bestbits, dealt ? 1 : 0, best_count, best_scale, best_rot);
+        GMS_STAMP_OUT(9, 11);
+        GMS_STAMP_FLUSH;
+        return true;
+    }
     // the record the hashed kernel continues from: scales 0..3 (or all five) are decided
     if (tid == 0) {
         part[0] = decided;
