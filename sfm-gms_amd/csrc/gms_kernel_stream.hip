@@ -23,9 +23,10 @@
 //   stream_compact_kernel    getInlierMask's strict '>' over the (scale, rotation) counts in the reference's order, the winner's bit of
 //                            every match of a tile (four table look-ups), the survivors in front of the tile from the tile counts, and
 //                            the order-preserving copy-out.
-// Right grids: 10 x 10, 14 x 14 and 20 x 20 fit the LDS whole; 28 x 28 takes three bands of eight rows (+ a halo row either side),
-// 40 x 40 seven bands of three. A band streams only the rows it holds -- not the pair.
-// An entry that would exceed its byte (more than 255 matches in ONE (left cell, right cell) pair), a left cell above 65 535 matches or
+// Right grids: 20 x 20 fits the LDS whole; 28 x 28 takes three bands of eight rows (+ a halo row either side), 40 x 40 seven bands of
+// three; a band streams only the rows it holds -- not the pair. 10 x 10 and 14 x 14 are never binned: their matrices are the 20 x 20 and
+// 28 x 28 ones' rows summed two by two, in place, by the item that holds them (pool_rows).
+// A byte entry that would exceed its byte (more than 255 matches in ONE (left cell, right cell) pair), a left cell above 65 535 matches or
 // a frame table without code arrays flag the pair for the HBM-slab kernel (gms_kernel_big.hip), which runs behind on flagged pairs
 // only. Bit-exactness rules are those of gms_kernels.hip (same codes, same arg-max and tie rules, same threshold arithmetic).
 #include <hip/hip_runtime.h>
