@@ -395,24 +395,31 @@ __device__ __forceinline__ void stream_scale(const FilterParams& p, const Stream
     constexpr int kChunk = 8;  // entries per thread and round; two rounds in flight
     GMS_SSTAMP_DECL
     const int tid = threadIdx.x;
-    const gms_pair pr = p.pairs[pi];
-    const int m = pr.m;
+    constexpr uint32_t wr = S == 0 ? 20u : S == 1 ? 10u : S == 2 ? 14u : S == 3 ? 28u : 40u, nr = wr * wr, stride = 4u + nr;  // (checked by the launcher)
+    constexpr int band_rows = S == 4 ? 3 : S == 3 ? 8 : kLeftH;
+    const int gy_top = g >> 1, lo_top = band * band_rows, hi_top = min(lo_top + band_rows, kLeftH);
+    const int hlo_top = max(lo_top - 1, 0), hhi_top = min(hi_top + 1, kLeftH);
+    uint16_t* nleft = reinterpret_cast<uint16_t*>(reinterpret_cast<uint8_t*>(smem) + kSNleftOff);
+    uint32_t* misc = smem + kSMiscOff / 4;
+    // Everything the item needs before its entries, requested TOGETHER (one round trip, not three): the pair's match count, the two
+    // ends of the band's range of entries (written by stream_index_kernel<1>), nLeft of this grid type, and the pair's flag word --
+    // the index kernels write it before the launch, but the pair's OTHER workgroups of this launch may OR kSFlagGeneral into it at any
+    // time (below); waves reading it one by one could disagree and a part of the workgroup would run the barriers alone, so one thread
+    // reads it into scratch word [15] and everybody takes that value behind the first barrier.
+    const uint32_t* __restrict__ first_of_half = w.row_cnt + (size_t)pi * kSRowWords + 128;
+    uint32_t m_word = reinterpret_cast<const uint32_t*>(p.pairs + pi)[2];
+    uint32_t lo_word = first_of_half[max(2 * hlo_top - gy_top, 0)], hi_word = first_of_half[2 * hhi_top - gy_top];
+    if (tid == 0) misc[15] = __hip_atomic_load(&w.flags[pi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid < 15) misc[tid] = 0;
+    if (tid >= 64 && tid < 64 + kLeftN / 2)
+        reinterpret_cast<uint32_t*>(nleft)[tid - 64] = reinterpret_cast<const uint32_t*>(w.nleft + ((size_t)pi * 4 + g) * kLeftN)[tid - 64];
+    asm volatile("" : "+v"(m_word), "+v"(lo_word), "+v"(hi_word));
+    const int m = uniform((int)m_word);
     if (m <= 0 || m > mcap) return;
     const uint2* __restrict__ ents = w.entries + (size_t)pi * mcap;
     // the table of this (scale, grid type): a cell is written by the one band that owns its left row
     uint32_t* tab = w.tables + (((size_t)pi * n_scales + (n_scales == 5 ? S : 0)) * 4 + (size_t)g) * kLeftN;
 
-    uint16_t* nleft = reinterpret_cast<uint16_t*>(reinterpret_cast<uint8_t*>(smem) + kSNleftOff);
-    uint32_t* misc = smem + kSMiscOff / 4;
-    // The pair's flag word: the index kernels write it before the launch, but the pair's OTHER workgroups of this launch may OR
-    // kSFlagGeneral into it at any time (below); waves reading it one by one could disagree and a part of the workgroup would run the
-    // barriers alone, so one thread reads it into scratch word [15] and everybody takes that value behind the first barrier.
-    if (tid == 0) misc[15] = __hip_atomic_load(&w.flags[pi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (tid < 15) misc[tid] = 0;
-    const uint32_t* __restrict__ first_of_half = w.row_cnt + (size_t)pi * kSRowWords + 128;  // (written by stream_index_kernel<1>)
-
-    constexpr uint32_t wr = S == 0 ? 20u : S == 1 ? 10u : S == 2 ? 14u : S == 3 ? 28u : 40u, nr = wr * wr, stride = 4u + nr;  // (checked by the launcher)
-    constexpr int band_rows = S == 4 ? 3 : S == 3 ? 8 : kLeftH;
     const bool thr_fast = threshold_fast_ok(p.threshold_factor);
     static_assert((kLeftH + band_rows - 1) / band_rows == (S == 4 ? 7 : S == 3 ? 3 : 1), "bands per scale as the item table assumes");
 
@@ -436,8 +443,6 @@ __device__ __forceinline__ void stream_scale(const FilterParams& p, const Stream
         const int gx = g & 1, gy = g >> 1;
         const uint32_t q_mask = (uint32_t)(gx + 20 * gy);                               // l = l1 + (q & q_mask)
         const uint32_t out_mask = (1u << 5) | (gx ? 1u << 6 : 0u) | (gy ? 1u << 7 : 0u);  // never | x >= 20 | y >= 20 under this grid type
-        if (tid >= 64 && tid < 64 + kLeftN / 2)
-            reinterpret_cast<uint32_t*>(nleft)[tid - 64] = reinterpret_cast<const uint32_t*>(w.nleft + ((size_t)pi * 4 + g) * kLeftN)[tid - 64];
         {
             const int lo = band * band_rows, hi = min(lo + band_rows, kLeftH);          // own rows
             const int hlo = max(lo - 1, 0), hhi = min(hi + 1, kLeftH);                  // rows held (own + halo)
@@ -445,7 +450,7 @@ __device__ __forceinline__ void stream_scale(const FilterParams& p, const Stream
             const uint32_t own0 = (uint32_t)(lo * kLeftW), n_own = (uint32_t)((hi - lo) * kLeftW);
             // the entries of the rows held: half rows 2 hlo .. 2 hhi - 1, one half row down under the y-shifted grid types (whose row R
             // is made of the odd half row 2 R - 1 and the even one 2 R); the first round of them is on its way while the rows are cleared
-            const uint32_t p_lo = first_of_half[max(2 * hlo - gy, 0)], p_hi = first_of_half[2 * hhi - gy];
+            const uint32_t p_lo = (uint32_t)uniform((int)lo_word), p_hi = (uint32_t)uniform((int)hi_word);  // first_of_half[max(2 hlo - gy, 0)], [2 hhi - gy]
             uint32_t pos0 = (p_lo & ~1023u) + (uint32_t)tid;
             uint2 ea[kChunk], eb[kChunk];
             load_chunk(ea, pos0);
