@@ -281,7 +281,16 @@ __device__ __forceinline__ void hash_pair(const FilterParams& p, uint32_t* smem,
     const int lane = tid & 63;
     const int wave = tid >> 6;
 
+    // with scale hypotheses the byte-matrix kernel may have evaluated scales 0..2 already (see dense_scales_pair): its
+    // record holds the best hypothesis so far, and this kernel continues with scale 3. The record's four header words in one load,
+    // requested in front of the pair's record (one round trip for both: see load_pair).
+    const uint32_t* __restrict__ part = p.partial ? p.partial + (size_t)pair_idx * kPartialStrideDw : nullptr;
+    uint4 part_hdr = make_uint4(0u, 0u, 0u, 0u);
+    if (part != nullptr) part_hdr = *reinterpret_cast<const uint4*>(part);
     const gms_pair pr = load_pair(p.pairs, pair_idx);
+    if (part != nullptr) asm volatile("" : "+v"(part_hdr.x), "+v"(part_hdr.y), "+v"(part_hdr.z), "+v"(part_hdr.w));
+    const uint32_t part0 = (uint32_t)uniform((int)part_hdr.x);  // workgroup-uniform: 0, or what the first kernel decided:
+    if (part0 == 6u) return;                                     //   6: everything, the survivors copied out as well (scales_copy_out)
     const int m = pr.m;
     const gms_dmatch* __restrict__ matches = p.matches + pr.match_off;
 
@@ -303,16 +312,6 @@ __device__ __forceinline__ void hash_pair(const FilterParams& p, uint32_t* smem,
     if (tid < 48) misc[tid] = 0;
     if (tid < 128) trash[tid] = 0;
     if (tid >= 128 && tid < 132) trash[tid] = kEmpty;
-    // with scale hypotheses the byte-matrix kernel may have evaluated scales 0..2 already (see dense_scales_pair): its
-    // record holds the best hypothesis so far, and this kernel continues with scale 3
-    const uint32_t* __restrict__ part = p.partial ? p.partial + (size_t)pair_idx * kPartialStrideDw : nullptr;
-    uint4 part_hdr = make_uint4(0u, 0u, 0u, 0u);  // (the record's four header words in one load: see load_pair)
-    if (part != nullptr) {
-        part_hdr = *reinterpret_cast<const uint4*>(part);
-        asm volatile("" : "+v"(part_hdr.x), "+v"(part_hdr.y), "+v"(part_hdr.z), "+v"(part_hdr.w));
-    }
-    const uint32_t part0 = (uint32_t)uniform((int)part_hdr.x);  // workgroup-uniform: 0, or what the first kernel decided:
-    if (part0 == 6u) return;                                     //   6: everything, the survivors copied out as well (scales_copy_out)
     const int scales_done = (int)(part0 & 15u);                  //   scales 0..3 (4) or all five (5: its probe bounded scale 4 out)
     const bool probed4 = (part0 >> 4) != 0;                      //   "scale 4 was probed and cannot be bounded out"
     const bool resumed = scales_done != 0;
