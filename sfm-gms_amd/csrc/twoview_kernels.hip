@@ -16,6 +16,7 @@
 // order by one lane). fp64 throughout; the arithmetic itself is twoview_core.h.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "gms_kernels.h"
 #include "twoview_core.h"
@@ -28,10 +29,12 @@ constexpr int kSolvers = 16;  // samples solved per round
 
 // per-lane view of an LDS array whose element i of solver lane s sits at base[i * kSolvers + s]: the sixteen lanes of a solver
 // wave touch sixteen consecutive doubles whatever (run-time) element each of them indexes in lockstep
-struct LdsLane {
+template <int STRIDE>
+struct LdsLaneT {
     double* base;
-    __device__ __forceinline__ double& operator()(int i) const { return base[i * kSolvers]; }
+    __device__ __forceinline__ double& operator()(int i) const { return base[i * STRIDE]; }
 };
+using LdsLane = LdsLaneT<kSolvers>;
 
 __device__ __forceinline__ int pair_count(const gms_pair& pr, const gms_two_view& t)
 {
@@ -76,19 +79,29 @@ struct EssentialParams {
     int max_iters;
 };
 
-__global__ void __launch_bounds__(kTvThreads, 2)   // two workgroups per CU: the solver is a latency chain, a second pair hides it (14.3 -> 10.9 ms per 1024 pairs for the stage)
+// THREADS x SOLVERS. The minimal solver is ONE wave's latency chain (256 vector registers: two waves per SIMD, eight per CU) however
+// many of its lanes hold a sample; the scoring of a round's models is throughput work for all the waves of the workgroup. What a CU can
+// overlap is workgroups, and their number is set by the LDS of the solver lanes (3.1 KB per sample). Round 3: 256 threads and sixteen
+// samples, two pairs per CU (14.3 -> 10.9 ms per 1024 pairs for the stage against one). Round 4 swept the shape (tools/poses_bench.py
+// with GMS_TV_GEOM, two-view stage per 1024 pairs): 256 x 16 6.50 ms, 256 x 8 6.57, 192 x 12 6.89, 128 x 16 7.37 and 128 x 14 7.42
+// (three workgroups fit), 128 x 10 5.82, 128 x 8 6.16, 64 x 12 5.75, 64 x 6 7.43, 64 x 4 7.90, **128 x 12 5.4** -- four pairs per
+// CU, 37 KB each, one solver wave per SIMD and a second wave per pair for the scoring. At SfMUtil.cpp:39's confidence of 0.7 the mean
+// iteration count is 3.2: twelve samples are one round for almost every pair.
+template <int THREADS, int SOLVERS>
+__global__ void __launch_bounds__(THREADS, 2)  // (two waves per SIMD: the 256-register budget -- eight waves per CU)
 find_essential_kernel(EssentialParams prm, const gms_pair* __restrict__ pairs, const float2* __restrict__ coords1,
                       const float2* __restrict__ coords2, uint8_t* __restrict__ mask, gms_two_view* __restrict__ tv)
 {
-    __shared__ double s_A[200 * kSolvers];
-    __shared__ double s_basis[36 * kSolvers];
-    __shared__ double s_work[60 * kSolvers];
-    __shared__ double s_models[kSolvers * 10 * 9];  // [solver][model][9]
+    __shared__ double s_A[200 * SOLVERS];
+    __shared__ double s_basis[36 * SOLVERS];
+    __shared__ double s_work[60 * SOLVERS];
+    __shared__ double s_models[SOLVERS * 10 * 9];  // [solver][model][9]
     __shared__ double s_best[9];
-    __shared__ int s_samples[kSolvers * 5];
-    __shared__ int s_nmodels[kSolvers];
-    __shared__ unsigned s_counts[kSolvers * 10];
+    __shared__ int s_samples[SOLVERS * 5];
+    __shared__ int s_nmodels[SOLVERS];
+    __shared__ unsigned s_counts[SOLVERS * 10];
     __shared__ int s_ctl[4];  // [0] iteration bound, [1] iterations done, [2] best inlier count
+    static_assert(SOLVERS <= 64, "the solver lanes in one wave");
 
     const int p = (int)blockIdx.x, tid = (int)threadIdx.x, lane = tid & 63;
     const gms_pair pr = pairs[p];
@@ -116,7 +129,8 @@ find_essential_kernel(EssentialParams prm, const gms_pair* __restrict__ pairs, c
             norm1(idx, x1[j], y1[j]);
             norm2(idx, x2[j], y2[j]);
         }
-        tv::FivePointMem<LdsLane> mem{LdsLane{s_A + k}, LdsLane{s_basis + k}, LdsLane{s_work + k}};
+        using Lane = LdsLaneT<SOLVERS>;
+        tv::FivePointMem<Lane> mem{Lane{s_A + k}, Lane{s_basis + k}, Lane{s_work + k}};
         struct Out {
             double* base;
             __device__ __forceinline__ double& operator()(int i) const { return base[i]; }
@@ -150,22 +164,22 @@ find_essential_kernel(EssentialParams prm, const gms_pair* __restrict__ pairs, c
         // (A round solves sixteen samples in lockstep. Measured and dropped: a first round of four -- the lanes of a round run as many
         //  sweeps of the root finder as the slowest of them -- costs more in second rounds, each a whole solve's latency, than it saves:
         //  4.2 -> 5.0 ms per 1024 pairs at SfMUtil.cpp:39's confidence of 0.7, where the mean iteration count is 3.2.)
-        for (int it0 = 0, width = kSolvers;; it0 += width) {
+        for (int it0 = 0, width = SOLVERS;; it0 += width) {
             // (1) the samples of iterations it0 .. it0 + width - 1, in cv::RNG's order
             if (tid == 0)
                 for (int k = 0; k < width; ++k) rng.sample5(n, s_samples + 5 * k);
-            if (tid < kSolvers * 10) s_counts[tid] = 0u;
+            for (int i = tid; i < SOLVERS * 10; i += THREADS) s_counts[i] = 0u;
             __syncthreads();
             const int bound = s_ctl[0];
             const int live = min(width, bound - it0);  // iterations of this round that can still be reached
             // (2) sixteen minimal solves, one lane each
-            if (tid < kSolvers) {
+            if (tid < SOLVERS) {
                 if (tid < live) solve(tid);
                 else s_nmodels[tid] = 0;
             }
             __syncthreads();
             // (3) every model of the round against every correspondence
-            for (int base = 0; base < n; base += kTvThreads) {
+            for (int base = 0; base < n; base += THREADS) {
                 const int i = base + tid;
                 double x1 = 0.0, y1 = 0.0, x2 = 0.0, y2 = 0.0;
                 if (i < n) {
@@ -208,7 +222,7 @@ find_essential_kernel(EssentialParams prm, const gms_pair* __restrict__ pairs, c
     const int best_count = s_ctl[2];
     double E[9];
     for (int k = 0; k < 9; ++k) E[k] = s_best[k];
-    for (int i = tid; i < n; i += kTvThreads) {
+    for (int i = tid; i < n; i += THREADS) {
         uint8_t in = 0;
         if (best_count > 0) {
             if (n == 5) {
@@ -541,8 +555,14 @@ hipError_t launch_find_essential_batch(const gms_camera& cam, double prob, doubl
                                        const float* d_coords1, const float* d_coords2, uint8_t* d_mask, gms_two_view* d_tv, hipStream_t stream)
 {
     EssentialParams prm{cam.fx, cam.fy, cam.cx, cam.cy, prob, threshold, max_iters};
-    hipLaunchKernelGGL(find_essential_kernel, dim3((unsigned)n_pairs), dim3(kTvThreads), 0, stream, prm, d_pairs,
-                       reinterpret_cast<const float2*>(d_coords1), reinterpret_cast<const float2*>(d_coords2), d_mask, d_tv);
+    // GMS_TV_GEOM=0: round 3's workgroup shape (256 threads, sixteen samples per round), for A/B runs
+    static const bool wide = [] { const char* e = getenv("GMS_TV_GEOM"); return e && atoi(e) == 0; }();
+    if (wide)
+        hipLaunchKernelGGL((find_essential_kernel<kTvThreads, kSolvers>), dim3((unsigned)n_pairs), dim3(kTvThreads), 0, stream, prm, d_pairs,
+                           reinterpret_cast<const float2*>(d_coords1), reinterpret_cast<const float2*>(d_coords2), d_mask, d_tv);
+    else
+        hipLaunchKernelGGL((find_essential_kernel<128, 12>), dim3((unsigned)n_pairs), dim3(128), 0, stream, prm, d_pairs,
+                           reinterpret_cast<const float2*>(d_coords1), reinterpret_cast<const float2*>(d_coords2), d_mask, d_tv);
     return hipGetLastError();
 }
 
